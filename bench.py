@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec (forward) of ViT-B/16 with a Switch-MoE MLP (E=8, top-1) in every block,
+224x224, batch 256 per GPU -- BASELINE.json configs[1] -- plus the roofline of the dominant hot-path kernel
+(the grouped expert GEMM) and the CPU oracle timed beside it.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one eval-mode forward of the whole model over one batch of synthetic images already resident in
+HBM (reference harness: engine.py:88-121 -- eval(), no_grad, fp16 autocast).  The MoE operator (router,
+dispatch plan, token scatter, grouped GEMMs, combine) runs on the hand-written HIP kernels; the dense shell
+around it (patch embed, attention, LayerNorm, head) is ordinary torch.  N > 1 = expert parallel: the 8
+experts are partitioned over the ranks, every rank keeps 256 images (weak scaling) and tokens travel by
+RCCL all-to-all (slim_switch_moe_vit_amd/ep.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--experts", type=int, default=8, help="global number of experts")
+    ap.add_argument("--compute-dtype", default=os.environ.get("SLIMMOE_COMPUTE_DTYPE", "f16"), choices=["f16", "bf16", "f32"])
+    ap.add_argument("--ep-chunks", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8, help="images in the CPU-oracle sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-variant", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_model(args, world, rank, device):
+    """ViT-B/16 shell + MoE MLP in every block; random init of that architecture (no checkpoints offline).
+    Router / expert tensors are drawn for all E experts from one seed, then sliced per rank, so the
+    N-GPU model is the same function as the 1-GPU model."""
+    import slim_switch_moe_vit_amd as sm
+    from slim_switch_moe_vit_amd.vit import _deit
+    from slim_switch_moe_vit_amd.resmoe import patch_blocks_with_moe
+
+    E, d, h = args.experts, 768, 3072
+    assert E % world == 0, "experts must divide over ranks"
+    E_local = E // world
+    cd = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.compute_dtype]
+    torch.manual_seed(0)
+    model = _deit(768, 12, 12, num_classes=1000)
+    patch_blocks_with_moe(model, E_local, 1, False, world_size=world, compute_dtype=cd, gemm_variant=args.gemm_variant)
+    g = torch.Generator().manual_seed(1)
+    full_sd = {}  # all-E tensors for the oracle (rank 0, N=1 only keeps them)
+    with torch.no_grad():
+        for i, blk in enumerate(model.blocks):
+            wg = torch.randn(E, d, generator=g) * 0.02
+            w1 = torch.nn.init.trunc_normal_(torch.empty(E, h, d), std=0.02, a=-2, b=2, generator=g)
+            w2 = torch.nn.init.trunc_normal_(torch.empty(E, d, h), std=0.02, a=-2, b=2, generator=g)
+            blk.mlp.gate.gate.weight.copy_(wg)
+            blk.mlp.gate.gate.bias.zero_()
+            sl = slice(rank * E_local, (rank + 1) * E_local)
+            blk.mlp.experts.htoh4.weight.copy_(w1[sl]); blk.mlp.experts.htoh4.bias.zero_()
+            blk.mlp.experts.h4toh.weight.copy_(w2[sl]); blk.mlp.experts.h4toh.bias.zero_()
+            blk.mlp.ep_chunks = args.ep_chunks
+            # the head is zero-initialised in the reference (vision_transformer.py:859-861); give it signal
+        torch.nn.init.trunc_normal_(model.head.weight, std=0.02, a=-2, b=2, generator=g)
+    sd_cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return model.to(device).eval(), sd_cpu
+
+
+def cpu_baseline(sd, images, seconds):
+    """The CPU oracle (oracle/moe_oracle.py: 'port' of the path, fp32 torch on the host cores) on a bounded
+    sample of the same workload."""
+    from oracle import moe_oracle as mo
+
+    n = images.shape[0]
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        logits = mo.vit_forward(images, sd, depth=12, num_heads=12, k=1, residual_moe=False)
+        first = time.perf_counter() - t0
+        iters, t_acc = 0, 0.0
+        while t_acc < seconds and iters < 50:
+            t0 = time.perf_counter()
+            mo.vit_forward(images, sd, depth=12, num_heads=12, k=1, residual_moe=False)
+            t_acc += time.perf_counter() - t0
+            iters += 1
+    return n * iters / t_acc, logits, {"iters": iters, "first_call_s": round(first, 3)}
+
+
+def hot_path_parity(model, sd_cpu, device):
+    """Layer-0 MoE operator on cfg-2-sized random tokens vs the oracle (routing on all tokens, expert
+    outputs on a 1024-token sample)."""
+    from oracle import moe_oracle as mo
+
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(256 * 197, 768, generator=g)
+    mlp = model.blocks[0].mlp
+    with torch.no_grad():
+        out = mlp(x.to(device).reshape(256, 197, 768)).reshape(-1, 768).cpu()
+    pre = "blocks.0.mlp."
+    wg, bg = sd_cpu[pre + "gate.gate.weight"], sd_cpu[pre + "gate.gate.bias"]
+    o_idx, _, _ = mo.naive_gate(x, wg, bg, 1)
+    routing_exact = bool(torch.equal(mlp.last_plan[0].cpu(), o_idx))
+    sel = torch.randperm(x.shape[0], generator=g)[:1024]
+    r = mo.moe_forward(x[sel], wg, bg, sd_cpu[pre + "experts.htoh4.weight"], sd_cpu[pre + "experts.htoh4.bias"],
+                       sd_cpu[pre + "experts.h4toh.weight"], sd_cpu[pre + "experts.h4toh.bias"], 1)
+    return {"routing_bit_exact": routing_exact, "expert_out_max_abs_err": float((out[sel] - r.out).abs().max()),
+            "tolerance": 1e-3, "sample_tokens": 1024}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from slim_switch_moe_vit_amd import ops
+
+    model, sd_cpu = build_model(args, world, rank, device)
+    gi = torch.Generator().manual_seed(100 + rank)
+    images_cpu = torch.randn(args.batch, 3, 224, 224, generator=gi)   # synthetic, never zero-filled
+    images = images_cpu.to(device)
+
+    def step():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return model(images)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel accounting from the HIP events recorded inside the timed region --------------------
+    agg = {}
+    for name, meta, ms in prof:
+        a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        a["launches"] += 1
+        a["ms"] += ms
+        a["flops"] += meta.get("flops", 0.0)
+        a["bytes"] += meta.get("bytes", 0.0)
+    kernels = {}
+    for name, a in agg.items():
+        ent = {"launches_per_step": a["launches"] / args.steps, "avg_ms": a["ms"] / a["launches"]}
+        if a["flops"]:
+            ent["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        if a["bytes"]:
+            ent["gbs"] = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+        kernels[name] = {k: round(v, 4) for k, v in ent.items()}
+    roofline = None
+    if "grouped_gemm" in agg:
+        a = agg["grouped_gemm"]
+        achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.compute_dtype]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("grouped_gemm_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "grouped_gemm (expert FFN, both linears)", "bound": "mfma", "achieved": round(achieved, 2),
+                    "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "avg_launch_ms": round(a["ms"] / a["launches"], 4),
+                    "flops_per_launch": a["flops"] / a["launches"]}
+
+    if rank == 0:
+        total_images = args.batch * world * args.steps
+        out = {
+            "metric": "images/sec (fwd) ViT-B/16 E=8 @224^2",
+            "value": round(total_images / elapsed, 2),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.compute_dtype,
+            "data": "synthetic",
+            "config": {"workload": f"ViT-B/16 Switch-MoE E={args.experts} top-1, 224^2, batch {args.batch}/GPU, "
+                                   f"full eval forward (12 blocks: attention + MoE MLP), fp16 autocast",
+                       "global_batch": args.batch * world, "tokens_per_image": 197,
+                       "parallelism": "single" if world == 1 else f"ep{world} (experts/{world} per rank, all-to-all, {args.ep_chunks} chunks)"},
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        moe_ms = sum(a["ms"] for a in agg.values()) / args.steps
+        out["hot_path"] = {"moe_kernels_ms_per_step": round(moe_ms, 3),
+                           "share_of_step": round(moe_ms / (elapsed / args.steps * 1e3), 3)}
+        if world == 1 and sd_cpu is not None:
+            ips, cpu_logits, info = cpu_baseline(sd_cpu, images_cpu[: args.cpu_batch], args.cpu_seconds)
+            out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+                                   "kind": "port",
+                                   "sample": f"oracle vit_forward (fp32 torch CPU), same model, batch {args.cpu_batch}, "
+                                             f"{info['iters']} iterations"}
+            out["speedup_vs_cpu"] = round(out["value"] / ips, 1)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                gl = model(images[: args.cpu_batch]).float().cpu()
+            out["parity"] = hot_path_parity(model, sd_cpu, device)
+            out["parity"]["model_logits_max_abs_diff_vs_cpu_fp32"] = float((gl - cpu_logits).abs().max())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+/* slimmoe.h -- C-ABI of libslimmoe_hip.so: MI355X (gfx950) kernels for the Switch-MoE ViT hot path.
+ *
+ * Drop-in boundary.  The reference (d0-rb/slim-switch-moe-vit) has no FFI of its own: its MoE
+ * operator is `from fmoe import FMoETransformerMLP` (models/resMoE.py:6, ctor at 27-29, forward at
+ * 121/143 and models/vision_transformer.py:321), and FastMoE in turn binds a pybind module
+ * `fmoe_cuda` (expert_count, assign_pos, linear_forward, limit_by_capacity, prune_gate_by_capacity,
+ * global_scatter/gather ...).  The entry points below are what a binding
+ * for that op set would bind; each comment names the upstream op it replaces.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
+ *    (torch tensors), contiguous, 16-byte aligned; nothing here allocates, frees or synchronises,
+ *    so every call is graph-capturable;
+ *  - all launches go to `stream` (a hipStream_t passed as void*);
+ *  - return 0 on success, non-zero on error; smoe_last_error() gives the thread-local message;
+ *  - dtype codes: SMOE_F32 / SMOE_F16 / SMOE_BF16.
+ */
+#ifndef SLIMMOE_H
+#define SLIMMOE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SMOE_F32 = 0, SMOE_F16 = 1, SMOE_BF16 = 2 };
+enum { SMOE_GATE_NAIVE = 0, SMOE_GATE_SWITCH = 1 };
+enum { SMOE_EPI_NONE = 0, SMOE_EPI_GELU = 1 };
+
+/* library ABI version (bumped on any signature change) */
+int smoe_abi_version(void);
+/* message for the last non-zero return on this thread */
+const char* smoe_last_error(void);
+
+/* ---- router ------------------------------------------------------------------------------------
+ * Replaces fmoe NaiveGate.forward / SwitchGate.forward (gate = nn.Linear(d,E): evidenced by
+ * models/resmoe_flop_hook.py:7-8; selected at models/resMoE.py:26-29).
+ *   logits = x @ wg^T + bg           accumulated in f64, rounded once to f32
+ *   NAIVE : (val, idx) = top-k(logits) [ties: lowest expert id; descending logit]; score = softmax(val)
+ *   SWITCH: k == 1; p = softmax(logits + noise) over all E; idx = argmax; score = p[idx];
+ *           probs (may be NULL) receives p [T,E] for the aux loss.
+ * x [T,d] (x_dtype), wg [E,d] f32, bg [E] f32 or NULL, noise [T,E] f32 or NULL.
+ * idx [T,k] i64, score [T,k] f32, logits_out [T,E] f32 or NULL.
+ * Requires d % 8 == 0, d <= 2048, 1 <= k <= E, k <= 8.                                         */
+int smoe_router_topk(const void* x, int x_dtype, const float* wg, const float* bg, const float* noise,
+                     int64_t T, int d, int E, int k, int gate_kind,
+                     int64_t* idx, float* score, float* logits_out, float* probs, void* stream);
+
+/* ---- dispatch plan --------------------------------------------------------------------------------
+ * Replaces fmoe_cuda.expert_count + cumsum + assign_pos (+ limit_by_capacity /
+ * prune_gate_by_capacity) = fmoe count_by_gate / prepare_forward.
+ * Deterministic stable counting sort of the n = T*k flat entries by expert id:
+ *   counts[e]  = kept entries on e (min(raw, capacity) when capacity >= 0)
+ *   offsets    = exclusive prefix of counts, offsets[E] = kept total
+ *   pos[s]     = flat index t*k+j of slot s (ascending flat index inside an expert); -1 for s >= kept
+ *   inv_pos[i] = slot of flat entry i, -1 if dropped (idx < 0 or over capacity)
+ *   idx_pruned = idx with dropped entries set to -1 (may be NULL when capacity < 0)
+ * idx values must lie in [-1, E).  workspace: smoe_dispatch_plan_workspace_bytes(n, E) bytes.   */
+size_t smoe_dispatch_plan_workspace_bytes(int64_t n, int E);
+int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t capacity,
+                       int32_t* counts, int32_t* offsets, int64_t* pos, int64_t* inv_pos,
+                       int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- token scatter (MOEScatter.forward local part: index_select(x, 0, pos // k)) ----
+ * buf[s,:] = cast(x[pos[s] / k, :]) for every slot s < n_slots with pos[s] >= 0; other rows untouched.
+ * x [T,d], buf [n_slots,d]; d % 8 == 0.                                                            */
+int smoe_scatter_rows(const void* x, int x_dtype, const int64_t* pos, int64_t n_slots, int k, int d,
+                      void* buf, int buf_dtype, void* stream);
+
+/* ---- gather + combine (MOEGather.forward + bmm(gate_score, y)) -------------------
+ * out[t,:] = sum_j score[t,j] * y[inv_pos[t*k+j], :]   (a dropped entry contributes 0)
+ * optional fused residual add (the `+ tk + skip_tk` of models/resMoE.py:143): out[t,:] += residual[t,:]
+ * when residual != NULL (same dtype as out).  y [n_slots,d] (y_dtype), out [T,d] (out_dtype).       */
+int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, const float* score,
+                        int64_t T, int k, int d, const void* residual, void* out, int out_dtype,
+                        void* stream);
+
+/* ---- grouped (variable-batch) expert GEMM on MFMA ----------------------------------------------------
+ * Replaces fmoe_cuda.linear_forward = MOELinear / FMoELinear: for each local
+ * expert e, rows r in [offsets[e], offsets[e+1]):
+ *     out[r, :] = epilogue( A[r, :] @ W[e]^T + bias[e] )          W [E,N,K] row-major ([out,in])
+ * One launch for all experts; the tile -> (expert, m-tile) map is derived on device from `offsets`
+ * (no host sync; empty experts are fine).  m_rows_max = upper bound on offsets[E] (rows allocated in A/out).
+ * ab_dtype: SMOE_F16 / SMOE_BF16 (MFMA 16-bit inputs, f32 accumulate) or SMOE_F32 (exact f32 MFMA).
+ * bias f32 [E,N] or NULL.  epilogue SMOE_EPI_GELU = exact-erf GELU (models/resMoE.py:23-25).
+ * Optional fused combine for top-1 (row_map != NULL): row r is stored to out[row_map[r], :]
+ * multiplied by row_scale[row_map[r]] if row_scale != NULL  (MOEGather + bmm for k = 1).
+ * Optional group -> expert map (group_expert != NULL, i32 [G]): `offsets` then delimits G row groups and
+ * group g uses W[group_expert[g]] / bias[group_expert[g]] (expert-parallel receive layout: one group per
+ * (source rank, local expert)); n_experts = leading dimension of W / bias.
+ * Requires K*sizeof(ab) % 128 == 0 and N % 8 == 0.                                                  */
+int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int32_t* offsets,
+                      const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
+                      int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,
+                      void* out, int out_dtype, int variant, void* stream);
+
+/* ---- small helpers ------------------------------------------------------------------------------------
+ * elementwise cast between dtypes (weight shadow copies; not on the per-step path)                  */
+int smoe_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLIMMOE_H */

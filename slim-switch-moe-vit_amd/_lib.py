@@ -1,0 +1,70 @@
+"""ctypes loader for libslimmoe_hip.so (the C-ABI in include/slimmoe.h).
+
+There is no CPU fallback: if the library is missing or lacks a symbol this module raises, so a
+product path can never silently run on something other than the HIP kernels."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: the library resolves libamdhip64.so.7 to torch's runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslimmoe_hip.so")
+ABI_VERSION = 1
+
+c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/slimmoe.h one to one
+SIGNATURES = {
+    "smoe_abi_version": (c_int, []),
+    "smoe_last_error": (ctypes.c_char_p, []),
+    "smoe_router_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "smoe_dispatch_plan_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "smoe_dispatch_plan": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "smoe_scatter_rows": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "smoe_gather_combine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
+                                    c_int, c_void_p]),
+    "smoe_grouped_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
+                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "smoe_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+class SlimMoEError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises SlimMoEError if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlimMoEError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the MoE hot path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise SlimMoEError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.smoe_abi_version()
+    if got != ABI_VERSION:
+        raise SlimMoEError(f"libslimmoe_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().smoe_last_error()
+        raise SlimMoEError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

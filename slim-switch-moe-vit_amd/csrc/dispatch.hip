@@ -1,0 +1,401 @@
+// Dispatch plan (histogram + stable counting sort + capacity prune), token scatter, gather+combine.
+// Replaces fmoe_cuda.expert_count / assign_pos / limit_by_capacity / prune_gate_by_capacity and the
+// index_select / index_copy_ / bmm of MOEScatter / MOEGather (N1-N3, N6-N9).
+//
+// Plan = three small launches over n = T*k flat entries, chunked CH entries per workgroup:
+//   plan_count : per-chunk LDS histogram                    -> blockcnt[nblk][E]
+//   plan_scan  : per expert, exclusive scan over chunks      -> rawbase[nblk][E], counts, offsets
+//   plan_assign: per chunk, stable rank of each entry among same-expert entries with lower flat
+//                index (wave ballot + LDS running counters) -> pos / inv_pos / idx_pruned
+// Upstream orders slots by atomicSub race; here slot order is ascending flat index (deterministic),
+// and with a capacity an entry is kept iff its raw rank in its expert is < capacity.
+#include "smoe_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int PLAN_THREADS = 256;
+constexpr int PLAN_WAVES = PLAN_THREADS / 64;
+constexpr int PLAN_ITERS = 4;                                   // 64-entry steps per wave
+constexpr int PLAN_CH = PLAN_THREADS * PLAN_ITERS;              // entries per workgroup
+
+__global__ __launch_bounds__(PLAN_THREADS) void plan_count_kernel(const int64_t* __restrict__ idx, int64_t n, int E,
+                                                                  int32_t* __restrict__ blockcnt,
+                                                                  int32_t* __restrict__ err_flag) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* hist = reinterpret_cast<int32_t*>(smem);
+  for (int e = threadIdx.x; e < E; e += PLAN_THREADS) hist[e] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * PLAN_CH;
+#pragma unroll
+  for (int it = 0; it < PLAN_ITERS; ++it) {
+    const int64_t i = base + it * PLAN_THREADS + threadIdx.x;
+    if (i < n) {
+      const int64_t e = idx[i];
+      if (e >= 0 && e < E) atomicAdd(&hist[(int)e], 1);
+      else if (e >= E || e < -1) atomicOr(err_flag, 1);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += PLAN_THREADS) blockcnt[(int64_t)blockIdx.x * E + e] = hist[e];
+}
+
+// single workgroup.  rawbase[b][e] = sum_{b'<b} blockcnt[b'][e]; counts[e] = min(total, cap); offsets = prefix.
+__global__ __launch_bounds__(1024) void plan_scan_kernel(const int32_t* __restrict__ blockcnt, int nblk, int E,
+                                                         int64_t capacity, int32_t* __restrict__ rawbase,
+                                                         int32_t* __restrict__ counts, int32_t* __restrict__ offsets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* cnt = reinterpret_cast<int32_t*>(smem);  // [E]
+  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+    int32_t run = 0;
+    for (int b = 0; b < nblk; ++b) {
+      const int32_t c = blockcnt[(int64_t)b * E + e];
+      rawbase[(int64_t)b * E + e] = run;
+      run += c;
+    }
+    if (capacity >= 0 && (int64_t)run > capacity) run = (int32_t)capacity;
+    cnt[e] = run;
+    counts[e] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t run = 0;
+    for (int e = 0; e < E; ++e) {
+      offsets[e] = run;
+      run += cnt[e];
+    }
+    offsets[E] = run;
+  }
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
+    const int64_t* __restrict__ idx, int64_t n, int E, int64_t capacity, const int32_t* __restrict__ rawbase,
+    const int32_t* __restrict__ offsets, int64_t* __restrict__ pos, int64_t* __restrict__ inv_pos,
+    int64_t* __restrict__ idx_pruned) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // run[w][e]: raw rank of the next entry of expert e seen by wave w (wave w owns a contiguous quarter of the chunk)
+  int32_t* run = reinterpret_cast<int32_t*>(smem);  // [PLAN_WAVES][E]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t chunk_base = (int64_t)blockIdx.x * PLAN_CH;
+  const int64_t wave_base = chunk_base + (int64_t)wave * (64 * PLAN_ITERS);
+
+  for (int i = tid; i < PLAN_WAVES * E; i += PLAN_THREADS) run[i] = 0;
+  __syncthreads();
+  // pass 1: per-wave histogram of its quarter
+  int64_t myidx[PLAN_ITERS];
+#pragma unroll
+  for (int it = 0; it < PLAN_ITERS; ++it) {
+    const int64_t i = wave_base + it * 64 + lane;
+    int64_t e = -1;
+    if (i < n) e = idx[i];
+    if (e >= E) e = -1;
+    myidx[it] = e;
+    if (e >= 0) atomicAdd(&run[wave * E + (int)e], 1);
+  }
+  __syncthreads();
+  // turn per-wave counts into per-wave starting raw ranks: rawbase[b][e] + sum_{w'<w} cnt[w'][e]
+  for (int e = tid; e < E; e += PLAN_THREADS) {
+    int32_t acc = rawbase[(int64_t)blockIdx.x * E + e];
+#pragma unroll
+    for (int w = 0; w < PLAN_WAVES; ++w) {
+      const int32_t c = run[w * E + e];
+      run[w * E + e] = acc;
+      acc += c;
+    }
+  }
+  __syncthreads();
+  // pass 2: in flat-index order inside the wave's quarter
+  int32_t* myrun = run + wave * E;
+#pragma unroll
+  for (int it = 0; it < PLAN_ITERS; ++it) {
+    const int64_t i = wave_base + it * 64 + lane;
+    const int e = (int)myidx[it];
+    // rank among lanes of this step with the same expert: peel one distinct expert per round
+    int rank_in_step = 0, group = 0;
+    unsigned long long todo = __ballot(e >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int e0 = __shfl(e, leader, 64);
+      const unsigned long long m = __ballot(e == e0);
+      if (e == e0) {
+        rank_in_step = __popcll(m & ((1ull << lane) - 1ull));
+        group = __popcll(m);
+      }
+      todo &= ~m;
+    }
+    if (e >= 0) {
+      const int32_t raw = myrun[e] + rank_in_step;
+      const bool keep = (capacity < 0) || ((int64_t)raw < capacity);
+      if (keep) {
+        const int64_t slot = (int64_t)offsets[e] + raw;
+        pos[slot] = i;
+        inv_pos[i] = slot;
+      } else {
+        inv_pos[i] = -1;
+      }
+      if (idx_pruned) idx_pruned[i] = keep ? (int64_t)e : -1;
+    } else if (i < n) {
+      inv_pos[i] = -1;
+      if (idx_pruned) idx_pruned[i] = -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the first lane of each expert group advances that expert's running rank
+    if (e >= 0 && rank_in_step == 0) myrun[e] += group;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// fill the tail pos[kept .. n) with -1
+__global__ void plan_tail_kernel(const int32_t* __restrict__ offsets, int E, int64_t n, int64_t* __restrict__ pos) {
+  const int64_t kept = offsets[E];
+  for (int64_t i = kept + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    pos[i] = -1;
+}
+
+// ------------------------------------------------------------------------------------------------ rows
+// one wave per slot; 8 elements per lane per step
+template <typename XT, typename BT>
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const XT* __restrict__ x, const int64_t* __restrict__ pos,
+                                                           int64_t n_slots, int k, int d, BT* __restrict__ buf) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t s = wave_gid; s < n_slots; s += nwaves) {
+    const int64_t p = pos[s];
+    if (p < 0) continue;  // wave-uniform
+    const XT* src = x + (p / k) * (int64_t)d;
+    BT* dst = buf + s * (int64_t)d;
+    for (int c = lane * 8; c < d; c += 512) {
+      float v[8];
+      load8(src + c, v);
+      store8(dst + c, v);
+    }
+  }
+}
+
+template <typename YT, typename OT, int KMAX>
+__global__ __launch_bounds__(256) void gather_combine_kernel(const YT* __restrict__ y,
+                                                             const int64_t* __restrict__ inv_pos,
+                                                             const float* __restrict__ score, int64_t T, int k, int d,
+                                                             const OT* __restrict__ residual, OT* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave_gid; t < T; t += nwaves) {
+    int64_t slot[KMAX];
+    float sc[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      slot[j] = (j < k) ? inv_pos[t * k + j] : -1;
+      sc[j] = (j < k) ? score[t * k + j] : 0.f;
+    }
+    for (int c = lane * 8; c < d; c += 512) {
+      float acc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        if (slot[j] >= 0) {
+          float v[8];
+          load8(y + slot[j] * (int64_t)d + c, v);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[q] = fmaf(sc[j], v[q], acc[q]);
+        }
+      }
+      if (residual) {
+        float r[8];
+        load8(residual + t * (int64_t)d + c, r);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += r[q];
+      }
+      store8(out + t * (int64_t)d + c, acc);
+    }
+  }
+}
+
+template <typename ST, typename DT>
+__global__ __launch_bounds__(256) void cast_kernel(const ST* __restrict__ src, DT* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      float v[8];
+      load8(src + i, v);
+      store8(dst + i, v);
+    } else {
+      for (int64_t j = i; j < n; ++j) {
+        float v[4];
+        // scalar tail
+        if constexpr (sizeof(ST) == 4) v[0] = ((const float*)src)[j];
+        else if constexpr (std::is_same<ST, f16>::value) v[0] = (float)((const f16*)src)[j];
+        else v[0] = bf16_to_f32(((const bf16_bits*)src)[j]);
+        if constexpr (sizeof(DT) == 4) ((float*)dst)[j] = v[0];
+        else if constexpr (std::is_same<DT, f16>::value) ((f16*)dst)[j] = (f16)v[0];
+        else ((bf16_bits*)dst)[j] = f32_to_bf16(v[0]);
+      }
+    }
+  }
+}
+
+inline int rows_grid(int64_t rows) {
+  int64_t blocks = (rows + 3) / 4;  // 4 waves per workgroup
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  return (int)blocks;
+}
+
+template <typename XT>
+int scatter_dispatch_b(const void* x, const int64_t* pos, int64_t n_slots, int k, int d, void* buf, int buf_dtype,
+                       hipStream_t s) {
+  const int grid = rows_grid(n_slots);
+  switch (buf_dtype) {
+    case SMOE_F32:
+      hipLaunchKernelGGL((scatter_rows_kernel<XT, float>), dim3(grid), dim3(256), 0, s, (const XT*)x, pos, n_slots, k, d, (float*)buf);
+      break;
+    case SMOE_F16:
+      hipLaunchKernelGGL((scatter_rows_kernel<XT, f16>), dim3(grid), dim3(256), 0, s, (const XT*)x, pos, n_slots, k, d, (f16*)buf);
+      break;
+    case SMOE_BF16:
+      hipLaunchKernelGGL((scatter_rows_kernel<XT, bf16_bits>), dim3(grid), dim3(256), 0, s, (const XT*)x, pos, n_slots, k, d, (bf16_bits*)buf);
+      break;
+    default:
+      smoe_set_error("smoe_scatter_rows: bad buf_dtype %d", buf_dtype);
+      return 1;
+  }
+  SMOE_CHECK_LAUNCH("smoe_scatter_rows");
+  return 0;
+}
+
+template <typename YT, typename OT>
+int combine_launch(const void* y, const int64_t* inv_pos, const float* score, int64_t T, int k, int d,
+                   const void* residual, void* out, hipStream_t s) {
+  const int grid = rows_grid(T);
+  if (k == 1)
+    hipLaunchKernelGGL((gather_combine_kernel<YT, OT, 1>), dim3(grid), dim3(256), 0, s, (const YT*)y, inv_pos, score, T, k, d, (const OT*)residual, (OT*)out);
+  else if (k == 2)
+    hipLaunchKernelGGL((gather_combine_kernel<YT, OT, 2>), dim3(grid), dim3(256), 0, s, (const YT*)y, inv_pos, score, T, k, d, (const OT*)residual, (OT*)out);
+  else if (k <= 4)
+    hipLaunchKernelGGL((gather_combine_kernel<YT, OT, 4>), dim3(grid), dim3(256), 0, s, (const YT*)y, inv_pos, score, T, k, d, (const OT*)residual, (OT*)out);
+  else
+    hipLaunchKernelGGL((gather_combine_kernel<YT, OT, 8>), dim3(grid), dim3(256), 0, s, (const YT*)y, inv_pos, score, T, k, d, (const OT*)residual, (OT*)out);
+  SMOE_CHECK_LAUNCH("smoe_gather_combine");
+  return 0;
+}
+
+template <typename YT>
+int combine_dispatch_o(const void* y, const int64_t* inv_pos, const float* score, int64_t T, int k, int d,
+                       const void* residual, void* out, int out_dtype, hipStream_t s) {
+  switch (out_dtype) {
+    case SMOE_F32: return combine_launch<YT, float>(y, inv_pos, score, T, k, d, residual, out, s);
+    case SMOE_F16: return combine_launch<YT, f16>(y, inv_pos, score, T, k, d, residual, out, s);
+    case SMOE_BF16: return combine_launch<YT, bf16_bits>(y, inv_pos, score, T, k, d, residual, out, s);
+  }
+  smoe_set_error("smoe_gather_combine: bad out_dtype %d", out_dtype);
+  return 1;
+}
+
+template <typename ST>
+int cast_dispatch_d(const void* src, void* dst, int dst_dtype, int64_t n, hipStream_t s) {
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  switch (dst_dtype) {
+    case SMOE_F32: hipLaunchKernelGGL((cast_kernel<ST, float>), dim3((int)blocks), dim3(256), 0, s, (const ST*)src, (float*)dst, n); break;
+    case SMOE_F16: hipLaunchKernelGGL((cast_kernel<ST, f16>), dim3((int)blocks), dim3(256), 0, s, (const ST*)src, (f16*)dst, n); break;
+    case SMOE_BF16: hipLaunchKernelGGL((cast_kernel<ST, bf16_bits>), dim3((int)blocks), dim3(256), 0, s, (const ST*)src, (bf16_bits*)dst, n); break;
+    default: smoe_set_error("smoe_cast: bad dst_dtype %d", dst_dtype); return 1;
+  }
+  SMOE_CHECK_LAUNCH("smoe_cast");
+  return 0;
+}
+
+inline int64_t plan_nblk(int64_t n) { return n > 0 ? (n + PLAN_CH - 1) / PLAN_CH : 1; }
+
+}  // namespace
+
+// workspace layout: [err_flag pad to 16 B][blockcnt nblk*E i32][rawbase nblk*E i32]
+extern "C" size_t smoe_dispatch_plan_workspace_bytes(int64_t n, int E) {
+  if (n < 0 || E <= 0) return 0;
+  const size_t per = (((size_t)plan_nblk(n) * (size_t)E * 4) + 15) & ~(size_t)15;
+  return 16 + 2 * per;
+}
+
+extern "C" int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t capacity, int32_t* counts,
+                                  int32_t* offsets, int64_t* pos, int64_t* inv_pos, int64_t* idx_pruned,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  SMOE_REQUIRE(counts && offsets && workspace, "smoe_dispatch_plan: null pointer");
+  SMOE_REQUIRE(n >= 0 && n < (1ll << 31), "smoe_dispatch_plan: n=%lld out of range", (long long)n);
+  SMOE_REQUIRE(E >= 1 && E <= 8192, "smoe_dispatch_plan: E=%d out of range [1, 8192]", E);
+  SMOE_REQUIRE(n == 0 || (idx && pos && inv_pos), "smoe_dispatch_plan: null pointer");
+  SMOE_REQUIRE(workspace_bytes >= smoe_dispatch_plan_workspace_bytes(n, E),
+               "smoe_dispatch_plan: workspace too small (%zu < %zu)", workspace_bytes,
+               smoe_dispatch_plan_workspace_bytes(n, E));
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nblk = plan_nblk(n);
+  const size_t per = (((size_t)nblk * (size_t)E * 4) + 15) & ~(size_t)15;
+  int32_t* err_flag = reinterpret_cast<int32_t*>(workspace);
+  int32_t* blockcnt = reinterpret_cast<int32_t*>((char*)workspace + 16);
+  int32_t* rawbase = reinterpret_cast<int32_t*>((char*)workspace + 16 + per);
+  hipError_t me = hipMemsetAsync(workspace, 0, 16, s);
+  SMOE_REQUIRE(me == hipSuccess, "smoe_dispatch_plan: memset failed: %s", hipGetErrorString(me));
+  hipLaunchKernelGGL(plan_count_kernel, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)E * 4, s, idx, n, E, blockcnt, err_flag);
+  SMOE_CHECK_LAUNCH("smoe_dispatch_plan/count");
+  const int scan_threads = E < 64 ? 64 : (E > 1024 ? 1024 : ((E + 63) / 64) * 64);
+  hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(scan_threads), (size_t)E * 4, s, blockcnt, (int)nblk, E, capacity, rawbase, counts, offsets);
+  SMOE_CHECK_LAUNCH("smoe_dispatch_plan/scan");
+  if (n > 0) {
+    hipLaunchKernelGGL(plan_assign_kernel, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)PLAN_WAVES * E * 4, s, idx, n, E, capacity, rawbase, offsets, pos, inv_pos, idx_pruned);
+    SMOE_CHECK_LAUNCH("smoe_dispatch_plan/assign");
+    int tb = (int)((n + 255) / 256);
+    if (tb > 1024) tb = 1024;
+    hipLaunchKernelGGL(plan_tail_kernel, dim3(tb), dim3(256), 0, s, offsets, E, n, pos);
+    SMOE_CHECK_LAUNCH("smoe_dispatch_plan/tail");
+  }
+  return 0;
+}
+
+extern "C" int smoe_scatter_rows(const void* x, int x_dtype, const int64_t* pos, int64_t n_slots, int k, int d,
+                                 void* buf, int buf_dtype, void* stream) {
+  SMOE_REQUIRE(n_slots >= 0 && k >= 1 && d > 0 && d % 8 == 0, "smoe_scatter_rows: bad sizes n_slots=%lld k=%d d=%d",
+               (long long)n_slots, k, d);
+  if (n_slots == 0) return 0;
+  SMOE_REQUIRE(x && pos && buf, "smoe_scatter_rows: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  switch (x_dtype) {
+    case SMOE_F32: return scatter_dispatch_b<float>(x, pos, n_slots, k, d, buf, buf_dtype, s);
+    case SMOE_F16: return scatter_dispatch_b<f16>(x, pos, n_slots, k, d, buf, buf_dtype, s);
+    case SMOE_BF16: return scatter_dispatch_b<bf16_bits>(x, pos, n_slots, k, d, buf, buf_dtype, s);
+  }
+  smoe_set_error("smoe_scatter_rows: bad x_dtype %d", x_dtype);
+  return 1;
+}
+
+extern "C" int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, const float* score, int64_t T,
+                                   int k, int d, const void* residual, void* out, int out_dtype, void* stream) {
+  SMOE_REQUIRE(T >= 0 && k >= 1 && k <= 8 && d > 0 && d % 8 == 0, "smoe_gather_combine: bad sizes T=%lld k=%d d=%d",
+               (long long)T, k, d);
+  if (T == 0) return 0;
+  SMOE_REQUIRE(y && inv_pos && score && out, "smoe_gather_combine: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  switch (y_dtype) {
+    case SMOE_F32: return combine_dispatch_o<float>(y, inv_pos, score, T, k, d, residual, out, out_dtype, s);
+    case SMOE_F16: return combine_dispatch_o<f16>(y, inv_pos, score, T, k, d, residual, out, out_dtype, s);
+    case SMOE_BF16: return combine_dispatch_o<bf16_bits>(y, inv_pos, score, T, k, d, residual, out, out_dtype, s);
+  }
+  smoe_set_error("smoe_gather_combine: bad y_dtype %d", y_dtype);
+  return 1;
+}
+
+extern "C" int smoe_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+  SMOE_REQUIRE(n >= 0, "smoe_cast: n < 0");
+  if (n == 0) return 0;
+  SMOE_REQUIRE(src && dst, "smoe_cast: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  switch (src_dtype) {
+    case SMOE_F32: return cast_dispatch_d<float>(src, dst, dst_dtype, n, s);
+    case SMOE_F16: return cast_dispatch_d<f16>(src, dst, dst_dtype, n, s);
+    case SMOE_BF16: return cast_dispatch_d<bf16_bits>(src, dst, dst_dtype, n, s);
+  }
+  smoe_set_error("smoe_cast: bad src_dtype %d", src_dtype);
+  return 1;
+}

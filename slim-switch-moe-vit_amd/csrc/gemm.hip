@@ -1,0 +1,319 @@
+// Grouped (variable-batch) expert GEMM on MFMA.  Replaces fmoe_cuda.linear_forward (MOELinear /
+// FMoELinear):  out[r,:] = epi(A[r,:] @ W[e]^T + bias[e])  for r in expert e's slice.
+//
+// One launch covers every expert.  The grid is an upper bound (ceil(M/BM) + E m-tiles); each workgroup
+// finds its (expert, m-tile) from `offsets` on device, surplus workgroups exit.  No host sync.
+//
+// variant 0 ("t128"): 128x128x64 tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 (f16/bf16) or
+// 16x16x4 (f32-exact).  Operands are staged global -> VGPR -> LDS (XOR-swizzled 128-B rows, 16-B chunks:
+// chunk' = chunk ^ ((row>>1)&7), conflict-free for the ds_read_b128 fragment reads), double-buffered.
+// MFMA runs "swapped" (W fragment as the A operand) so every lane ends up with 4 consecutive output
+// columns of one token row -> 8-byte LDS writes in the epilogue; the output tile then leaves through
+// LDS as whole 16-B-per-lane row segments (optionally scattered through row_map = fused combine).
+#include "smoe_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128, BK_BYTES = 128;  // K-step = 128 bytes of a row (64 halfs / 32 floats)
+constexpr int GEMM_THREADS = 256;
+constexpr int STAGE_BYTES = (BM + BN) * BK_BYTES;  // 32 KiB
+constexpr int C_PAD = 16;                          // bytes
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * BK_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename OT> struct OutPack;
+template <> struct OutPack<float> {
+  static constexpr int bytes = 4;
+  __device__ static void write4(char* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct OutPack<f16> {
+  static constexpr int bytes = 2;
+  __device__ static void write4(char* p, const f32x4& v) {
+    f16x4 t; t[0] = (f16)v[0]; t[1] = (f16)v[1]; t[2] = (f16)v[2]; t[3] = (f16)v[3];
+    *reinterpret_cast<f16x4*>(p) = t;
+  }
+};
+template <> struct OutPack<bf16_bits> {
+  static constexpr int bytes = 2;
+  __device__ static void write4(char* p, const f32x4& v) {
+    s16x4 t; t[0] = (short)f32_to_bf16(v[0]); t[1] = (short)f32_to_bf16(v[1]); t[2] = (short)f32_to_bf16(v[2]); t[3] = (short)f32_to_bf16(v[3]);
+    *reinterpret_cast<s16x4*>(p) = t;
+  }
+};
+
+// scale 16 bytes of output elements in place (fused combine)
+template <typename OT> __device__ __forceinline__ u32x4 scale16(u32x4 raw, float s);
+template <> __device__ __forceinline__ u32x4 scale16<float>(u32x4 raw, float s) {
+  f32x4 v = __builtin_bit_cast(f32x4, raw);
+  v *= s;
+  return __builtin_bit_cast(u32x4, v);
+}
+template <> __device__ __forceinline__ u32x4 scale16<f16>(u32x4 raw, float s) {
+  f16x8 v = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (f16)((float)v[i] * s);
+  return __builtin_bit_cast(u32x4, v);
+}
+template <> __device__ __forceinline__ u32x4 scale16<bf16_bits>(u32x4 raw, float s) {
+  s16x8 v = __builtin_bit_cast(s16x8, raw);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (short)f32_to_bf16(bf16_to_f32((unsigned short)v[i]) * s);
+  return __builtin_bit_cast(u32x4, v);
+}
+
+// locate the (expert, row range) of global m-tile `mt`; returns false if there is no such tile
+__device__ __forceinline__ bool find_tile(const int32_t* __restrict__ offsets, int E, int mt, int& e_out, int& m0,
+                                          int& m_end) {
+  int tile_base = 0;
+  for (int e = 0; e < E; ++e) {
+    const int lo = offsets[e], hi = offsets[e + 1];
+    const int nt = (hi - lo + BM - 1) / BM;
+    if (mt < tile_base + nt) {
+      e_out = e;
+      m0 = lo + (mt - tile_base) * BM;
+      m_end = hi;
+      return true;
+    }
+    tile_base += nt;
+  }
+  return false;
+}
+
+template <typename AB, typename OT>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void grouped_gemm_t128(
+    const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, OT* __restrict__ out, int n_tiles_n,
+    int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = sizeof(AB);
+  constexpr int BKE = BK_BYTES / ES;  // elements per K-step
+
+  // ---- tile id: XCD-contiguous remap, then grouped (m, n) order -------------------------------------
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int per_group = group_m * n_tiles_n;
+  const int g = bid / per_group, rem = bid % per_group;
+  const int mt = g * group_m + rem % group_m;
+  const int nt = rem / group_m;
+
+  int e, m0, m_end;
+  if (!find_tile(offsets, E, mt, e, m0, m_end)) return;
+  if (group_expert) e = group_expert[e];  // group -> weight index
+  const int n0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- global -> register staging addresses --------------------------------------------------------
+  const int ld_chunk = tid & 7, ld_row = tid >> 3;  // 32 rows per pass, 4 passes for A and for B
+  const AB* a_ptr[4];
+  const AB* w_ptr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int ar = m0 + ld_row + 32 * i;
+    if (ar >= m_end) ar = m_end - 1;
+    a_ptr[i] = A + (int64_t)ar * K + ld_chunk * (16 / ES);
+    int wr = n0 + ld_row + 32 * i;
+    if (wr >= N) wr = N - 1;
+    w_ptr[i] = W + ((int64_t)e * N + wr) * K + ld_chunk * (16 / ES);
+  }
+  u32x4 ra[4], rw[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + k0);
+      rw[i] = *reinterpret_cast<const u32x4*>(w_ptr[i] + k0);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    char* sw = sa + BM * BK_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<u32x4*>(sa + swz(ld_row + 32 * i, ld_chunk)) = ra[i];
+      *reinterpret_cast<u32x4*>(sw + swz(ld_row + 32 * i, ld_chunk)) = rw[i];
+    }
+  };
+
+  f32x4 acc[4][4];  // [mi][ni]; lane holds n = 4*(lane>>4)+r (r=0..3) of token m = lane&15
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BKE;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BKE);
+    const char* sa = smem + cur * STAGE_BYTES;
+    const char* sw = sa + BM * BK_BYTES;
+    if constexpr (ES == 2) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        u32x4 af[4], wf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          af[i] = *reinterpret_cast<const u32x4*>(sa + swz(wm * 64 + i * 16 + fr, kk * 4 + fq));
+          wf[i] = *reinterpret_cast<const u32x4*>(sw + swz(wn * 64 + i * 16 + fr, kk * 4 + fq));
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            if constexpr (std::is_same<AB, f16>::value)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[ni]),
+                                                                    __builtin_bit_cast(f16x8, af[mi]), acc[mi][ni], 0, 0, 0);
+            else
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[ni]),
+                                                                     __builtin_bit_cast(bf16x8_t, af[mi]), acc[mi][ni], 0, 0, 0);
+          }
+      }
+    } else {
+      // f32-exact: 16x16x4, K-step of 32 floats = 8 MFMA k-steps; lane reads element k = 4*ks + fq of row fr
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        float af[4], wf[4];
+        const int kel = ks * 4 + fq;  // float index within the 32-float K-step
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          af[i] = *reinterpret_cast<const float*>(sa + swz(wm * 64 + i * 16 + fr, kel >> 2) + (kel & 3) * 4);
+          wf[i] = *reinterpret_cast<const float*>(sw + swz(wn * 64 + i * 16 + fr, kel >> 2) + (kel & 3) * 4);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ni], af[mi], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias (+GELU), convert, stage the tile through LDS, store whole row segments -------
+  constexpr int OB = OutPack<OT>::bytes;
+  constexpr int C_STRIDE = BN * OB + C_PAD;
+  {
+    const float* bias_e = bias ? bias + (int64_t)e * N : nullptr;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int nl = wn * 64 + ni * 16 + fq * 4;  // tile-local column of r=0
+      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (bias_e && n0 + nl < N) bv = *reinterpret_cast<const f32x4*>(bias_e + n0 + nl);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        f32x4 v = acc[mi][ni] + bv;
+        if (epilogue == SMOE_EPI_GELU) {
+          v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+        }
+        const int ml = wm * 64 + mi * 16 + fr;
+        OutPack<OT>::write4(smem + ml * C_STRIDE + nl * OB, v);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int CHUNKS = BN * OB / 16;        // 16-B chunks per tile row: 16 (2-byte out) or 32 (f32)
+    constexpr int ROWS_PER_PASS = GEMM_THREADS / CHUNKS;
+    const int ch = tid % CHUNKS, r0 = tid / CHUNKS;
+    const int ncol = n0 + ch * (16 / OB);
+    if (ncol < N) {
+      for (int r = r0; r < BM; r += ROWS_PER_PASS) {
+        const int m = m0 + r;
+        if (m >= m_end) break;
+        u32x4 v = *reinterpret_cast<const u32x4*>(smem + r * C_STRIDE + ch * 16);
+        int64_t orow = m;
+        if (row_map) {
+          orow = row_map[m];
+          if (row_scale) v = scale16<OT>(v, row_scale[orow]);
+        }
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow * (int64_t)N + ncol) * OB) = v;
+      }
+    }
+  }
+}
+
+template <typename AB, typename OT>
+int launch_t128(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
+                int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
+                void* out, hipStream_t s) {
+  const int n_tiles_n = (N + BN - 1) / BN;
+  const int max_m_tiles = (int)((m_rows_max + BM - 1) / BM) + E;
+  const int group_m = 8;
+  const int m_groups = (max_m_tiles + group_m - 1) / group_m;
+  const int grid = m_groups * group_m * n_tiles_n;
+  constexpr int OB = OutPack<OT>::bytes;
+  size_t smem = 2 * STAGE_BYTES;
+  const size_t ctile = (size_t)BM * (BN * OB + C_PAD);
+  if (ctile > smem) smem = ctile;
+  auto kern = grouped_gemm_t128<AB, OT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (ae != hipSuccess) {
+      smoe_set_error("smoe_grouped_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
+      return (int)ae;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert,
+                     E, K, N, epilogue, row_map, row_scale, (OT*)out, n_tiles_n, group_m);
+  SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
+  return 0;
+}
+
+template <typename AB>
+int dispatch_out(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
+                 int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
+                 void* out, int out_dtype, hipStream_t s) {
+  switch (out_dtype) {
+    case SMOE_F32: return launch_t128<AB, float>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
+    case SMOE_F16: return launch_t128<AB, f16>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
+    case SMOE_BF16: return launch_t128<AB, bf16_bits>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
+  }
+  smoe_set_error("smoe_grouped_gemm: bad out_dtype %d", out_dtype);
+  return 1;
+}
+
+}  // namespace
+
+extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int32_t* offsets,
+                                 const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
+                                 int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale, void* out,
+                                 int out_dtype, int variant, void* stream) {
+  SMOE_REQUIRE(offsets && G >= 1 && G <= 65536, "smoe_grouped_gemm: bad G=%d / offsets", G);
+  SMOE_REQUIRE(n_experts >= 1 && (group_expert || n_experts == G), "smoe_grouped_gemm: n_experts=%d != G=%d without a group map", n_experts, G);
+  SMOE_REQUIRE(m_rows_max >= 0 && m_rows_max < (1ll << 31), "smoe_grouped_gemm: m_rows_max=%lld out of range",
+               (long long)m_rows_max);
+  SMOE_REQUIRE(K > 0 && N > 0, "smoe_grouped_gemm: bad K=%d N=%d", K, N);
+  SMOE_REQUIRE(epilogue == SMOE_EPI_NONE || epilogue == SMOE_EPI_GELU, "smoe_grouped_gemm: bad epilogue %d", epilogue);
+  SMOE_REQUIRE(smoe_dtype_ok(ab_dtype) && smoe_dtype_ok(out_dtype), "smoe_grouped_gemm: bad dtype");
+  const int bke = BK_BYTES / smoe_dtype_size(ab_dtype);
+  SMOE_REQUIRE(K % bke == 0, "smoe_grouped_gemm: K=%d must be a multiple of %d for this dtype", K, bke);
+  SMOE_REQUIRE(N % 8 == 0, "smoe_grouped_gemm: N=%d must be a multiple of 8", N);
+  if (m_rows_max == 0) return 0;
+  SMOE_REQUIRE(A && W && out, "smoe_grouped_gemm: null pointer");
+  (void)variant;
+  hipStream_t s = (hipStream_t)stream;
+  switch (ab_dtype) {
+    case SMOE_F32: return dispatch_out<float>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
+    case SMOE_F16: return dispatch_out<f16>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
+    case SMOE_BF16: return dispatch_out<bf16_bits>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
+  }
+  return 1;
+}

@@ -1,0 +1,111 @@
+// Shared device/host helpers for libslimmoe_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/slimmoe.h"
+
+#define SMOE_WAVE 64
+
+void smoe_set_error(const char* fmt, ...);
+
+#define SMOE_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      smoe_set_error(__VA_ARGS__);         \
+      return 1;                            \
+    }                                      \
+  } while (0)
+
+#define SMOE_CHECK_LAUNCH(name)                                                  \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      smoe_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+      return (int)e__;                                                           \
+    }                                                                            \
+  } while (0)
+
+typedef _Float16 f16;
+typedef unsigned short bf16_bits;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) {
+  return __uint_as_float(((unsigned int)b) << 16);
+}
+// round-to-nearest-even; NaN stays NaN (plain cast path, see MI355X_MICROARCH 'Correctness boundaries')
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// dtype tags
+struct TagF32 { typedef float T; static constexpr int code = SMOE_F32; };
+struct TagF16 { typedef f16 T; static constexpr int code = SMOE_F16; };
+struct TagBF16 { typedef bf16_bits T; static constexpr int code = SMOE_BF16; };
+
+// load 4 consecutive elements as float
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+  f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+__device__ __forceinline__ void load4(const f16* p, float (&v)[4]) {
+  f16x4 t = *reinterpret_cast<const f16x4*>(p);
+  v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+}
+__device__ __forceinline__ void load4(const bf16_bits* p, float (&v)[4]) {
+  s16x4 t = *reinterpret_cast<const s16x4*>(p);
+  v[0] = bf16_to_f32((unsigned short)t[0]); v[1] = bf16_to_f32((unsigned short)t[1]);
+  v[2] = bf16_to_f32((unsigned short)t[2]); v[3] = bf16_to_f32((unsigned short)t[3]);
+}
+// load / store 8 consecutive elements
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+__device__ __forceinline__ void load8(const f16* p, float (&v)[8]) {
+  f16x8 t = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
+__device__ __forceinline__ void load8(const bf16_bits* p, float (&v)[8]) {
+  s16x8 t = *reinterpret_cast<const s16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = bf16_to_f32((unsigned short)t[i]);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+__device__ __forceinline__ void store8(f16* p, const float (&v)[8]) {
+  f16x8 t;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = (f16)v[i];
+  *reinterpret_cast<f16x8*>(p) = t;
+}
+__device__ __forceinline__ void store8(bf16_bits* p, const float (&v)[8]) {
+  s16x8 t;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = (short)f32_to_bf16(v[i]);
+  *reinterpret_cast<s16x8*>(p) = t;
+}
+
+static inline int smoe_dtype_size(int code) { return code == SMOE_F32 ? 4 : 2; }
+static inline bool smoe_dtype_ok(int code) { return code == SMOE_F32 || code == SMOE_F16 || code == SMOE_BF16; }

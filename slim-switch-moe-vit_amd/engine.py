@@ -1,0 +1,44 @@
+"""Eval harness mirroring the reference's engine.evaluate (engine.py:88-121): eval mode, no_grad,
+autocast on the GPU, cross-entropy + top-1/top-5, per-batch loop.  Returns the same dict keys plus
+images/sec.  MetricLogger / distributed meters are out of scope."""
+from __future__ import annotations
+
+import time
+from typing import Iterable, Tuple
+
+import torch
+
+
+def accuracy(output: torch.Tensor, target: torch.Tensor, topk=(1,)):
+    """timm.utils.accuracy: top-k accuracy in percent."""
+    maxk = min(max(topk), output.shape[1])
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.reshape(1, -1).expand_as(pred.t()))
+    return [correct[: min(k, maxk)].reshape(-1).float().sum(0) * 100.0 / target.shape[0] for k in topk]
+
+
+@torch.no_grad()
+def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: torch.nn.Module, device,
+             autocast: bool = True):
+    criterion = torch.nn.CrossEntropyLoss()
+    model.eval()
+    dev = torch.device(device)
+    n, loss_sum, a1, a5 = 0, 0.0, 0.0, 0.0
+    t0 = time.perf_counter()
+    for images, target in data_loader:
+        images = images.to(dev, non_blocking=True)
+        target = target.to(dev, non_blocking=True)
+        with torch.autocast(device_type=dev.type, dtype=torch.float16, enabled=autocast and dev.type == "cuda"):
+            output = model(images)
+            loss = criterion(output, target)
+        acc1, acc5 = accuracy(output, target, topk=(1, 5))
+        bs = images.shape[0]
+        n += bs
+        loss_sum += loss.item() * bs
+        a1 += acc1.item() * bs
+        a5 += acc5.item() * bs
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    n = max(n, 1)
+    return {"loss": loss_sum / n, "acc1": a1 / n, "acc5": a5 / n, "images_per_sec": n / dt}

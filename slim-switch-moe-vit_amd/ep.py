@@ -1,0 +1,136 @@
+"""Expert parallelism for the MoE operator: count exchange + token all-to-all-v, pipelined against the
+grouped GEMMs (replaces fmoe_cuda.expert_exchange / global_scatter / global_gather and FasterMoE's
+smart schedule).
+
+One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm, and an all-to-all maps 1:1 onto
+the xGMI mesh (every peer pair has its own link).  Experts are partitioned contiguously: rank w owns
+global experts [w*E_local, (w+1)*E_local).  Every rank routes its own tokens over all W*E_local experts;
+its expert-sorted send buffer is therefore already grouped by destination rank.
+
+Receive layout: rows arrive rank-major ([source rank][local expert][token]).  Instead of re-sorting them
+expert-major (an extra HBM pass) the grouped GEMM takes one row group per (source rank, local expert) with
+a group -> expert map (``group_expert`` in include/slimmoe.h).
+
+Overlap: the local tokens are cut into ``ep_chunks`` micro-batches; the all-to-all of chunk c+1 runs on
+RCCL's stream under the expert GEMMs of chunk c (and the return all-to-all of chunk c under the GEMMs of
+chunk c+1).  Only ONE host sync per layer: every chunk's count matrix travels in a single small all-to-all.
+The functions that only move data (exchange_counts, segment_table, all_to_all_rows) are device-agnostic and
+are exercised on CPU with the gloo backend in tests/test_ep_gloo.py.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def exchange_counts(counts_per_chunk: List[torch.Tensor], world_size: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """counts_per_chunk[c]: int32 [W*E_local] rows this rank routes to each GLOBAL expert from chunk c.
+    Returns host int64 tensors (lec, gec), both [C, W, E_local]:
+      lec[c, w, e] = rows of chunk c this rank sends to rank w's local expert e
+      gec[c, w, e] = rows of chunk c rank w sends to this rank's local expert e.
+    One small all-to-all + one device->host copy for all chunks."""
+    C = len(counts_per_chunk)
+    W = world_size
+    E_local = counts_per_chunk[0].numel() // W
+    lec = torch.stack([c.reshape(W, E_local) for c in counts_per_chunk], 0)          # [C, W, E]
+    send = lec.permute(1, 0, 2).contiguous()                                          # [W, C, E]: row w goes to rank w
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    host = torch.stack([send, recv], 0).to("cpu", torch.int64)                        # the single sync point
+    return host[0].permute(1, 0, 2).contiguous(), host[1].permute(1, 0, 2).contiguous()
+
+
+def segment_table(gec_c: torch.Tensor) -> Tuple[List[int], List[int]]:
+    """gec_c: host [W, E_local] for one chunk.  Received rows are laid out [w][e][token]; returns
+    (offsets of the W*E_local row groups in that order, local expert id of every group)."""
+    W, E_local = gec_c.shape
+    offs = [0]
+    for n in gec_c.reshape(-1).tolist():
+        offs.append(offs[-1] + int(n))
+    return offs, [e for _ in range(W) for e in range(E_local)]
+
+
+def all_to_all_rows(rows: torch.Tensor, send_rows: List[int], recv_rows: List[int], group=None, async_op: bool = False):
+    """all-to-all-v of whole rows: ``rows[:sum(send_rows)]`` is split by destination rank; returns
+    (received [sum(recv_rows), d], work handle or None)."""
+    n_send, n_recv = int(sum(send_rows)), int(sum(recv_rows))
+    out = torch.empty((n_recv, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    work = dist.all_to_all_single(out, rows[:n_send], output_split_sizes=[int(v) for v in recv_rows],
+                                  input_split_sizes=[int(v) for v in send_rows], group=group, async_op=async_op)
+    return out, work
+
+
+def chunk_bounds(T: int, chunks: int) -> List[Tuple[int, int]]:
+    chunks = max(1, min(chunks, T)) if T > 0 else 1
+    return [((T * c) // chunks, (T * (c + 1)) // chunks) for c in range(chunks)]
+
+
+def ep_forward(mod, x: torch.Tensor, cd: torch.dtype) -> torch.Tensor:
+    """Expert-parallel FMoETransformerMLP forward for this rank's tokens x [T, d] -> [T, d]."""
+    from . import ops
+    from .fmoe import SwitchGate
+
+    g = mod.gate
+    W, E_local, k, d = mod.world_size, mod.num_expert, mod.top_k, mod.d_model
+    group = mod.moe_group
+    T = x.shape[0]
+    cap = g.capacity(T)
+    # capacity is defined over the whole local batch, so dropping gates run un-chunked
+    n_chunks = 1 if cap >= 0 else max(1, int(getattr(mod, "ep_chunks", 2)))
+    bounds = chunk_bounds(T, n_chunks) if T > 0 else [(0, 0)] * n_chunks
+    if len(bounds) < n_chunks:  # tiny batches: keep the collective count identical on every rank
+        bounds = bounds + [(T, T)] * (n_chunks - len(bounds))
+
+    noise = g.make_noise(T, x.device) if isinstance(g, SwitchGate) else None
+    gw = g.gate.weight.detach().float().contiguous()
+    gb = g.gate.bias.detach().float() if g.gate.bias is not None else None
+    idx, score, _, probs = ops.router_topk(x, gw, gb, k, g.kind, noise, want_probs=isinstance(g, SwitchGate))
+    plans = []
+    for (t0, t1) in bounds:
+        plans.append(ops.dispatch_plan(idx[t0:t1], g.tot_expert, cap))
+    mod.last_plan = (idx, score) + tuple(plans[0][:4])
+    if isinstance(g, SwitchGate):
+        from .autograd import switch_aux_loss
+        pruned = plans[0][4] if plans[0][4] is not None else idx
+        g.set_loss(switch_aux_loss(pruned, probs, g.tot_expert))
+
+    lec, gec = exchange_counts([p[0] for p in plans], W, group)          # host [C, W, E_local]
+
+    out = torch.empty((T, d), dtype=x.dtype, device=x.device)
+    # stage A: scatter + dispatch all-to-all (async; chunk c+1 travels under chunk c's GEMMs)
+    inflight = []
+    for c, (t0, t1) in enumerate(bounds):
+        counts, offsets, pos, inv_pos, _ = plans[c]
+        send = ops.scatter_rows(x[t0:t1], pos, k, cd)
+        send_rows = lec[c].sum(1).tolist()
+        recv_rows = gec[c].sum(1).tolist()
+        recv, work = all_to_all_rows(send, send_rows, recv_rows, group, async_op=True)
+        inflight.append((send, recv, work, send_rows, recv_rows))
+    # stage B: expert FFN on the received rows + return all-to-all (async)
+    returning = []
+    for c in range(len(bounds)):
+        send, recv, work, send_rows, recv_rows = inflight[c]
+        work.wait()
+        n_recv = recv.shape[0]
+        if n_recv > 0:
+            offs, gexp = segment_table(gec[c])
+            offs_dev = torch.tensor(offs, dtype=torch.int32, device=x.device)
+            gexp_dev = torch.tensor(gexp, dtype=torch.int32, device=x.device)
+            y = mod._experts_fwd(recv, offs_dev, cd, out_dtype=cd, group_expert=gexp_dev)
+        else:
+            y = recv
+        back, work2 = all_to_all_rows(y, recv_rows, send_rows, group, async_op=True)
+        returning.append((y, back, work2))
+    # stage C: gather + combine in sender order
+    for c, (t0, t1) in enumerate(bounds):
+        y, back, work2 = returning[c]
+        work2.wait()
+        if t1 > t0:
+            inv_pos = plans[c][3]
+            if back.shape[0] == 0:  # every entry of the chunk was dropped
+                out[t0:t1].zero_()
+            else:
+                ops.gather_combine(back, inv_pos, score[t0:t1], t1 - t0, k, x.dtype, out=out[t0:t1])
+    return out

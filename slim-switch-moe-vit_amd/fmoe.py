@@ -1,0 +1,258 @@
+"""MI355X-native stand-in for the third-party ``fmoe`` operator the reference imports.
+
+The reference's whole MoE hot path is ``from fmoe import FMoETransformerMLP`` (models/resMoE.py:6),
+constructed at models/resMoE.py:27-29 and called at models/resMoE.py:121,143 and
+models/vision_transformer.py:321.  This module re-exports that surface -- same constructor arguments,
+same sub-module / parameter names (``gate.gate``, ``experts.htoh4``, ``experts.h4toh``: evidenced by
+models/resmoe_flop_hook.py:7 and SURVEY.md section 5 checkpoint row) -- on top of hand-written HIP kernels
+(router, dispatch plan, token scatter, grouped MFMA GEMM, gather/combine) reached through the C-ABI
+in include/slimmoe.h.  There is no CPU implementation here: tensors must be on the GPU.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_COMPUTE_DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
+
+
+def default_compute_dtype() -> torch.dtype:
+    """dtype of the MFMA operands of the expert GEMMs (accumulation is always f32)."""
+    return _COMPUTE_DTYPES[os.environ.get("SLIMMOE_COMPUTE_DTYPE", "f16")]
+
+
+class FMoELinear(nn.Module):
+    """E independent linears held as one [E, out, in] weight and one [E, out] bias (fmoe.linear.FMoELinear)."""
+
+    def __init__(self, num_expert: int, in_feat: int, out_feat: int, bias: bool = True, rank: int = 0):
+        super().__init__()
+        self.num_expert, self.in_feat, self.out_feat, self.rank = num_expert, in_feat, out_feat, rank
+        self.weight = nn.Parameter(torch.empty(num_expert, out_feat, in_feat))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(num_expert, out_feat))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+        self._shadow = {}  # compute dtype -> (version, tensor)
+
+    def reset_parameters(self):
+        # upstream: kaiming_uniform_(a=sqrt(5)) on the 3-D weight, zero bias
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def weight_as(self, dtype: torch.dtype) -> torch.Tensor:
+        """Weight in the MFMA operand dtype; a cached shadow copy, refreshed when the parameter changes."""
+        w = self.weight
+        if w.dtype == dtype:
+            return w.detach()
+        key = (dtype, w.device)
+        ver = (w._version, w.data_ptr())
+        hit = self._shadow.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.cast(w.detach().contiguous(), dtype))
+            self._shadow[key] = hit
+        return hit[1]
+
+    def extra_repr(self):
+        return f"num_expert={self.num_expert}, in_features={self.in_feat}, out_features={self.out_feat}"
+
+
+class NaiveGate(nn.Module):
+    """``gate = nn.Linear(d_model, num_expert * world_size)``; top-k of the logits, softmax over the kept k."""
+
+    kind = ops.GATE_NAIVE
+
+    def __init__(self, d_model: int, num_expert: int, world_size: int, top_k: int = 2):
+        super().__init__()
+        self.gate = nn.Linear(d_model, num_expert * world_size)
+        self.top_k = top_k
+        self.num_expert, self.world_size = num_expert, world_size
+        self.tot_expert = num_expert * world_size
+        self.loss = None
+
+    def capacity(self, n_tokens: int) -> int:
+        return -1
+
+    def set_loss(self, loss):
+        self.loss = loss
+
+    def get_loss(self, clear: bool = True):
+        loss = self.loss
+        if clear:
+            self.loss = None
+        return loss
+
+
+class SwitchGate(NaiveGate):
+    """Switch-Transformer top-1 gate with capacity and load-balance loss (fmoe.gates.SwitchGate).
+
+    ``capacity_factor`` follows the Switch definition per source rank: cap = ceil(cf * T_local * k / E_total);
+    ``capacity_mode="fmoe"`` selects upstream's ceil(cf * T_local) instead (cf = (train, eval) pair)."""
+
+    kind = ops.GATE_SWITCH
+
+    def __init__(self, d_model: int, num_expert: int, world_size: int, top_k: int = 1, switch_eps: float = 0.1,
+                 capacity=(1.2, 2.4), capacity_mode: str = "switch"):
+        assert top_k == 1, "SwitchGate is top-1"
+        super().__init__(d_model, num_expert, world_size, top_k=1)
+        self.switch_eps = switch_eps
+        self.capacity_factor = capacity
+        self.capacity_mode = capacity_mode
+
+    def capacity(self, n_tokens: int) -> int:
+        cf = self.capacity_factor
+        if cf is None:
+            return -1
+        if isinstance(cf, (tuple, list)):
+            cf = cf[0] if self.training else cf[1]
+        if self.capacity_mode == "fmoe":
+            return int(math.ceil(cf * n_tokens))
+        return int(math.ceil(cf * n_tokens * self.top_k / self.tot_expert))
+
+    def make_noise(self, T: int, device) -> Optional[torch.Tensor]:
+        if not self.training or self.switch_eps <= 0:
+            return None
+        # upstream adds U[0,1) * 2*eps + (1 - eps) to the logits
+        return torch.rand(T, self.tot_expert, device=device) * (2 * self.switch_eps) + (1.0 - self.switch_eps)
+
+
+class _Expert(nn.Module):
+    """fmoe.transformer._Expert: htoh4 -> activation -> h4toh over expert-sorted rows."""
+
+    def __init__(self, num_expert: int, d_model: int, d_hidden: int, activation, rank: int = 0):
+        super().__init__()
+        self.htoh4 = FMoELinear(num_expert, d_model, d_hidden, bias=True, rank=rank)
+        self.h4toh = FMoELinear(num_expert, d_hidden, d_model, bias=True, rank=rank)
+        self.activation = activation
+
+
+def _parse_activation(act):
+    """-> (fused_gelu: bool, dropout_p: float, generic_module | None)."""
+    mods = list(act) if isinstance(act, nn.Sequential) else [act]
+    fused, p, rest = False, 0.0, []
+    for i, m in enumerate(mods):
+        if i == 0 and isinstance(m, nn.GELU) and getattr(m, "approximate", "none") == "none":
+            fused = True
+        elif fused and isinstance(m, nn.Dropout) and not rest:
+            p = 1 - (1 - p) * (1 - m.p)
+        elif isinstance(m, nn.Identity):
+            continue
+        else:
+            rest.append(m)
+    if rest:
+        return False, 0.0, act
+    return fused, p, None if fused else act
+
+
+class FMoETransformerMLP(nn.Module):
+    """Drop-in for ``fmoe.FMoETransformerMLP(num_expert, d_model, d_hidden, activation, top_k=...)``.
+
+    forward(x[..., d]) -> same shape:  router -> dispatch plan -> token scatter -> grouped GEMM (+bias,
+    +GELU) -> grouped GEMM (+bias) -> gather/combine, all HIP kernels.
+    Keyword-only extensions with reference defaults: ``gate`` ("naive" | "switch" | a gate class),
+    ``capacity_factor``, ``world_size`` / ``moe_group`` (expert parallel), ``compute_dtype``.
+    """
+
+    def __init__(self, num_expert: int = 32, d_model: int = 1024, d_hidden: int = 4096, activation=None,
+                 expert_dp_comm: str = "none", expert_rank: int = 0, *, top_k: int = 2, world_size: int = 1,
+                 moe_group=None, gate="naive", capacity_factor=None, capacity_mode: str = "switch",
+                 compute_dtype: Optional[torch.dtype] = None, gemm_variant: int = 0):
+        super().__init__()
+        if activation is None:
+            activation = nn.GELU()
+        self.num_expert, self.d_model, self.d_hidden = num_expert, d_model, d_hidden
+        self.world_size, self.moe_group, self.top_k = world_size, moe_group, top_k
+        self.expert_dp_comm = expert_dp_comm
+        if isinstance(gate, str):
+            if gate == "naive":
+                self.gate = NaiveGate(d_model, num_expert, world_size, top_k)
+            elif gate == "switch":
+                cap = capacity_factor if capacity_factor is not None else (1.2, 2.4)
+                self.gate = SwitchGate(d_model, num_expert, world_size, top_k, capacity=cap, capacity_mode=capacity_mode)
+            else:
+                raise ValueError(f"unknown gate {gate!r}")
+        else:
+            self.gate = gate(d_model, num_expert, world_size, top_k)
+        self.experts = _Expert(num_expert, d_model, d_hidden, activation, rank=expert_rank)
+        self.compute_dtype = compute_dtype
+        self.gemm_variant = gemm_variant
+        self.ep_chunks = 2  # micro-batches of the expert-parallel pipeline (ep.py)
+        self._fused_gelu, self._drop_p, self._generic_act = _parse_activation(activation)
+        self.last_plan = None  # (idx, score, counts, offsets, pos, inv_pos) of the latest forward, for inspection
+
+    # -- hot path ------------------------------------------------------------------------------------
+    def forward(self, inp: torch.Tensor) -> torch.Tensor:
+        if not inp.is_cuda:
+            raise RuntimeError("FMoETransformerMLP: input must be on the GPU; this build has no CPU path "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+        if torch.is_grad_enabled() and (inp.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd import moe_forward_train
+            return moe_forward_train(self, inp)
+        return self._forward_infer(inp)
+
+    def _route(self, x: torch.Tensor):
+        g = self.gate
+        T = x.shape[0]
+        noise = g.make_noise(T, x.device) if isinstance(g, SwitchGate) else None
+        want_probs = isinstance(g, SwitchGate)
+        gw = g.gate.weight.detach()
+        gb = g.gate.bias.detach() if g.gate.bias is not None else None
+        if gw.dtype != torch.float32:
+            gw, gb = gw.float(), (gb.float() if gb is not None else None)
+        idx, score, _, probs = ops.router_topk(x, gw.contiguous(), gb, g.top_k, g.kind, noise, want_probs=want_probs)
+        cap = g.capacity(T)
+        counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, g.tot_expert, cap)
+        return idx, score, probs, counts, offsets, pos, inv_pos, pruned
+
+    def _experts_fwd(self, rows: torch.Tensor, offsets: torch.Tensor, cd: torch.dtype, out=None, row_map=None,
+                     row_scale=None, out_dtype=None, group_expert=None):
+        ex = self.experts
+        w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
+        b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
+        b2 = ex.h4toh.bias.detach().float() if ex.h4toh.bias is not None else None
+        if self._fused_gelu:
+            h = ops.grouped_gemm(rows, w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant,
+                                 group_expert=group_expert)
+            if self._drop_p > 0 and self.training:
+                h = torch.nn.functional.dropout(h, self._drop_p, True)
+        else:
+            h = ops.grouped_gemm(rows, w1, b1, offsets, ops.EPI_NONE, cd, variant=self.gemm_variant,
+                                 group_expert=group_expert)
+            h = self._generic_act(h).to(cd).contiguous()
+        return ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, out_dtype, row_map=row_map, row_scale=row_scale,
+                                out=out, variant=self.gemm_variant, group_expert=group_expert)
+
+    def _forward_infer(self, inp: torch.Tensor) -> torch.Tensor:
+        shape = inp.shape
+        d, k = self.d_model, self.top_k
+        x = inp.reshape(-1, d)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        T = x.shape[0]
+        cd = self.compute_dtype or default_compute_dtype()
+        if self.world_size > 1:
+            from .ep import ep_forward
+            return ep_forward(self, x, cd).reshape(shape)
+        idx, score, probs, counts, offsets, pos, inv_pos, pruned = self._route(x)
+        self.last_plan = (idx, score, counts, offsets, pos, inv_pos)
+        if isinstance(self.gate, SwitchGate):
+            from .autograd import switch_aux_loss
+            self.gate.set_loss(switch_aux_loss(pruned if pruned is not None else idx, probs, self.gate.tot_expert))
+        buf = ops.scatter_rows(x, pos, k, cd)
+        if k == 1:
+            # fused combine: GEMM-2 stores row s to out[pos[s]] * score[pos[s]]; dropped tokens stay 0
+            dropping = self.gate.capacity(T) >= 0
+            out = (torch.zeros if dropping else torch.empty)((T, d), dtype=inp.dtype, device=inp.device)
+            self._experts_fwd(buf, offsets, cd, out=out, row_map=pos, row_scale=score.reshape(-1),
+                              out_dtype=inp.dtype)
+        else:
+            y = self._experts_fwd(buf, offsets, cd, out_dtype=cd)
+            out = ops.gather_combine(y, inv_pos, score, T, k, inp.dtype)
+        return out.reshape(shape)

@@ -1,0 +1,239 @@
+"""Python face of the C-ABI (include/slimmoe.h): torch tensors in, torch tensors out.
+
+Torch is plumbing here (device memory, streams); every function below launches hand-written HIP
+kernels from libslimmoe_hip.so on torch's current stream and raises if that library is missing.
+Shapes / dtypes / contiguity are validated here, before the C call (SURVEY.md 8b error convention).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+F32, F16, BF16 = 0, 1, 2
+GATE_NAIVE, GATE_SWITCH = 0, 1
+EPI_NONE, EPI_GELU = 0, 1
+
+_DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dt}; expected float32/float16/bfloat16") from None
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+# ---- optional per-launch timing (bench.py's roofline leg): HIP events on the stream the kernels run on ----
+_PROFILE = None  # list of (name, meta, start_event, end_event) while enabled
+
+
+def profile_begin():
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_end():
+    """-> list of (name, meta, milliseconds); call after a device synchronize."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE or [], None
+    return [(n, m, s.elapsed_time(e)) for n, m, s, e in rec]
+
+
+class _timed:
+    def __init__(self, name, meta, ref):
+        self.on = _PROFILE is not None
+        if self.on:
+            self.name, self.meta, self.ref = name, meta, ref
+
+    def __enter__(self):
+        if self.on:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record(torch.cuda.current_stream(self.ref.device))
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e.record(torch.cuda.current_stream(self.ref.device))
+            _PROFILE.append((self.name, self.meta, self.s, self.e))
+
+
+def _chk(t: torch.Tensor, name: str, dtype=None, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: must live on the GPU (got {t.device}); the MoE hot path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
+    if t.data_ptr() % 16 != 0 and t.numel() > 0:
+        raise RuntimeError(f"{name}: data pointer must be 16-byte aligned")
+
+
+def router_topk(x: torch.Tensor, wg: torch.Tensor, bg: Optional[torch.Tensor], k: int, gate_kind: int = GATE_NAIVE,
+                noise: Optional[torch.Tensor] = None, want_logits: bool = False, want_probs: bool = False):
+    """(idx int64 [T,k], score f32 [T,k], logits f32 [T,E] | None, probs f32 [T,E] | None)."""
+    _chk(x, "x", ndim=2)
+    _chk(wg, "wg", torch.float32, 2)
+    T, d = x.shape
+    E = wg.shape[0]
+    if wg.shape[1] != d:
+        raise RuntimeError(f"wg: expected [E,{d}], got {tuple(wg.shape)}")
+    if bg is not None:
+        _chk(bg, "bg", torch.float32, 1)
+        if bg.shape[0] != E:
+            raise RuntimeError("bg: expected [E]")
+    if noise is not None:
+        _chk(noise, "noise", torch.float32, 2)
+        if tuple(noise.shape) != (T, E):
+            raise RuntimeError("noise: expected [T,E]")
+    idx = torch.empty((T, k), dtype=torch.int64, device=x.device)
+    score = torch.empty((T, k), dtype=torch.float32, device=x.device)
+    logits = torch.empty((T, E), dtype=torch.float32, device=x.device) if want_logits else None
+    probs = torch.empty((T, E), dtype=torch.float32, device=x.device) if want_probs else None
+    lib = _lib.load()
+    with _timed("router", {"bytes": T * d * x.element_size()}, x):
+        rc = lib.smoe_router_topk(_ptr(x), dtype_code(x.dtype), _ptr(wg), _ptr(bg), _ptr(noise), T, d, E, k, gate_kind,
+                                  _ptr(idx), _ptr(score), _ptr(logits), _ptr(probs), _stream(x))
+    _lib.check(rc, "smoe_router_topk")
+    return idx, score, logits, probs
+
+
+def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Optional[bool] = None):
+    """(counts i32 [E], offsets i32 [E+1], pos i64 [n], inv_pos i64 [n], idx_pruned i64 [n] | None)."""
+    _chk(idx, "idx", torch.int64)
+    flat = idx.reshape(-1)
+    n = flat.numel()
+    dev = idx.device
+    if want_pruned is None:
+        want_pruned = capacity >= 0
+    lib = _lib.load()
+    ws_bytes = lib.smoe_dispatch_plan_workspace_bytes(n, E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    counts = torch.empty(E, dtype=torch.int32, device=dev)
+    offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    pos = torch.empty(n, dtype=torch.int64, device=dev)
+    inv_pos = torch.empty(n, dtype=torch.int64, device=dev)
+    pruned = torch.empty(n, dtype=torch.int64, device=dev) if want_pruned else None
+    with _timed("plan", {"bytes": n * 24}, idx):
+        rc = lib.smoe_dispatch_plan(_ptr(flat), n, E, int(capacity), _ptr(counts), _ptr(offsets), _ptr(pos),
+                                    _ptr(inv_pos), _ptr(pruned), _ptr(ws), ws_bytes, _stream(idx))
+    _lib.check(rc, "smoe_dispatch_plan")
+    return counts, offsets, pos, inv_pos, pruned
+
+
+def scatter_rows(x: torch.Tensor, pos: torch.Tensor, k: int, out_dtype: torch.dtype,
+                 out: Optional[torch.Tensor] = None, zero_fill: bool = False) -> torch.Tensor:
+    """buf[s] = cast(x[pos[s] // k]) for every slot with pos[s] >= 0 (MOEScatter local part)."""
+    _chk(x, "x", ndim=2)
+    _chk(pos, "pos", torch.int64, 1)
+    n_slots = pos.numel()
+    d = x.shape[1]
+    if out is None:
+        out = (torch.zeros if zero_fill else torch.empty)((n_slots, d), dtype=out_dtype, device=x.device)
+    else:
+        _chk(out, "out", out_dtype, 2)
+    lib = _lib.load()
+    with _timed("scatter", {"bytes": n_slots * d * (x.element_size() + out.element_size())}, x):
+        rc = lib.smoe_scatter_rows(_ptr(x), dtype_code(x.dtype), _ptr(pos), n_slots, k, d, _ptr(out),
+                                   dtype_code(out.dtype), _stream(x))
+    _lib.check(rc, "smoe_scatter_rows")
+    return out
+
+
+def gather_combine(y: torch.Tensor, inv_pos: torch.Tensor, score: torch.Tensor, T: int, k: int,
+                   out_dtype: torch.dtype, residual: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[t] = sum_j score[t,j] * y[inv_pos[t*k+j]] (+ residual[t]); dropped entries contribute 0."""
+    _chk(y, "y", ndim=2)
+    _chk(inv_pos, "inv_pos", torch.int64)
+    _chk(score, "score", torch.float32)
+    d = y.shape[1]
+    if inv_pos.numel() != T * k or score.numel() != T * k:
+        raise RuntimeError("inv_pos / score: expected T*k entries")
+    if out is None:
+        out = torch.empty((T, d), dtype=out_dtype, device=y.device)
+    else:
+        _chk(out, "out", out_dtype, 2)
+        if tuple(out.shape) != (T, d):
+            raise RuntimeError("out: expected [T,d]")
+    if residual is not None:
+        _chk(residual, "residual", out_dtype, 2)
+    lib = _lib.load()
+    with _timed("combine", {"bytes": T * d * (k * y.element_size() + out.element_size())}, y):
+        rc = lib.smoe_gather_combine(_ptr(y), dtype_code(y.dtype), _ptr(inv_pos), _ptr(score), T, k, d, _ptr(residual),
+                                     _ptr(out), dtype_code(out_dtype), _stream(y))
+    _lib.check(rc, "smoe_gather_combine")
+    return out
+
+
+def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], offsets: torch.Tensor,
+                 epilogue: int = EPI_NONE, out_dtype: Optional[torch.dtype] = None,
+                 row_map: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None, variant: int = 0,
+                 group_expert: Optional[torch.Tensor] = None, rows_hint: Optional[int] = None) -> torch.Tensor:
+    """out[r] = epi(A[r] @ W[e]^T + bias[e]) for r in [offsets[g], offsets[g+1]), e = group_expert[g] (or g).
+    W [E,N,K].  ``rows_hint`` = number of rows actually routed (for the profiler's FLOP count only)."""
+    _chk(A, "A", ndim=2)
+    _chk(W, "W", A.dtype, 3)
+    _chk(offsets, "offsets", torch.int32, 1)
+    M, K = A.shape
+    E, N, K2 = W.shape
+    if K2 != K:
+        raise RuntimeError(f"W: expected [E,N,{K}], got {tuple(W.shape)}")
+    G = offsets.numel() - 1
+    if group_expert is None:
+        if G != E:
+            raise RuntimeError("offsets: expected E+1 entries")
+    else:
+        _chk(group_expert, "group_expert", torch.int32, 1)
+        if group_expert.numel() != G:
+            raise RuntimeError("group_expert: expected one entry per row group")
+    if bias is not None:
+        _chk(bias, "bias", torch.float32, 2)
+        if tuple(bias.shape) != (E, N):
+            raise RuntimeError("bias: expected [E,N]")
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else A.dtype
+    if row_map is not None:
+        _chk(row_map, "row_map", torch.int64, 1)
+        if out is None:
+            raise RuntimeError("row_map needs a caller-provided `out`")
+        if row_scale is not None:
+            _chk(row_scale, "row_scale", torch.float32)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    else:
+        _chk(out, "out", out_dtype, 2)
+        if out.shape[1] != N:
+            raise RuntimeError("out: expected N columns")
+    lib = _lib.load()
+    rows = M if rows_hint is None else rows_hint
+    with _timed("grouped_gemm", {"flops": 2.0 * rows * K * N, "K": K, "N": N, "epilogue": epilogue}, A):
+        rc = lib.smoe_grouped_gemm(_ptr(A), _ptr(W), _ptr(bias), _ptr(offsets), _ptr(group_expert), G, E, M, K, N,
+                                   dtype_code(A.dtype), epilogue, _ptr(row_map), _ptr(row_scale), _ptr(out),
+                                   dtype_code(out_dtype), variant, _stream(A))
+    _lib.check(rc, "smoe_grouped_gemm")
+    return out
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    _chk(src, "src")
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    lib = _lib.load()
+    rc = lib.smoe_cast(_ptr(src), dtype_code(src.dtype), _ptr(dst), dtype_code(dtype), src.numel(), _stream(src))
+    _lib.check(rc, "smoe_cast")
+    return dst

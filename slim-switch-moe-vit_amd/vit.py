@@ -1,0 +1,198 @@
+"""Caller-side ViT shell (timm-free) that the MoE block plugs into.
+
+The reference builds its models from timm pieces that are absent on both boxes:
+``PatchEmbed``, ``DropPath``, ``Mlp``, ``trunc_normal_`` and the model registry.  This file restates
+just enough of them -- with the reference's attribute names, so ``state_dict()`` keys match
+models/vision_transformer.py:642-848 / models/model.py:80-183 -- for the MoE factories in resmoe.py to
+patch.  It is the *caller* of the hot path, not the hot path: dense pieces run as ordinary torch ops.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Callable, Dict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_MODEL_REGISTRY: Dict[str, Callable] = {}
+
+
+def register_model(fn: Callable) -> Callable:
+    """timm.models.registry.register_model: name -> factory (later registration wins)."""
+    _MODEL_REGISTRY[fn.__name__] = fn
+    return fn
+
+
+def create_model(model_name: str, pretrained: bool = False, **kwargs):
+    """timm.create_model(name, pretrained, **kwargs) as used at main.py:520-530 (None-valued kwargs dropped)."""
+    if model_name not in _MODEL_REGISTRY:
+        raise RuntimeError(f"Unknown model ({model_name}); registered: {sorted(_MODEL_REGISTRY)}")
+    kwargs = {k: v for k, v in kwargs.items() if v is not None}
+    return _MODEL_REGISTRY[model_name](pretrained=pretrained, **kwargs)
+
+
+def list_models():
+    return sorted(_MODEL_REGISTRY)
+
+
+def trunc_normal_(t: torch.Tensor, std: float = 0.02):
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth; identity in eval or when p == 0."""
+
+    def __init__(self, drop_prob: float = 0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * mask / keep
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+        self.patch_size = (patch_size, patch_size) if isinstance(patch_size, int) else tuple(patch_size)
+        self.grid_size = (self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+
+    def forward(self, x):
+        assert tuple(x.shape[-2:]) == self.img_size, f"input {tuple(x.shape[-2:])} != model {self.img_size}"
+        return self.proj(x).flatten(2).transpose(1, 2)
+
+
+class Mlp(nn.Module):
+    """Dense FFN each expert generalises (models/layers.py:391-414)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class Attention(nn.Module):
+    """models/vision_transformer.py:248-280 (softmax(q k^T * scale) v, then proj)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+        p = self.attn_drop.p if self.training else 0.0
+        x = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
+        return self.proj_drop(self.proj(x.transpose(1, 2).reshape(B, N, C)))
+
+
+class Block(nn.Module):
+    """models/vision_transformer.py:283-322; ``mlp`` is what the MoE factories replace."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, drop=0.0, attn_drop=0.0, drop_path=0.0,
+                 act_layer=nn.GELU, norm_layer=nn.LayerNorm, num_tokens=-1):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x):
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        x = x + self.drop_path(self.mlp(self.norm2(x)))
+        return x
+
+
+def _init_vit_weights(m: nn.Module):
+    # non-jax branch of models/vision_transformer.py:851-885
+    if isinstance(m, nn.Linear):
+        trunc_normal_(m.weight, std=0.02)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.zeros_(m.bias)
+        nn.init.ones_(m.weight)
+
+
+class VisionTransformer(nn.Module):
+    """Non-distilled ViT (models/vision_transformer.py:642-848); unknown kwargs are swallowed as there."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4.0, qkv_bias=True, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0,
+                 embed_layer=PatchEmbed, norm_layer=None, act_layer=None, **kwargs):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 1
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        act_layer = act_layer or nn.GELU
+        self.patch_embed = embed_layer(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = None
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + self.num_tokens, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.Sequential(*[
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
+                  attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, act_layer=act_layer,
+                  num_tokens=num_patches + self.num_tokens)
+            for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.head_dist = None
+        trunc_normal_(self.pos_embed, std=0.02)
+        trunc_normal_(self.cls_token, std=0.02)
+        self.apply(_init_vit_weights)
+
+    def no_weight_decay(self):
+        return {"pos_embed", "cls_token", "dist_token"}
+
+    def forward_features(self, x):
+        x = self.patch_embed(x)
+        x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
+        x = self.pos_drop(x + self.pos_embed)
+        x = self.blocks(x)
+        x = self.norm(x)
+        return self.pre_logits(x[:, 0])
+
+    def forward(self, x):
+        return self.head(self.forward_features(x))
+
+
+def _deit(embed_dim, depth, num_heads, pretrained=False, **kwargs):
+    if pretrained:
+        raise RuntimeError("pretrained weights need network access (torch.hub); not available offline")
+    return VisionTransformer(patch_size=16, embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=4,
+                             qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+@register_model
+def deit_tiny_patch16_224(pretrained=False, **kwargs):
+    """models/model.py:80-100."""
+    return _deit(192, 12, 3, pretrained, **kwargs)
+
+
+@register_model
+def deit_base_patch16_224(pretrained=False, **kwargs):
+    """models/model.py:163-183."""
+    return _deit(768, 12, 12, pretrained, **kwargs)

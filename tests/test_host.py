@@ -1,0 +1,119 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/slimmoe.h
+declares (no compute calls without a GPU), and the nn.Module surface mirrors models/resMoE.py."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+
+import slim_switch_moe_vit_amd as sm
+from slim_switch_moe_vit_amd import _lib, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "slimmoe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(smoe_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _declared_symbols()
+    assert len(syms) >= 9
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"libslimmoe_hip.so does not export {s}"
+    assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table out of sync with include/slimmoe.h"
+
+
+def test_library_loads_and_reports_abi():
+    lib = _lib.load()
+    assert lib.smoe_abi_version() == _lib.ABI_VERSION
+    assert lib.smoe_dispatch_plan_workspace_bytes(50432, 8) >= 2 * 50 * 8 * 4
+
+
+def test_argument_validation_errors_come_back_as_messages():
+    lib = _lib.load()
+    # null pointers / bad sizes are rejected before any launch (safe without a GPU)
+    rc = lib.smoe_router_topk(None, 0, None, None, None, 4, 12, 2, 1, 0, None, None, None, None, None)
+    assert rc != 0 and b"null" in lib.smoe_last_error()
+    rc = lib.smoe_grouped_gemm(None, None, None, None, None, 0, 0, 8, 64, 64, 1, 0, None, None, None, 1, 0, None)
+    assert rc != 0 and lib.smoe_last_error()
+    with pytest.raises(_lib.SlimMoEError):
+        _lib.check(rc, "smoe_grouped_gemm")
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU fallback: the shipped module raises instead of silently computing elsewhere."""
+    m = sm.CustomizedMoEMLP(32, 64, 4, 1, 0.0).eval()
+    with pytest.raises(RuntimeError, match="GPU"):
+        with torch.no_grad():
+            m(torch.randn(2, 3, 32))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.dispatch_plan(torch.zeros(4, dtype=torch.int64), 2)
+
+
+def test_customized_moe_mlp_signature_and_state_dict_keys():
+    sig = inspect.signature(sm.CustomizedMoEMLP.__init__)
+    assert list(sig.parameters)[:7] == ["self", "in_features", "hidden_features", "moe_num_experts", "moe_top_k",
+                                        "drop", "act_layer"]  # models/resMoE.py:15-24
+    m = sm.CustomizedMoEMLP(192, 768, 8, 2, 0.0)
+    sd = m.state_dict()
+    assert sd["gate.gate.weight"].shape == (8, 192) and sd["gate.gate.bias"].shape == (8,)
+    assert sd["experts.htoh4.weight"].shape == (8, 768, 192) and sd["experts.htoh4.bias"].shape == (8, 768)
+    assert sd["experts.h4toh.weight"].shape == (8, 192, 768) and sd["experts.h4toh.bias"].shape == (8, 192)
+    assert m.gate.gate.in_features == 192 and m.gate.gate.out_features == 8  # models/resmoe_flop_hook.py:7
+    assert isinstance(m.experts.activation, nn.Sequential) and isinstance(m.experts.activation[0], nn.GELU)
+
+
+def test_gate_module_mirrors_reference():
+    g = sm.Gate(16, 1.0, starting_threshold=1.0, target_threshold=0.9)
+    assert set(g.state_dict()) == {"head.1.weight", "head.1.bias", "_threshold", "threshold"}  # resMoE.py:43-45
+    x = torch.randn(2, 5, 16)
+    g.disable = True
+    m = g(x)
+    assert m.shape == (2, 5, 2) and torch.all(m[..., 1] == 1) and torch.all(m[..., 0] == 0)
+    g.disable = False
+    g.eval()
+    m = g(x)
+    p = torch.sigmoid(g.head(x))
+    assert torch.equal(m[..., 0:1] > 0.5, p > 0.9) and torch.allclose(m.sum(-1), torch.ones(2, 5))
+    assert g._total_tokens == 10 and g._skipped_tokens == float((p > 0.9).sum())
+    g.step(torch.tensor(0.25))
+    assert float(g._threshold) == pytest.approx(0.9)  # clamps at the target (resMoE.py:53-57)
+
+
+def test_factories_registered_and_patch_every_block():
+    for name in ("resmoe_tiny_patch16_224_expert8", "moe_tiny_patch16_224_expert8"):  # resMoE.py:151,190
+        assert name in sm.list_models()
+    m = sm.create_model("resmoe_tiny_patch16_224_expert8", pretrained=False, num_classes=10, drop_block_rate=None,
+                        starting_threshold=1.0, target_threshold=0.9)
+    blocks = [b for b in m.modules() if isinstance(b, sm.Block)]
+    assert len(blocks) == 12
+    for b in blocks:
+        assert isinstance(b.mlp, sm.CustomizedMoEMLP) and b.mlp.top_k == 2 and b.mlp.num_expert == 8
+        assert isinstance(b.dense_gate, sm.Gate) and isinstance(b.moe_gate, sm.Gate)
+        assert b.forward.__func__ is sm.forward_residule_moe
+    names = [n for n, _ in m.named_parameters()]
+    assert any("moe_gate" in n for n in names) and any("dense_gate" in n for n in names)  # main.py:623
+    m2 = sm.create_model("moe_base_patch16_224_expert8_top1", num_classes=1000)
+    assert m2.blocks[0].mlp.d_model == 768 and m2.blocks[0].mlp.d_hidden == 3072 and m2.blocks[0].mlp.top_k == 1
+
+
+def test_switch_gate_capacity_definitions():
+    g = sm.SwitchGate(768, 8, 1, capacity=1.0)
+    assert g.capacity(50432) == 6304  # BASELINE.md cfg 5: ceil(cf * T_local * k / E)
+    g2 = sm.SwitchGate(768, 8, 1, capacity=(1.2, 2.4), capacity_mode="fmoe")
+    g2.eval()
+    assert g2.capacity(1000) == 2400
+
+
+def test_dense_shell_runs_on_cpu():
+    m = sm.create_model("deit_tiny_patch16_224", num_classes=10).eval()
+    with torch.no_grad():
+        y = m(torch.randn(1, 3, 224, 224))
+    assert y.shape == (1, 10)
