@@ -37,7 +37,9 @@ const char* smoe_last_error(void);
 /* ---- router ------------------------------------------------------------------------------------
  * Replaces fmoe NaiveGate.forward / SwitchGate.forward (gate = nn.Linear(d,E): evidenced by
  * models/resmoe_flop_hook.py:7-8; selected at models/resMoE.py:26-29).
- *   logits = x @ wg^T + bg           accumulated in f64, rounded once to f32
+ *   logits = x @ wg^T + bg           routing decided as if accumulated in f64 and rounded once to f32:
+ *                                    f32 fast path with a rigorous error bound, f64 re-do of a token when a
+ *                                    deciding gap is inside the bound (gate_kind | 0x100 forces f64 for all)
  *   NAIVE : (val, idx) = top-k(logits) [ties: lowest expert id; descending logit]; score = softmax(val)
  *   SWITCH: k == 1; p = softmax(logits + noise) over all E; idx = argmax; score = p[idx];
  *           probs (may be NULL) receives p [T,E] for the aux loss.

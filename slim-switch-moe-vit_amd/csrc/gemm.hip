@@ -22,7 +22,21 @@ constexpr int GEMM_THREADS = 256;
 constexpr int STAGE_BYTES = (BM + BN) * BK_BYTES;  // 32 KiB
 constexpr int C_PAD = 16;                          // bytes
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// exact-erf GELU, erf by Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7): 0.5*(v + |v|*erf(|v|/sqrt2)).
+// ~14 VALU ops incl. one v_rcp_f32 and one v_exp_f32; absolute GELU error < 1e-6 for |v| < 10.
+__device__ __forceinline__ float gelu_erf(float v) {
+  const float a = fabsf(v);
+  const float z = a * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float ex = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+  const float erf_abs = fmaf(-p, ex, 1.0f);
+  return 0.5f * fmaf(a, erf_abs, v);
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * BK_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -68,14 +82,14 @@ template <> __device__ __forceinline__ u32x4 scale16<bf16_bits>(u32x4 raw, float
 
 // locate the (expert, row range) of global m-tile `mt`; returns false if there is no such tile
 __device__ __forceinline__ bool find_tile(const int32_t* __restrict__ offsets, int E, int mt, int& e_out, int& m0,
-                                          int& m_end) {
+                                          int& m_end, int bm = BM) {
   int tile_base = 0;
   for (int e = 0; e < E; ++e) {
     const int lo = offsets[e], hi = offsets[e + 1];
-    const int nt = (hi - lo + BM - 1) / BM;
+    const int nt = (hi - lo + bm - 1) / bm;
     if (mt < tile_base + nt) {
       e_out = e;
-      m0 = lo + (mt - tile_base) * BM;
+      m0 = lo + (mt - tile_base) * bm;
       m_end = hi;
       return true;
     }
@@ -277,14 +291,223 @@ int launch_t128(const void* A, const void* W, const float* bias, const int32_t* 
   return 0;
 }
 
+
+// =====================================================================================================
+// glds variants: global -> LDS by DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write), source
+// address pre-swizzled so the lane-linear LDS image is the same XOR-swizzled image the fragment reads expect
+// (cdna_hip_programming.md rule 21).  Tile TBM x TBN x 64, WM x WN waves, two LDS stages, one barrier per
+// K-tile ("2-phase" structure).  16-bit operands only.
+template <typename AB, typename OT, int TBM, int TBN, int WM, int WN, int MINW>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void grouped_gemm_glds(
+    const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, OT* __restrict__ out, int n_tiles_n,
+    int group_m) {
+  static_assert(sizeof(AB) == 2, "glds variants take 16-bit operands");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = 64 * WM * WN, NW = WM * WN;
+  constexpr int TM = TBM / WM, TN = TBN / WN, MI = TM / 16, NI = TN / 16;
+  constexpr int STAGE = (TBM + TBN) * BK_BYTES;
+  constexpr int A_SLOTS = TBM / 8 / NW, W_SLOTS = TBN / 8 / NW;  // 1-KiB (8-row) DMA pieces per wave
+  static_assert(TBM % (8 * NW) == 0 && TBN % (8 * NW) == 0, "tile rows must split into 8-row pieces per wave");
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int per_group = group_m * n_tiles_n;
+  const int g = bid / per_group, rem = bid % per_group;
+  const int mt = g * group_m + rem % group_m;
+  const int nt = rem / group_m;
+  int e, m0, m_end;
+  if (!find_tile(offsets, E, mt, e, m0, m_end, TBM)) return;
+  if (group_expert) e = group_expert[e];
+  const int n0 = nt * TBN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  // DMA source pointers: piece s of this wave covers tile rows [8*(s*NW+wave), +8); lane -> (row, LDS chunk pos)
+  const int l_row = lane >> 3, l_pos = lane & 7;
+  const AB* a_src[A_SLOTS];
+  const AB* w_src[W_SLOTS];
+#pragma unroll
+  for (int s = 0; s < A_SLOTS; ++s) {
+    const int r = 8 * (s * NW + wave) + l_row;
+    int gr = m0 + r;
+    if (gr >= m_end) gr = m_end - 1;
+    a_src[s] = A + (int64_t)gr * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int s = 0; s < W_SLOTS; ++s) {
+    const int r = 8 * (s * NW + wave) + l_row;
+    int gr = n0 + r;
+    if (gr >= N) gr = N - 1;
+    w_src[s] = W + ((int64_t)e * N + gr) * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+  }
+  auto stage = [&](int kt, int buf) {
+    char* sa = smem + buf * STAGE;
+    char* sw = sa + TBM * BK_BYTES;
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s] + k0),
+                                       (__attribute__((address_space(3))) void*)(sa + (s * NW + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int s = 0; s < W_SLOTS; ++s)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[s] + k0),
+                                       (__attribute__((address_space(3))) void*)(sw + (s * NW + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / 64;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+    const char* sa = smem + cur * STAGE + (wm * TM) * BK_BYTES;
+    const char* sw = smem + cur * STAGE + (TBM + wn * TN) * BK_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      u32x4 af[MI], wf[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const u32x4*>(sw + swz(i * 16 + fr, kk * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const u32x4*>(sa + swz(i * 16 + fr, kk * 4 + fq));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if constexpr (std::is_same<AB, f16>::value)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wf[ni]),
+                                                                  __builtin_bit_cast(f16x8, af[mi]), acc[mi][ni], 0, 0, 0);
+          else
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[ni]),
+                                                                   __builtin_bit_cast(bf16x8_t, af[mi]), acc[mi][ni], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue in row passes through LDS ----------------------------------------------------------------
+  constexpr int OB = OutPack<OT>::bytes;
+  constexpr int C_STRIDE = TBN * OB + C_PAD;
+  constexpr int LDS_BYTES = 2 * STAGE;
+  constexpr int RP = (TBM * C_STRIDE <= LDS_BYTES) ? TBM : ((TBM / 2) * C_STRIDE <= LDS_BYTES ? TBM / 2 : TBM / 4);
+  static_assert(RP * C_STRIDE <= LDS_BYTES, "epilogue pass does not fit in LDS");
+  static_assert(RP % 16 == 0, "pass rows must be whole fragments");
+  constexpr int NPASS = TBM / RP;
+  constexpr int CHUNKS = TBN * OB / 16;
+  constexpr int ROWS_PER_IT = NT / CHUNKS;
+  static_assert(NT % CHUNKS == 0, "threads must tile the row chunks");
+  const float* bias_e = bias ? bias + (int64_t)e * N : nullptr;
+  f32x4 bv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int nl = wn * TN + ni * 16 + fq * 4;
+    bv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias_e && n0 + nl < N) bv[ni] = *reinterpret_cast<const f32x4*>(bias_e + n0 + nl);
+  }
+  const int ch = tid % CHUNKS, r0 = tid / CHUNKS;
+  const int ncol = n0 + ch * (16 / OB);
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row = wm * TM + mi * 16;  // wave-uniform
+      if (row / RP == p) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          f32x4 v = acc[mi][ni] + bv[ni];
+          if (epilogue == SMOE_EPI_GELU) {
+            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+          }
+          const int nl = wn * TN + ni * 16 + fq * 4;
+          OutPack<OT>::write4(smem + (row - p * RP + fr) * C_STRIDE + nl * OB, v);
+        }
+      }
+    }
+    __syncthreads();
+    if (ncol < N) {
+      for (int r = r0; r < RP; r += ROWS_PER_IT) {
+        const int m = m0 + p * RP + r;
+        if (m >= m_end) break;
+        u32x4 v = *reinterpret_cast<const u32x4*>(smem + r * C_STRIDE + ch * 16);
+        int64_t orow = m;
+        if (row_map) {
+          orow = row_map[m];
+          if (row_scale) v = scale16<OT>(v, row_scale[orow]);
+        }
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow * (int64_t)N + ncol) * OB) = v;
+      }
+    }
+    if (p + 1 < NPASS) __syncthreads();
+  }
+}
+
+template <typename AB, typename OT, int TBM, int TBN, int WM, int WN, int MINW>
+int launch_glds(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
+                int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
+                void* out, int group_m, hipStream_t s) {
+  const int n_tiles_n = (N + TBN - 1) / TBN;
+  const int max_m_tiles = (int)((m_rows_max + TBM - 1) / TBM) + E;
+  const int m_groups = (max_m_tiles + group_m - 1) / group_m;
+  const int grid = m_groups * group_m * n_tiles_n;
+  const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
+  auto kern = grouped_gemm_glds<AB, OT, TBM, TBN, WM, WN, MINW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ae != hipSuccess) {
+      smoe_set_error("smoe_grouped_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
+      return (int)ae;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert,
+                     E, K, N, epilogue, row_map, row_scale, (OT*)out, n_tiles_n, group_m);
+  SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
+  return 0;
+}
+
+template <typename AB, typename OT>
+int launch_variant(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets,
+                   const int32_t* group_expert, int E, int64_t m_rows_max, int K, int N, int epilogue,
+                   const int64_t* row_map, const float* row_scale, void* out, hipStream_t s) {
+  if constexpr (sizeof(AB) == 2) {
+    switch (variant) {
+      case 1: return launch_glds<AB, OT, 128, 128, 2, 2, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 8, s);
+      case 2: return launch_glds<AB, OT, 256, 128, 2, 2, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+      case 3: return launch_glds<AB, OT, 256, 256, 2, 4, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+      default: break;
+    }
+  }
+  return launch_t128<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
+}
+
 template <typename AB>
-int dispatch_out(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
+int dispatch_out(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                  int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
                  void* out, int out_dtype, hipStream_t s) {
   switch (out_dtype) {
-    case SMOE_F32: return launch_t128<AB, float>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
-    case SMOE_F16: return launch_t128<AB, f16>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
-    case SMOE_BF16: return launch_t128<AB, bf16_bits>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
+    case SMOE_F32: return launch_variant<AB, float>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
+    case SMOE_F16: return launch_variant<AB, f16>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
+    case SMOE_BF16: return launch_variant<AB, bf16_bits>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
   }
   smoe_set_error("smoe_grouped_gemm: bad out_dtype %d", out_dtype);
   return 1;
@@ -308,12 +531,12 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   SMOE_REQUIRE(N % 8 == 0, "smoe_grouped_gemm: N=%d must be a multiple of 8", N);
   if (m_rows_max == 0) return 0;
   SMOE_REQUIRE(A && W && out, "smoe_grouped_gemm: null pointer");
-  (void)variant;
+  if (K % 64 != 0 || smoe_dtype_size(ab_dtype) != 2) variant = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (ab_dtype) {
-    case SMOE_F32: return dispatch_out<float>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
-    case SMOE_F16: return dispatch_out<f16>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
-    case SMOE_BF16: return dispatch_out<bf16_bits>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
+    case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
+    case SMOE_F16: return dispatch_out<f16>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
+    case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
   }
   return 1;
 }

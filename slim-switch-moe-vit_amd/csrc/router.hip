@@ -1,11 +1,18 @@
-// Router: gate logits (f64 accumulate) + top-k + softmax.  HBM-bound: reads the token matrix once.
+// Router: gate logits + top-k + softmax.  HBM-bound: reads the token matrix once.
 // Replaces fmoe NaiveGate / SwitchGate forward.
 //
-// Layout: one wave per token row (coalesced 16-B loads of the whole row: lane l owns elements
-// [256c + 4l, 256c + 4l + 4) of chunk c), eight experts at a time.  The router weights sit in LDS as
-// f64 (or are read through L2 as f32 when E*d*8 exceeds the LDS budget).  The 8 per-lane partial sums
-// of a group of 8 experts are reduced with a transposed butterfly (10 shuffles instead of 48): after
-// it, lanes with equal (lane>>3) hold the full logit of expert 4*b5 + 2*b4 + b3.
+// Contract (oracle/moe_oracle.py): routing is decided on logits accumulated in f64 and rounded once to
+// f32, so it cannot depend on summation order.  f64 FMAs for every token would make this kernel
+// compute-bound (measured 1.05 TB/s), so each token first gets f32 logits with a rigorous error bound
+//     |logit_f32 - exact| <= (n1 + 7) u ||x|| ||w||max   (n1 = per-lane FMA chain, 6 butterfly levels + bias)
+// and only when one of the gaps that decide the result (between consecutive entries of the top-(k+1))
+// is inside that bound is the token re-done in f64 -- a wave-uniform, rare branch (~1e-4 of tokens).
+// Either way idx equals the oracle's; score/logits carry f32 rounding (<= ~1e-6).
+//
+// Layout: one wave per token row (coalesced 16-B loads: lane l owns elements [256c + 4l, +4) of chunk c),
+// eight experts at a time; router weights in LDS as f32.  The 8 per-lane partial sums of a group of 8
+// experts are reduced with a transposed butterfly (10 shuffles instead of 48): afterwards lanes with
+// equal (lane>>3) hold the full logit of expert 4*b5 + 2*b4 + b3 of the group.
 #include "smoe_common.h"
 
 namespace {
@@ -13,35 +20,84 @@ namespace {
 constexpr int ROUTER_THREADS = 512;
 constexpr int ROUTER_WAVES = ROUTER_THREADS / 64;
 constexpr int ROUTER_MAX_K = 8;
+constexpr int NONE_IDX = 0x7fffffff;
 
-__device__ __forceinline__ double shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 64); }
+template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int m) { return __shfl_xor(v, m, 64); }
+
+// 8 values per lane (value i = partial sum of expert i) -> every lane gets the wave total of expert
+// 4*b5 + 2*b4 + b3 (b = bits of its lane id)
+template <typename T> __device__ __forceinline__ T butterfly8(const T (&acc)[8], int lane) {
+  T a4[4], a2[2], a1;
+  {
+    const bool hi = lane & 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const T send = hi ? acc[i] : acc[i + 4];
+      const T keep = hi ? acc[i + 4] : acc[i];
+      a4[i] = keep + shfl_xor_t(send, 32);
+    }
+  }
+  {
+    const bool hi = lane & 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const T send = hi ? a4[i] : a4[i + 2];
+      const T keep = hi ? a4[i + 2] : a4[i];
+      a2[i] = keep + shfl_xor_t(send, 16);
+    }
+  }
+  {
+    const bool hi = lane & 8;
+    const T send = hi ? a2[0] : a2[1];
+    const T keep = hi ? a2[1] : a2[0];
+    a1 = keep + shfl_xor_t(send, 8);
+  }
+  a1 += shfl_xor_t(a1, 4);
+  a1 += shfl_xor_t(a1, 2);
+  a1 += shfl_xor_t(a1, 1);
+  return a1;
+}
 
 template <typename XT, int NCH, bool W_LDS>
 __global__ __launch_bounds__(ROUTER_THREADS) void router_kernel(
     const XT* __restrict__ x, const float* __restrict__ wg, const float* __restrict__ bg,
-    const float* __restrict__ noise, int64_t T, int d, int E, int k, int gate_kind,
+    const float* __restrict__ noise, int64_t T, int d, int E, int k, int gate_kind, int force_f64,
     int64_t* __restrict__ idx_out, float* __restrict__ score_out, float* __restrict__ logits_out,
     float* __restrict__ probs_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Epad = (E + 7) & ~7;
-  // carve: [ROUTER_WAVES][Epad] f32 logits, then (W_LDS) [Epad][d] f64 weights
+  // carve: [ROUTER_WAVES][Epad] f32 logits | [Epad] f32 squared weight norms (+pad) | (W_LDS) [Epad][d] f32 weights
   float* lds_logit = reinterpret_cast<float*>(smem);
-  const size_t logit_bytes = ((size_t)ROUTER_WAVES * Epad * 4 + 15) & ~(size_t)15;
-  double* lds_w = reinterpret_cast<double*>(smem + logit_bytes);
+  const size_t logit_bytes = ((size_t)(ROUTER_WAVES + 1) * Epad * 4 + 15) & ~(size_t)15;
+  float* lds_wn2 = lds_logit + ROUTER_WAVES * Epad;
+  float* lds_w = reinterpret_cast<float*>(smem + logit_bytes);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
 
   if (W_LDS) {
-    for (int i = tid; i < Epad * d; i += ROUTER_THREADS) {
-      const int e = i / d;
-      lds_w[i] = (e < E) ? (double)wg[i] : 0.0;
+    for (int i = tid * 4; i < Epad * d; i += ROUTER_THREADS * 4) {
+      const int e = i / d;  // d % 4 == 0: a float4 never straddles two experts
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e < E) v = *reinterpret_cast<const f32x4*>(wg + i);
+      *reinterpret_cast<f32x4*>(lds_w + i) = v;
     }
-    __syncthreads();
   }
-  float* my_logit = lds_logit + wave * Epad;
+  // squared row norms of the router weights (for the error bound)
+  for (int e = wave; e < Epad; e += ROUTER_WAVES) {
+    float s = 0.f;
+    if (e < E)
+      for (int c = lane; c < d; c += 64) { const float w = wg[(size_t)e * d + c]; s = fmaf(w, w, s); }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) lds_wn2[e] = s;
+  }
+  __syncthreads();
+  float wmax2 = 0.f;
+  for (int e = 0; e < E; ++e) wmax2 = fmaxf(wmax2, lds_wn2[e]);
 
+  float* my_logit = lds_logit + wave * Epad;
   const int64_t wave_gid = (int64_t)blockIdx.x * ROUTER_WAVES + wave;
   const int64_t wave_stride = (int64_t)gridDim.x * ROUTER_WAVES;
 
@@ -60,118 +116,143 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_kernel(
       }
     }
   };
+  auto load_w = [&](int e, int col, float (&wf)[4]) {
+    if (W_LDS) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(lds_w + (size_t)e * d + col);
+      wf[0] = v[0]; wf[1] = v[1]; wf[2] = v[2]; wf[3] = v[3];
+    } else if (e < E) {
+      load4(wg + (size_t)e * d + col, wf);
+    } else {
+      wf[0] = wf[1] = wf[2] = wf[3] = 0.f;
+    }
+  };
 
   int64_t t = wave_gid;
   if (t < T) load_row(t);
   for (; t < T; t += wave_stride) {
-    double xd[NCH][4];
+    float xc[NCH][4];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xd[c][j] = (double)xn[c][j];
+      for (int j = 0; j < 4; ++j) xc[c][j] = xn[c][j];
     const int64_t tn = t + wave_stride;
     if (tn < T) load_row(tn);  // prefetch the next row under this row's arithmetic
 
-    for (int eb = 0; eb < Epad; eb += 8) {
-      double acc[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = 0.0;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if (cvalid[c]) {
-          const int col = c * 256 + lane * 4;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            double w0, w1, w2, w3;
-            if (W_LDS) {
-              const double* wp = lds_w + (size_t)(eb + i) * d + col;
-              w0 = wp[0]; w1 = wp[1]; w2 = wp[2]; w3 = wp[3];
-            } else {
-              if (eb + i < E) {
-                float wf[4];
-                load4(wg + (size_t)(eb + i) * d + col, wf);
-                w0 = wf[0]; w1 = wf[1]; w2 = wf[2]; w3 = wf[3];
-              } else {
-                w0 = w1 = w2 = w3 = 0.0;
-              }
-            }
-            acc[i] = fma(xd[c][0], w0, acc[i]);
-            acc[i] = fma(xd[c][1], w1, acc[i]);
-            acc[i] = fma(xd[c][2], w2, acc[i]);
-            acc[i] = fma(xd[c][3], w3, acc[i]);
-          }
-        }
-      }
-      // transposed butterfly: 8 values/lane -> 1 value/lane
-      double a4[4], a2[2], a1;
-      {
-        const bool hi = lane & 32;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const double send = hi ? acc[i] : acc[i + 4];
-          const double keep = hi ? acc[i + 4] : acc[i];
-          a4[i] = keep + shfl_xor_f64(send, 32);
-        }
-      }
-      {
-        const bool hi = lane & 16;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const double send = hi ? a4[i] : a4[i + 2];
-          const double keep = hi ? a4[i + 2] : a4[i];
-          a2[i] = keep + shfl_xor_f64(send, 16);
-        }
-      }
-      {
-        const bool hi = lane & 8;
-        const double send = hi ? a2[0] : a2[1];
-        const double keep = hi ? a2[1] : a2[0];
-        a1 = keep + shfl_xor_f64(send, 8);
-      }
-      a1 += shfl_xor_f64(a1, 4);
-      a1 += shfl_xor_f64(a1, 2);
-      a1 += shfl_xor_f64(a1, 1);
+    auto publish = [&](int eb, float lg_wave, bool f64_path, double lg64) {
       const int el = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
       const int e = eb + el;
       if ((lane & 7) == 0 && e < E) {
-        const double b = bg ? (double)bg[e] : 0.0;
-        float lg = (float)(a1 + b);
+        float lg;
+        if (f64_path) lg = (float)(lg64 + (bg ? (double)bg[e] : 0.0));
+        else lg = lg_wave + (bg ? bg[e] : 0.f);
         if (logits_out) logits_out[t * (int64_t)E + e] = lg;
         if (gate_kind == SMOE_GATE_SWITCH && noise) lg += noise[t * (int64_t)E + e];
         my_logit[e] = lg;
       }
-    }
-    // LDS writes by this wave are visible to this wave after the wait (same wave, in-order DS pipe)
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- top-k over my_logit[0..E) : ties -> lowest expert id ----
-    int chosen[ROUTER_MAX_K];
-    float chosen_val[ROUTER_MAX_K];
+    };
+    auto logits_f32 = [&]() {
+      for (int eb = 0; eb < Epad; eb += 8) {
+        float acc[8];
 #pragma unroll
-    for (int r = 0; r < ROUTER_MAX_K; ++r) { chosen[r] = -1; chosen_val[r] = 0.f; }
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int r = 0; r < ROUTER_MAX_K; ++r) {
-      if (r < k) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int e = lane; e < E; e += 64) {
-          bool taken = false;
+        for (int c = 0; c < NCH; ++c) {
+          if (cvalid[c]) {
+            const int col = c * 256 + lane * 4;
 #pragma unroll
-          for (int q = 0; q < ROUTER_MAX_K; ++q) taken |= (q < r) && (chosen[q] == e);
-          const float v = my_logit[e];
-          if (!taken && (v > bv || (v == bv && e < bi) || bi == 0x7fffffff)) { bv = v; bi = e; }
+            for (int i = 0; i < 8; ++i) {
+              float wf[4];
+              load_w(eb + i, col, wf);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[i] = fmaf(xc[c][j], wf[j], acc[i]);
+            }
+          }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-          const float ov = __shfl_xor(bv, m, 64);
-          const int oi = __shfl_xor(bi, m, 64);
-          const bool take = (oi != 0x7fffffff) && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi));
-          if (take) { bv = ov; bi = oi; }
-        }
-        chosen[r] = bi;
-        chosen_val[r] = bv;
+        publish(eb, butterfly8(acc, lane), false, 0.0);
       }
+    };
+    auto logits_f64 = [&]() {
+      for (int eb = 0; eb < Epad; eb += 8) {
+        double acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (cvalid[c]) {
+            const int col = c * 256 + lane * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              float wf[4];
+              load_w(eb + i, col, wf);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[i] = fma((double)xc[c][j], (double)wf[j], acc[i]);
+            }
+          }
+        }
+        publish(eb, 0.f, true, butterfly8(acc, lane));
+      }
+    };
+    // top-kc over my_logit[0..E): ties -> lowest expert id, order = descending value
+    int chosen[ROUTER_MAX_K + 1];
+    float chosen_val[ROUTER_MAX_K + 1];
+    auto select = [&](int kc) {
+#pragma unroll
+      for (int r = 0; r <= ROUTER_MAX_K; ++r) { chosen[r] = -1; chosen_val[r] = 0.f; }
+#pragma unroll
+      for (int r = 0; r <= ROUTER_MAX_K; ++r) {
+        if (r < kc) {
+          float bv = -INFINITY;
+          int bi = NONE_IDX;
+          for (int e = lane; e < E; e += 64) {
+            bool taken = false;
+#pragma unroll
+            for (int q = 0; q <= ROUTER_MAX_K; ++q) taken |= (q < r) && (chosen[q] == e);
+            const float v = my_logit[e];
+            if (!taken && (bi == NONE_IDX || v > bv || (v == bv && e < bi))) { bv = v; bi = e; }
+          }
+#pragma unroll
+          for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(bv, m, 64);
+            const int oi = __shfl_xor(bi, m, 64);
+            const bool take = (oi != NONE_IDX) && (bi == NONE_IDX || ov > bv || (ov == bv && oi < bi));
+            if (take) { bv = ov; bi = oi; }
+          }
+          chosen[r] = bi;
+          chosen_val[r] = bv;
+        }
+      }
+    };
+
+    const int kc = (k < E) ? k + 1 : k;  // the (k+1)-th value guards the boundary of the kept set
+    bool need_f64 = force_f64 != 0;
+    if (!need_f64) {
+      float xs = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs = fmaf(xc[c][j], xc[c][j], xs);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) xs += __shfl_xor(xs, m, 64);
+      logits_f32();
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes precede its reads
+      __builtin_amdgcn_wave_barrier();
+      select(kc);
+      // 2 x (bound on each logit) with a 2x safety factor; + rounding of the stored f32 values (+ noise add)
+      float amax = 0.f;
+#pragma unroll
+      for (int r = 0; r <= ROUTER_MAX_K; ++r)
+        if (r < kc) amax = fmaxf(amax, fabsf(chosen_val[r]));
+      const float bound = 4.0f * (float)(NCH * 4 + 8) * 5.9604645e-8f * sqrtf(xs * wmax2) + 9.6e-7f * (amax + 1.0f);
+#pragma unroll
+      for (int r = 0; r < ROUTER_MAX_K; ++r)
+        if (r + 1 < kc) need_f64 |= !((chosen_val[r] - chosen_val[r + 1]) > bound);
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (need_f64) {  // wave-uniform
+      logits_f64();
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      select(k);
     }
 
     if (gate_kind == SMOE_GATE_NAIVE) {
@@ -212,22 +293,22 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_kernel(
 }
 
 template <typename XT, int NCH>
-int launch_router(const void* x, const float* wg, const float* bg, const float* noise, int64_t T, int d,
-                  int E, int k, int gate_kind, int64_t* idx, float* score, float* logits_out, float* probs,
+int launch_router(const void* x, const float* wg, const float* bg, const float* noise, int64_t T, int d, int E,
+                  int k, int gate_kind, int force_f64, int64_t* idx, float* score, float* logits_out, float* probs,
                   hipStream_t stream) {
   const int Epad = (E + 7) & ~7;
-  const size_t logit_bytes = ((size_t)ROUTER_WAVES * Epad * 4 + 15) & ~(size_t)15;
-  const size_t w_bytes = (size_t)Epad * d * 8;
+  const size_t logit_bytes = ((size_t)(ROUTER_WAVES + 1) * Epad * 4 + 15) & ~(size_t)15;
+  const size_t w_bytes = (size_t)Epad * d * 4;
   const bool w_lds = (logit_bytes + w_bytes) <= 64 * 1024;
   const size_t smem = logit_bytes + (w_lds ? w_bytes : 0);
   int64_t need = (T + ROUTER_WAVES - 1) / ROUTER_WAVES;
   int grid = (int)(need < 512 ? (need < 1 ? 1 : need) : 512);
   if (w_lds) {
-    hipLaunchKernelGGL((router_kernel<XT, NCH, true>), dim3(grid), dim3(ROUTER_THREADS), smem, stream,
-                       (const XT*)x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs);
+    hipLaunchKernelGGL((router_kernel<XT, NCH, true>), dim3(grid), dim3(ROUTER_THREADS), smem, stream, (const XT*)x,
+                       wg, bg, noise, T, d, E, k, gate_kind, force_f64, idx, score, logits_out, probs);
   } else {
-    hipLaunchKernelGGL((router_kernel<XT, NCH, false>), dim3(grid), dim3(ROUTER_THREADS), smem, stream,
-                       (const XT*)x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs);
+    hipLaunchKernelGGL((router_kernel<XT, NCH, false>), dim3(grid), dim3(ROUTER_THREADS), smem, stream, (const XT*)x,
+                       wg, bg, noise, T, d, E, k, gate_kind, force_f64, idx, score, logits_out, probs);
   }
   SMOE_CHECK_LAUNCH("smoe_router_topk");
   return 0;
@@ -235,18 +316,18 @@ int launch_router(const void* x, const float* wg, const float* bg, const float* 
 
 template <typename XT>
 int dispatch_nch(const void* x, const float* wg, const float* bg, const float* noise, int64_t T, int d, int E,
-                 int k, int gate_kind, int64_t* idx, float* score, float* logits_out, float* probs,
+                 int k, int gate_kind, int f64, int64_t* idx, float* score, float* logits_out, float* probs,
                  hipStream_t s) {
   const int nch = (d + 255) / 256;
   switch (nch) {
-    case 1: return launch_router<XT, 1>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
-    case 2: return launch_router<XT, 2>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
-    case 3: return launch_router<XT, 3>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
-    case 4: return launch_router<XT, 4>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
-    case 5: return launch_router<XT, 5>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
-    case 6: return launch_router<XT, 6>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
-    case 7: return launch_router<XT, 7>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
-    case 8: return launch_router<XT, 8>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
+    case 1: return launch_router<XT, 1>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
+    case 2: return launch_router<XT, 2>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
+    case 3: return launch_router<XT, 3>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
+    case 4: return launch_router<XT, 4>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
+    case 5: return launch_router<XT, 5>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
+    case 6: return launch_router<XT, 6>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
+    case 7: return launch_router<XT, 7>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
+    case 8: return launch_router<XT, 8>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
   }
   smoe_set_error("smoe_router_topk: d=%d unsupported (d <= 2048)", d);
   return 1;
@@ -254,9 +335,12 @@ int dispatch_nch(const void* x, const float* wg, const float* bg, const float* n
 
 }  // namespace
 
+// gate_kind bit 8 (0x100) forces the all-f64 path (test hook: every token through the fallback)
 extern "C" int smoe_router_topk(const void* x, int x_dtype, const float* wg, const float* bg, const float* noise,
                                 int64_t T, int d, int E, int k, int gate_kind, int64_t* idx, float* score,
                                 float* logits_out, float* probs, void* stream) {
+  const int force_f64 = (gate_kind & 0x100) ? 1 : 0;
+  gate_kind &= 0xff;
   SMOE_REQUIRE(x && wg && idx && score, "smoe_router_topk: null pointer");
   SMOE_REQUIRE(T >= 0 && d > 0 && E > 0, "smoe_router_topk: bad sizes T=%lld d=%d E=%d", (long long)T, d, E);
   SMOE_REQUIRE(d % 8 == 0 && d <= 2048, "smoe_router_topk: d=%d must be a multiple of 8 and <= 2048", d);
@@ -269,9 +353,9 @@ extern "C" int smoe_router_topk(const void* x, int x_dtype, const float* wg, con
   if (T == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   switch (x_dtype) {
-    case SMOE_F32: return dispatch_nch<float>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
-    case SMOE_F16: return dispatch_nch<f16>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
-    case SMOE_BF16: return dispatch_nch<bf16_bits>(x, wg, bg, noise, T, d, E, k, gate_kind, idx, score, logits_out, probs, s);
+    case SMOE_F32: return dispatch_nch<float>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, idx, score, logits_out, probs, s);
+    case SMOE_F16: return dispatch_nch<f16>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, idx, score, logits_out, probs, s);
+    case SMOE_BF16: return dispatch_nch<bf16_bits>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, idx, score, logits_out, probs, s);
   }
   smoe_set_error("smoe_router_topk: bad x_dtype %d", x_dtype);
   return 1;

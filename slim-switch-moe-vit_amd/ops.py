@@ -84,7 +84,8 @@ def _chk(t: torch.Tensor, name: str, dtype=None, ndim=None):
 
 
 def router_topk(x: torch.Tensor, wg: torch.Tensor, bg: Optional[torch.Tensor], k: int, gate_kind: int = GATE_NAIVE,
-                noise: Optional[torch.Tensor] = None, want_logits: bool = False, want_probs: bool = False):
+                noise: Optional[torch.Tensor] = None, want_logits: bool = False, want_probs: bool = False,
+                force_f64: bool = False):
     """(idx int64 [T,k], score f32 [T,k], logits f32 [T,E] | None, probs f32 [T,E] | None)."""
     _chk(x, "x", ndim=2)
     _chk(wg, "wg", torch.float32, 2)
@@ -106,8 +107,9 @@ def router_topk(x: torch.Tensor, wg: torch.Tensor, bg: Optional[torch.Tensor], k
     probs = torch.empty((T, E), dtype=torch.float32, device=x.device) if want_probs else None
     lib = _lib.load()
     with _timed("router", {"bytes": T * d * x.element_size()}, x):
-        rc = lib.smoe_router_topk(_ptr(x), dtype_code(x.dtype), _ptr(wg), _ptr(bg), _ptr(noise), T, d, E, k, gate_kind,
-                                  _ptr(idx), _ptr(score), _ptr(logits), _ptr(probs), _stream(x))
+        rc = lib.smoe_router_topk(_ptr(x), dtype_code(x.dtype), _ptr(wg), _ptr(bg), _ptr(noise), T, d, E, k,
+                                  gate_kind | (0x100 if force_f64 else 0), _ptr(idx), _ptr(score), _ptr(logits),
+                                  _ptr(probs), _stream(x))
     _lib.check(rc, "smoe_router_topk")
     return idx, score, logits, probs
 

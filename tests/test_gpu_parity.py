@@ -41,16 +41,20 @@ def _mk(T, d, h, E, seed, wstd=0.02, skew=False):
 @pytest.mark.parametrize("T,d,E,k", [(1, 192, 4, 1), (777, 192, 4, 2), (5000, 768, 8, 1), (3000, 768, 8, 2),
                                      (2000, 1024, 32, 1), (513, 64, 3, 3), (1000, 384, 70, 2)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
-def test_router_naive_matches_oracle(T, d, E, k, dtype):
+@pytest.mark.parametrize("force_f64", [False, True])
+def test_router_naive_matches_oracle(T, d, E, k, dtype, force_f64):
     g = _gen(T + d + E)
     x = torch.randn(T, d, generator=g).to(dtype)
     wg = torch.randn(E, d, generator=g) * 0.05
     bg = torch.randn(E, generator=g) * 0.1
-    idx, score, logits, _ = ops.router_topk(x.to(DEV), wg.to(DEV), bg.to(DEV), k, ops.GATE_NAIVE, want_logits=True)
+    idx, score, logits, _ = ops.router_topk(x.to(DEV), wg.to(DEV), bg.to(DEV), k, ops.GATE_NAIVE, want_logits=True,
+                                            force_f64=force_f64)
     o_idx, o_score, o_logits = mo.naive_gate(x.float(), wg, bg, k)
     assert torch.equal(idx.cpu(), o_idx), "routing indices must be bit-exact"
-    assert torch.equal(logits.cpu(), o_logits), "f64-accumulated logits round to the same f32"
-    assert torch.allclose(score.cpu(), o_score, rtol=0, atol=2e-6)
+    if force_f64:
+        assert torch.equal(logits.cpu(), o_logits), "f64-accumulated logits round to the same f32"
+    assert torch.allclose(logits.cpu(), o_logits, rtol=0, atol=1e-5)
+    assert torch.allclose(score.cpu(), o_score, rtol=0, atol=5e-6)
     if k == 1:
         assert torch.all(score == 1.0)
 
@@ -64,6 +68,24 @@ def test_router_zero_rows_route_by_bias_with_lowest_id_tie_break():
     assert torch.allclose(score.cpu(), torch.full((300, 2), 0.5))
 
 
+def test_router_near_ties_take_the_f64_path_and_match_the_oracle():
+    """Experts whose logits differ by less than f32 summation noise: the f32 fast path must hand these
+    tokens to the f64 re-do, which orders them exactly like the oracle."""
+    T, d, E = 4096, 768, 8
+    g = _gen(21)
+    x = torch.randn(T, d, generator=g)
+    wg = torch.randn(E, d, generator=g) * 0.02
+    wg[5] = wg[2]                      # exact tie between experts 2 and 5 on every token
+    wg[6] = wg[1]; wg[6, 17] += 3e-9   # near tie: gap ~3e-9 * |x|, far below f32 accumulation error
+    wg[7] = wg[1]; wg[7, 400] -= 5e-9
+    bg = torch.zeros(E)
+    for k in (1, 2, 3):
+        idx, score, _, _ = ops.router_topk(x.to(DEV), wg.to(DEV), bg.to(DEV), k, ops.GATE_NAIVE)
+        o_idx, o_score, _ = mo.naive_gate(x, wg, bg, k)
+        assert torch.equal(idx.cpu(), o_idx)
+        assert torch.allclose(score.cpu(), o_score, rtol=0, atol=5e-6)
+
+
 @pytest.mark.parametrize("with_noise", [False, True])
 def test_router_switch_matches_oracle(with_noise):
     T, d, E = 4000, 768, 8
@@ -74,8 +96,8 @@ def test_router_switch_matches_oracle(with_noise):
                                            noise.to(DEV) if with_noise else None, want_probs=True)
     o_idx, o_score, o_p = mo.switch_gate(x, wg, bg, noise)
     assert torch.equal(idx.cpu(), o_idx)
-    assert torch.allclose(score.cpu(), o_score, rtol=0, atol=2e-6)
-    assert torch.allclose(probs.cpu(), o_p, rtol=0, atol=2e-6)
+    assert torch.allclose(score.cpu(), o_score, rtol=0, atol=5e-6)
+    assert torch.allclose(probs.cpu(), o_p, rtol=0, atol=5e-6)
 
 
 # ------------------------------------------------------------------------------------------ plan
@@ -147,7 +169,10 @@ def _gemm_ref(A, W, bias, offsets, gelu):
                                         ([700, 650, 600, 800, 655, 690, 710, 640], 768, 3072)])
 @pytest.mark.parametrize("cd,tol", [(torch.float32, 2e-5), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("gelu", [False, True])
-def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu):
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu, variant):
+    if variant and (cd == torch.float32 or K % 64):
+        pytest.skip("glds variants take 16-bit operands and K % 64 == 0")
     E = len(counts)
     offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
     M = int(offsets[-1])
@@ -157,7 +182,7 @@ def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu):
     bias = torch.randn(E, N, generator=g) * 0.1
     out = torch.full((M + 7, N), 7.0, dtype=torch.float32, device=DEV)
     ops.grouped_gemm(A.to(DEV), W.to(DEV), bias.to(DEV), torch.from_numpy(offsets).to(DEV),
-                     ops.EPI_GELU if gelu else ops.EPI_NONE, out=out)
+                     ops.EPI_GELU if gelu else ops.EPI_NONE, out=out, variant=variant)
     ref = _gemm_ref(A, W, bias, offsets, gelu)
     got = out.cpu().double()
     scale = max(1.0, float(ref.abs().max()))
@@ -165,7 +190,9 @@ def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu):
     assert torch.all(got[M:] == 7.0), "rows past the last expert must stay untouched"
 
 
-def test_grouped_gemm_fused_combine_row_map():
+@pytest.mark.parametrize("variant,cd", [(0, torch.float32), (0, torch.float16), (1, torch.float16), (3, torch.float16),
+                                        (3, torch.bfloat16)])
+def test_grouped_gemm_fused_combine_row_map(variant, cd):
     E, K, N, T = 4, 128, 64, 1000
     g = _gen(3)
     idx = torch.randint(0, E, (T, 1), generator=g)
@@ -174,14 +201,16 @@ def test_grouped_gemm_fused_combine_row_map():
     W = torch.randn(E, N, K, generator=g) * 0.05
     score = torch.rand(T, generator=g)
     out = torch.zeros(T, N, device=DEV)
-    ops.grouped_gemm(A.to(DEV), W.to(DEV), None, offsets, ops.EPI_NONE, row_map=pos, row_scale=score.to(DEV), out=out)
+    A, W = A.to(cd), W.to(cd)
+    ops.grouped_gemm(A.to(DEV), W.to(DEV), None, offsets, ops.EPI_NONE, row_map=pos, row_scale=score.to(DEV), out=out,
+                     variant=variant)
     p = mo.dispatch_plan(idx.numpy(), E, 200)
     ref = torch.zeros(T, N, dtype=torch.float64)
     y = _gemm_ref(A, W, None, p.offsets, False)
     kept = int(p.offsets[E])
     tok = torch.from_numpy(p.pos[:kept])
     ref[tok] = y[:kept] * score[tok, None].double()
-    assert (out.cpu().double() - ref).abs().max() < 2e-5
+    assert (out.cpu().double() - ref).abs().max() < (2e-5 if cd == torch.float32 else 1e-4)
 
 
 # ------------------------------------------------------------------------------------------ whole operator
@@ -296,8 +325,17 @@ def test_cfg2_full_size_properties():
         perm = torch.randperm(T, generator=_gen(1)).to(DEV)
         outp = mod(xg[perm].reshape(B, N, d)).reshape(T, d)
         assert (outp - out.reshape(T, d)[perm]).abs().max().item() == 0.0
-    # sampled oracle comparison: 2048 random tokens, tolerance 1e-3 (f16 MFMA operands, f32 accumulate)
+    # sampled oracle comparison on 2048 random tokens.  f16 MFMA operands (f32 accumulate): relative L2 error
+    # <= 1e-3 and max-abs <= 2.5e-3 at this scale (error budget in DESIGN.md: four 2^-11 roundings of O(1)
+    # data over K = 768 / 3072 give sigma ~ 2.3e-4, i.e. ~1.5e-3 at the 5.5-sigma tail of 1.5M samples)
     sel = torch.randperm(T, generator=_gen(2))[:2048]
     r = mo.moe_forward(x[sel], wg, bg, w1, b1, w2, b2, 1)
-    err = (out.reshape(T, d).cpu()[sel] - r.out).abs().max().item()
-    assert err <= 1e-3, err
+    diff = out.reshape(T, d).cpu()[sel] - r.out
+    rel_l2 = (diff.norm() / r.out.norm()).item()
+    assert rel_l2 <= 1e-3, rel_l2
+    assert diff.abs().max().item() <= 2.5e-3, diff.abs().max().item()
+    # the f32-exact MFMA mode meets the strict bound on every element
+    mod32 = _load_module(sm.CustomizedMoEMLP(d, h, E, 1, 0.0, compute_dtype=torch.float32), wg, bg, w1, b1, w2, b2)
+    with torch.no_grad():
+        out32 = mod32(xg[sel.to(DEV)].reshape(8, 256, d)).reshape(-1, d).cpu()
+    assert (out32 - r.out).abs().max().item() <= 1e-4
