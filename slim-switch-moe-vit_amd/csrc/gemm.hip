@@ -485,6 +485,255 @@ int launch_glds(const void* A, const void* W, const float* bias, const int32_t* 
   return 0;
 }
 
+
+// =====================================================================================================
+// variant 4 ("pp256"): 256x256x64 tile, 8 waves as 2(M) x 4(N), wave tile 128x64, glds staging into two
+// 64-KiB LDS buffers.  Waves w and w+4 share a SIMD; group 1 (waves 4-7) runs ONE barrier interval behind
+// group 0, so in every interval one wave of each SIMD issues its 16-MFMA cluster while its partner issues
+// the ds_read_b128 fragment reads (and the DMA prefetch) for its next cluster: LDS reads and MFMA overlap
+// instead of alternating.  Per K-tile a wave walks 4 quadrants of its 128x64 output (A-half x B-half),
+// re-reading only the operand half that changes: (A0,B0) (A0,B1) (A1,B1) (A1,B0).
+//
+// Interval clock (group-0 time, 8 intervals per K-tile t):  R1 M1 R2 M2 R3 M3 R4 M4; group 1 is +1.
+//   WAR: tile t+1 is staged into the buffer tile t-1 used; its last reads (group 1's R4(t-1)) are
+//        retired by that group's lgkmcnt(0) at the start of global interval 8t, so DMA issue starts in
+//        each wave's program interval 1 of tile t (global >= 8t+1).
+//   RAW: every wave drains its own DMAs (vmcnt(0)) before the barrier that closes global interval 8t+7
+//        (program interval 7 for group 0, 6 for group 1); first reads of tile t+1 come after that barrier.
+#define PP_BARRIER()                         \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    asm volatile("" ::: "memory");           \
+    __builtin_amdgcn_s_barrier();            \
+    asm volatile("" ::: "memory");           \
+    __builtin_amdgcn_sched_barrier(0);       \
+  } while (0)
+
+template <typename AB, typename OT>
+__global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
+    const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, OT* __restrict__ out, int n_tiles_n,
+    int group_m) {
+  static_assert(sizeof(AB) == 2, "16-bit operands");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TBM = 256, TBN = 256, NT = 512, NW = 8;
+  constexpr int STAGE = (TBM + TBN) * BK_BYTES;  // 64 KiB
+  constexpr int SLOTS = 4;                       // 1-KiB DMA pieces per wave per operand per K-tile
+
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int per_group = group_m * n_tiles_n;
+  const int g = bid / per_group, rem = bid % per_group;
+  const int mt = g * group_m + rem % group_m;
+  const int nt = rem / group_m;
+  int e, m0, m_end;
+  if (!find_tile(offsets, E, mt, e, m0, m_end, TBM)) return;
+  if (group_expert) e = group_expert[e];
+  const int n0 = nt * TBN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int l_row = lane >> 3, l_pos = lane & 7;
+  const AB* a_src[SLOTS];
+  const AB* w_src[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int r = 8 * (s * NW + wave) + l_row;
+    int gr = m0 + r;
+    if (gr >= m_end) gr = m_end - 1;
+    a_src[s] = A + (int64_t)gr * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+    int gw = n0 + r;
+    if (gw >= N) gw = N - 1;
+    w_src[s] = W + ((int64_t)e * N + gw) * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+  }
+  // DMA of pieces [s0, s0+2) of A or W of K-tile kt into buffer buf
+  auto dma_a = [&](int kt, int buf, int s0) {
+    char* sa = smem + buf * STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s0 + s] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(sa + ((s0 + s) * NW + wave) * 1024), 16, 0, 0);
+  };
+  auto dma_w = [&](int kt, int buf, int s0) {
+    char* sw = smem + buf * STAGE + TBM * BK_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[s0 + s] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(sw + ((s0 + s) * NW + wave) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 ar[4][2], br[2][2];  // current A-half (4 row fragments x 2 k-steps), B-half (2 col fragments x 2 k-steps)
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nk = K / 64;
+
+  auto read_a = [&](int buf, int half) {
+    const char* sa = smem + buf * STAGE + (wr * 128 + half * 64) * BK_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) ar[i][kk] = *reinterpret_cast<const u32x4*>(sa + swz(i * 16 + fr, kk * 4 + fq));
+  };
+  auto read_b = [&](int buf, int half) {
+    const char* sw = smem + buf * STAGE + (TBM + wc * 64 + half * 32) * BK_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) br[i][kk] = *reinterpret_cast<const u32x4*>(sw + swz(i * 16 + fr, kk * 4 + fq));
+  };
+#define PP_MFMA(AH, BH)                                                                                              \
+  do {                                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)                   \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+      if constexpr (std::is_same<AB, f16>::value)                                                                    \
+        acc[(AH)*4 + i][(BH)*2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                        \
+            __builtin_bit_cast(f16x8, br[j][kk]), __builtin_bit_cast(f16x8, ar[i][kk]), acc[(AH)*4 + i][(BH)*2 + j], 0, 0, 0); \
+      else                                                                                                           \
+        acc[(AH)*4 + i][(BH)*2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                       \
+            __builtin_bit_cast(bf16x8_t, br[j][kk]), __builtin_bit_cast(bf16x8_t, ar[i][kk]), acc[(AH)*4 + i][(BH)*2 + j], 0, 0, 0); \
+    }                                                                                                                \
+    __builtin_amdgcn_s_setprio(0);                                                                                   \
+  } while (0)
+
+  // ---- prologue: tile 0 -> buffer 0 ---------------------------------------------------------------
+  dma_a(0, 0, 0); dma_a(0, 0, 2); dma_w(0, 0, 0); dma_w(0, 0, 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_BARRIER();
+  if (wr == 1) PP_BARRIER();  // stagger: group 1 starts one interval late
+
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1, nxt = cur ^ 1;
+    const bool pre = (t + 1 < nk);
+    // R1: B-half 0 then A-half 0
+    read_b(cur, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(cur, 0);
+    PP_BARRIER();
+    // M1 (+ DMA pieces of the next tile)
+    if (pre) dma_a(t + 1, nxt, 0);
+    PP_MFMA(0, 0);
+    PP_BARRIER();
+    // R2: B-half 1
+    read_b(cur, 1);
+    if (pre) dma_a(t + 1, nxt, 2);
+    PP_BARRIER();
+    // M2
+    if (pre) dma_w(t + 1, nxt, 0);
+    PP_MFMA(0, 1);
+    PP_BARRIER();
+    // R3: A-half 1
+    read_a(cur, 1);
+    if (pre) dma_w(t + 1, nxt, 2);
+    PP_BARRIER();
+    // M3
+    PP_MFMA(1, 1);
+    PP_BARRIER();
+    // R4: B-half 0 again
+    read_b(cur, 0);
+    if (wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: its program interval 6 = global 8t+7
+    PP_BARRIER();
+    // M4
+    PP_MFMA(1, 0);
+    if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 0: program interval 7 = global 8t+7
+    PP_BARRIER();
+  }
+  if (wr == 0) PP_BARRIER();  // equalise barrier counts; after it every wave is done with LDS
+#undef PP_MFMA
+
+  // ---- epilogue in row passes through LDS (same as the glds variants) --------------------------------
+  constexpr int TM = 128, TN = 64, MI = 8, NI = 4;
+  constexpr int OB = OutPack<OT>::bytes;
+  constexpr int C_STRIDE = TBN * OB + C_PAD;
+  constexpr int LDS_BYTES = 2 * STAGE;
+  constexpr int RP = (TBM * C_STRIDE <= LDS_BYTES) ? TBM : ((TBM / 2) * C_STRIDE <= LDS_BYTES ? TBM / 2 : TBM / 4);
+  static_assert(RP * C_STRIDE <= LDS_BYTES, "epilogue pass does not fit in LDS");
+  constexpr int NPASS = TBM / RP;
+  constexpr int CHUNKS = TBN * OB / 16;
+  constexpr int ROWS_PER_IT = NT / CHUNKS;
+  const float* bias_e = bias ? bias + (int64_t)e * N : nullptr;
+  f32x4 bv[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int nl = wc * TN + ni * 16 + fq * 4;
+    bv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias_e && n0 + nl < N) bv[ni] = *reinterpret_cast<const f32x4*>(bias_e + n0 + nl);
+  }
+  const int ch = tid % CHUNKS, r0 = tid / CHUNKS;
+  const int ncol = n0 + ch * (16 / OB);
+#pragma unroll
+  for (int p = 0; p < NPASS; ++p) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int row = wr * TM + mi * 16;  // wave-uniform
+      if (row / RP == p) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          f32x4 v = acc[mi][ni] + bv[ni];
+          if (epilogue == SMOE_EPI_GELU) {
+            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+          }
+          const int nl = wc * TN + ni * 16 + fq * 4;
+          OutPack<OT>::write4(smem + (row - p * RP + fr) * C_STRIDE + nl * OB, v);
+        }
+      }
+    }
+    __syncthreads();
+    if (ncol < N) {
+      for (int r = r0; r < RP; r += ROWS_PER_IT) {
+        const int m = m0 + p * RP + r;
+        if (m >= m_end) break;
+        u32x4 v = *reinterpret_cast<const u32x4*>(smem + r * C_STRIDE + ch * 16);
+        int64_t orow = m;
+        if (row_map) {
+          orow = row_map[m];
+          if (row_scale) v = scale16<OT>(v, row_scale[orow]);
+        }
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow * (int64_t)N + ncol) * OB) = v;
+      }
+    }
+    if (p + 1 < NPASS) __syncthreads();
+  }
+}
+
+template <typename AB, typename OT>
+int launch_pp256(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
+                 int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
+                 void* out, int group_m, hipStream_t s) {
+  constexpr int TBM = 256, TBN = 256;
+  const int n_tiles_n = (N + TBN - 1) / TBN;
+  const int max_m_tiles = (int)((m_rows_max + TBM - 1) / TBM) + E;
+  const int m_groups = (max_m_tiles + group_m - 1) / group_m;
+  const int grid = m_groups * group_m * n_tiles_n;
+  const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
+  auto kern = grouped_gemm_pp256<AB, OT>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ae != hipSuccess) {
+      smoe_set_error("smoe_grouped_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
+      return (int)ae;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert, E, K, N,
+                     epilogue, row_map, row_scale, (OT*)out, n_tiles_n, group_m);
+  SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
+  return 0;
+}
+
 template <typename AB, typename OT>
 int launch_variant(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets,
                    const int32_t* group_expert, int E, int64_t m_rows_max, int K, int N, int epilogue,
@@ -494,6 +743,7 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
       case 1: return launch_glds<AB, OT, 128, 128, 2, 2, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 8, s);
       case 2: return launch_glds<AB, OT, 256, 128, 2, 2, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
       case 3: return launch_glds<AB, OT, 256, 256, 2, 4, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+      case 4: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
       default: break;
     }
   }
