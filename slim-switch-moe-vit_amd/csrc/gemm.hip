@@ -495,11 +495,10 @@ int launch_glds(const void* A, const void* W, const float* bias, const int32_t* 
 // re-reading only the operand half that changes: (A0,B0) (A0,B1) (A1,B1) (A1,B0).
 //
 // Interval clock (group-0 time, 8 intervals per K-tile t):  R1 M1 R2 M2 R3 M3 R4 M4; group 1 is +1.
-//   WAR: tile t+1 is staged into the buffer tile t-1 used; its last reads (group 1's R4(t-1)) are
-//        retired by that group's lgkmcnt(0) at the start of global interval 8t, so DMA issue starts in
-//        each wave's program interval 1 of tile t (global >= 8t+1).
-//   RAW: every wave drains its own DMAs (vmcnt(0)) before the barrier that closes global interval 8t+7
-//        (program interval 7 for group 0, 6 for group 1); first reads of tile t+1 come after that barrier.
+//   LDS regions of a buffer are re-staged one by one as soon as their last reader has retired its reads
+//   (A rows 0-127 belong to group 0, rows 128-255 to group 1, W rows are shared); see the schedule comment
+//   in the K loop.  Every wave drains its own DMAs with a COUNTED vmcnt before the barrier that closes
+//   global interval 8t+7 (program interval 7 for group 0, 6 for group 1).
 #define PP_BARRIER()                         \
   do {                                       \
     __builtin_amdgcn_sched_barrier(0);       \
@@ -509,7 +508,9 @@ int launch_glds(const void* A, const void* W, const float* bias, const int32_t* 
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
 
-template <typename AB, typename OT>
+// ABL: timing-only ablation bits (diagnostic variants 40-47; results are wrong by construction):
+//   1 = no DMA inside the K loop, 2 = no fragment ds_reads inside the K loop, 4 = no MFMA
+template <typename AB, typename OT, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   }
   // DMA of pieces [s0, s0+2) of A or W of K-tile kt into buffer buf
   auto dma_a = [&](int kt, int buf, int s0) {
+    if ((ABL & 1) && kt >= 2) return;
     char* sa = smem + buf * STAGE;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
                                        (__attribute__((address_space(3))) void*)(sa + ((s0 + s) * NW + wave) * 1024), 16, 0, 0);
   };
   auto dma_w = [&](int kt, int buf, int s0) {
+    if ((ABL & 1) && kt >= 2) return;
     char* sw = smem + buf * STAGE + TBM * BK_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -579,7 +582,18 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   const int fr = lane & 15, fq = lane >> 4;
   const int nk = K / 64;
 
+  if (ABL & 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) ar[i][kk] = u32x4{0x3c003800u + lane, 0xbc003400u, 0x38003c00u, 0x3400b800u + i};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) br[i][kk] = u32x4{0x2c002800u + lane, 0xac002400u, 0x28002c00u, 0x2400a800u + i};
+  }
   auto read_a = [&](int buf, int half) {
+    if (ABL & 2) { asm volatile("" : "+v"(ar[0][0]), "+v"(ar[1][1])); return; }
     const char* sa = smem + buf * STAGE + (wr * 128 + half * 64) * BK_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -587,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
       for (int kk = 0; kk < 2; ++kk) ar[i][kk] = *reinterpret_cast<const u32x4*>(sa + swz(i * 16 + fr, kk * 4 + fq));
   };
   auto read_b = [&](int buf, int half) {
+    if (ABL & 2) { asm volatile("" : "+v"(br[0][0]), "+v"(br[1][1])); return; }
     const char* sw = smem + buf * STAGE + (TBM + wc * 64 + half * 32) * BK_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -595,6 +610,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   };
 #define PP_MFMA(AH, BH)                                                                                              \
   do {                                                                                                               \
+    if (ABL & 4) { asm volatile("" :: "v"(ar[0][0]), "v"(ar[3][1]), "v"(br[0][0]), "v"(br[1][1])); break; }          \
     __builtin_amdgcn_s_setprio(1);                                                                                   \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)                   \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
@@ -608,46 +624,61 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     __builtin_amdgcn_s_setprio(0);                                                                                   \
   } while (0)
 
-  // ---- prologue: tile 0 -> buffer 0 ---------------------------------------------------------------
+  // ---- prologue: tiles 0 and 1 -> buffers 0 and 1 ------------------------------------------------------
   dma_a(0, 0, 0); dma_a(0, 0, 2); dma_w(0, 0, 0); dma_w(0, 0, 2);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nk > 1) {
+    dma_a(1, 1, 0); dma_a(1, 1, 2); dma_w(1, 1, 0); dma_w(1, 1, 2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   PP_BARRIER();
   if (wr == 1) PP_BARRIER();  // stagger: group 1 starts one interval late
 
+  // DMA schedule (all issues sit in READ intervals, behind the ds_reads; MFMA intervals stay pure):
+  //   R1(t): A rows 128-255 of tile t+1   R2(t): W rows 0-127 of t+1   R3(t): W rows 128-255 of t+1
+  //   R4(t): A rows 0-127 of tile t+2 (that region of tile t's buffer was last read in R3(t))
+  // Region reuse is safe because each region's last ds_read of the previous occupant is retired (lgkmcnt(0)
+  // at the head of the reader's next MFMA interval) at least one barrier before the issue; the data is
+  // needed >= 3 intervals later, and every wave drains all but its 2 newest DMAs before the barrier that
+  // closes tile t (counted vmcnt: the newest two belong to tile t+2).
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
-    const bool pre = (t + 1 < nk);
+    const bool pre1 = (t >= 1) && (t + 1 < nk);
+    const bool pre2 = (t + 2 < nk);
     // R1: B-half 0 then A-half 0
     read_b(cur, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_a(cur, 0);
+    if (pre1) dma_a(t + 1, nxt, 2);
     PP_BARRIER();
-    // M1 (+ DMA pieces of the next tile)
-    if (pre) dma_a(t + 1, nxt, 0);
     PP_MFMA(0, 0);
     PP_BARRIER();
     // R2: B-half 1
     read_b(cur, 1);
-    if (pre) dma_a(t + 1, nxt, 2);
+    if (pre1) dma_w(t + 1, nxt, 0);
     PP_BARRIER();
-    // M2
-    if (pre) dma_w(t + 1, nxt, 0);
     PP_MFMA(0, 1);
     PP_BARRIER();
     // R3: A-half 1
     read_a(cur, 1);
-    if (pre) dma_w(t + 1, nxt, 2);
+    if (pre1) dma_w(t + 1, nxt, 2);
     PP_BARRIER();
-    // M3
     PP_MFMA(1, 1);
     PP_BARRIER();
     // R4: B-half 0 again
     read_b(cur, 0);
-    if (wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 1: its program interval 6 = global 8t+7
+    if (pre2) dma_a(t + 2, cur, 0);
+    if (wr == 1) {  // group 1: its program interval 6 is global interval 8t+7, the last one of tile t
+      if (pre2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     PP_BARRIER();
-    // M4
     PP_MFMA(1, 0);
-    if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // group 0: program interval 7 = global 8t+7
+    if (wr == 0) {  // group 0: program interval 7 = global 8t+7
+      if (pre2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     PP_BARRIER();
   }
   if (wr == 0) PP_BARRIER();  // equalise barrier counts; after it every wave is done with LDS
@@ -708,7 +739,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   }
 }
 
-template <typename AB, typename OT>
+template <typename AB, typename OT, int ABL = 0>
 int launch_pp256(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                  int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
                  void* out, int group_m, hipStream_t s) {
@@ -718,7 +749,7 @@ int launch_pp256(const void* A, const void* W, const float* bias, const int32_t*
   const int m_groups = (max_m_tiles + group_m - 1) / group_m;
   const int grid = m_groups * group_m * n_tiles_n;
   const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
-  auto kern = grouped_gemm_pp256<AB, OT>;
+  auto kern = grouped_gemm_pp256<AB, OT, ABL>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -744,6 +775,14 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
       case 2: return launch_glds<AB, OT, 256, 128, 2, 2, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
       case 3: return launch_glds<AB, OT, 256, 256, 2, 4, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
       case 4: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+#ifdef SMOE_DIAG
+      case 41: return launch_pp256<AB, OT, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+      case 42: return launch_pp256<AB, OT, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+      case 43: return launch_pp256<AB, OT, 3>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+      case 44: return launch_pp256<AB, OT, 4>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+      case 46: return launch_pp256<AB, OT, 6>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+      case 47: return launch_pp256<AB, OT, 7>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+#endif
       default: break;
     }
   }

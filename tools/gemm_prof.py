@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Single-variant grouped-GEMM driver for rocprofv3 runs and calibration.
+usage: gemm_prof.py <variant> <shape: fc1|fc2|fc2h|sq8k|sq4k> [iters]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from slim_switch_moe_vit_amd import ops  # noqa: E402
+
+
+def main():
+    variant = int(sys.argv[1])
+    shape = sys.argv[2]
+    iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    if shape.startswith("sq"):
+        n = 8192 if shape == "sq8k" else 4096
+        E, M, K, N = 1, n, n, n
+        counts = [M]
+    else:
+        E, M = 8, 256 * 197
+        K, N = (768, 3072) if shape == "fc1" else (3072, 768)
+        base = M // E
+        counts = [base] * E
+        counts[-1] += M - base * E
+    offsets = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=dev)
+    A = torch.randn(M, K, device=dev).half()
+    W = (torch.randn(E, N, K, device=dev) * 0.02).half()
+    b = torch.randn(E, N, device=dev) * 0.02
+    epi = ops.EPI_GELU if shape == "fc1" else ops.EPI_NONE
+    odt = torch.float32 if shape == "fc2" else torch.float16
+    out = torch.empty(M, N, device=dev, dtype=odt)
+    for _ in range(3):
+        ops.grouped_gemm(A, W, b, offsets, epi, out=out, variant=variant)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        ops.grouped_gemm(A, W, b, offsets, epi, out=out, variant=variant)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    print(f"variant {variant} shape {shape} M={M} K={K} N={N}: {ms:.4f} ms  {2.0*M*K*N/ms/1e9:.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
