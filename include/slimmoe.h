@@ -45,10 +45,13 @@ const char* smoe_last_error(void);
  *           probs (may be NULL) receives p [T,E] for the aux loss.
  * x [T,d] (x_dtype), wg [E,d] f32, bg [E] f32 or NULL, noise [T,E] f32 or NULL.
  * idx [T,k] i64, score [T,k] f32, logits_out [T,E] f32 or NULL.
- * Requires d % 8 == 0, d <= 2048, 1 <= k <= E, k <= 8.                                         */
+ * Requires d % 8 == 0, d <= 2048, 1 <= k <= E, k <= 4.  workspace: smoe_router_workspace_bytes(T) bytes
+ * (redo counter + list of tokens handed to the f64 pass).                                          */
+size_t smoe_router_workspace_bytes(int64_t T);
 int smoe_router_topk(const void* x, int x_dtype, const float* wg, const float* bg, const float* noise,
                      int64_t T, int d, int E, int k, int gate_kind,
-                     int64_t* idx, float* score, float* logits_out, float* probs, void* stream);
+                     int64_t* idx, float* score, float* logits_out, float* probs,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- dispatch plan --------------------------------------------------------------------------------
  * Replaces fmoe_cuda.expert_count + cumsum + assign_pos (+ limit_by_capacity /

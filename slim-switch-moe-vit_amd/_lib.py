@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: the library resolves libamd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -19,8 +19,9 @@ c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int
 SIGNATURES = {
     "smoe_abi_version": (c_int, []),
     "smoe_last_error": (ctypes.c_char_p, []),
+    "smoe_router_workspace_bytes": (c_size_t, [c_int64]),
     "smoe_router_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
-                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_dispatch_plan_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "smoe_dispatch_plan": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -17,9 +17,9 @@
 
 namespace {
 
-constexpr int ROUTER_THREADS = 512;
+constexpr int ROUTER_THREADS = 256;
 constexpr int ROUTER_WAVES = ROUTER_THREADS / 64;
-constexpr int ROUTER_MAX_K = 8;
+constexpr int ROUTER_MAX_K = 4;
 constexpr int NONE_IDX = 0x7fffffff;
 
 template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int m) { return __shfl_xor(v, m, 64); }
@@ -58,10 +58,14 @@ template <typename T> __device__ __forceinline__ T butterfly8(const T (&acc)[8],
   return a1;
 }
 
-template <typename XT, int NCH, bool W_LDS>
-__global__ __launch_bounds__(ROUTER_THREADS) void router_kernel(
+// MODE 0: f32 pass over all tokens; a token whose deciding gaps are inside the error bound is appended to
+//         redo_list (its provisional outputs are overwritten later).  No f64 code -> low VGPR, high occupancy.
+// MODE 1: f64 pass over redo_list[0 .. *redo_count)  (or over all tokens when redo_list == nullptr).
+template <typename XT, int NCH, bool W_LDS, int MODE>
+__global__ __launch_bounds__(ROUTER_THREADS, (MODE == 0 ? 4 : 2)) void router_kernel(
     const XT* __restrict__ x, const float* __restrict__ wg, const float* __restrict__ bg,
-    const float* __restrict__ noise, int64_t T, int d, int E, int k, int gate_kind, int force_f64,
+    const float* __restrict__ noise, int64_t T, int d, int E, int k, int gate_kind,
+    int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_list,
     int64_t* __restrict__ idx_out, float* __restrict__ score_out, float* __restrict__ logits_out,
     float* __restrict__ probs_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,16 +131,14 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_kernel(
     }
   };
 
-  int64_t t = wave_gid;
-  if (t < T) load_row(t);
-  for (; t < T; t += wave_stride) {
-    float xc[NCH][4];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xc[c][j] = xn[c][j];
-    const int64_t tn = t + wave_stride;
-    if (tn < T) load_row(tn);  // prefetch the next row under this row's arithmetic
+  // work items: MODE 0 -> tokens 0..T-1; MODE 1 with a list -> list entries 0..count-1
+  int64_t n_items = T;
+  if (MODE == 1 && redo_list) n_items = *redo_count;
+  auto item_token = [&](int64_t it) -> int64_t { return (MODE == 1 && redo_list) ? (int64_t)redo_list[it] : it; };
+  for (int64_t it = wave_gid; it < n_items; it += wave_stride) {
+    const int64_t t = item_token(it);
+    load_row(t);  // latency is hidden by occupancy (4 blocks of 4 waves per CU), not by software prefetch
+    float (&xc)[NCH][4] = xn;
 
     auto publish = [&](int eb, float lg_wave, bool f64_path, double lg64) {
       const int el = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_kernel(
               load_w(eb + i, col, wf);
 #pragma unroll
               for (int j = 0; j < 4; ++j) acc[i] = fmaf(xc[c][j], wf[j], acc[i]);
+              if (i & 1) __builtin_amdgcn_sched_barrier(0);  // keep at most two weight loads in flight (VGPR budget)
             }
           }
         }
@@ -224,8 +227,7 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_kernel(
     };
 
     const int kc = (k < E) ? k + 1 : k;  // the (k+1)-th value guards the boundary of the kept set
-    bool need_f64 = force_f64 != 0;
-    if (!need_f64) {
+    if constexpr (MODE == 0) {
       float xs = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
@@ -243,12 +245,12 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_kernel(
       for (int r = 0; r <= ROUTER_MAX_K; ++r)
         if (r < kc) amax = fmaxf(amax, fabsf(chosen_val[r]));
       const float bound = 4.0f * (float)(NCH * 4 + 8) * 5.9604645e-8f * sqrtf(xs * wmax2) + 9.6e-7f * (amax + 1.0f);
+      bool ambiguous = false;
 #pragma unroll
       for (int r = 0; r < ROUTER_MAX_K; ++r)
-        if (r + 1 < kc) need_f64 |= !((chosen_val[r] - chosen_val[r + 1]) > bound);
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (need_f64) {  // wave-uniform
+        if (r + 1 < kc) ambiguous |= !((chosen_val[r] - chosen_val[r + 1]) > bound);
+      if (ambiguous && lane == 0) redo_list[atomicAdd(redo_count, 1)] = (int32_t)t;  // wave-uniform condition
+    } else {
       logits_f64();
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
@@ -294,40 +296,54 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_kernel(
 
 template <typename XT, int NCH>
 int launch_router(const void* x, const float* wg, const float* bg, const float* noise, int64_t T, int d, int E,
-                  int k, int gate_kind, int force_f64, int64_t* idx, float* score, float* logits_out, float* probs,
-                  hipStream_t stream) {
+                  int k, int gate_kind, int force_f64, int32_t* redo_count, int32_t* redo_list, int64_t* idx,
+                  float* score, float* logits_out, float* probs, hipStream_t stream) {
   const int Epad = (E + 7) & ~7;
   const size_t logit_bytes = ((size_t)(ROUTER_WAVES + 1) * Epad * 4 + 15) & ~(size_t)15;
   const size_t w_bytes = (size_t)Epad * d * 4;
   const bool w_lds = (logit_bytes + w_bytes) <= 64 * 1024;
   const size_t smem = logit_bytes + (w_lds ? w_bytes : 0);
   int64_t need = (T + ROUTER_WAVES - 1) / ROUTER_WAVES;
-  int grid = (int)(need < 512 ? (need < 1 ? 1 : need) : 512);
-  if (w_lds) {
-    hipLaunchKernelGGL((router_kernel<XT, NCH, true>), dim3(grid), dim3(ROUTER_THREADS), smem, stream, (const XT*)x,
-                       wg, bg, noise, T, d, E, k, gate_kind, force_f64, idx, score, logits_out, probs);
-  } else {
-    hipLaunchKernelGGL((router_kernel<XT, NCH, false>), dim3(grid), dim3(ROUTER_THREADS), smem, stream, (const XT*)x,
-                       wg, bg, noise, T, d, E, k, gate_kind, force_f64, idx, score, logits_out, probs);
+  const int grid = (int)(need < 2048 ? (need < 1 ? 1 : need) : 2048);
+#define ROUTER_LAUNCH(WL, MODE, GRID, RC, RL)                                                                      \
+  hipLaunchKernelGGL((router_kernel<XT, NCH, WL, MODE>), dim3(GRID), dim3(ROUTER_THREADS), smem, stream,          \
+                     (const XT*)x, wg, bg, noise, T, d, E, k, gate_kind, RC, RL, idx, score, logits_out, probs)
+  if (force_f64) {
+    if (w_lds) ROUTER_LAUNCH(true, 1, grid, nullptr, nullptr);
+    else ROUTER_LAUNCH(false, 1, grid, nullptr, nullptr);
+    SMOE_CHECK_LAUNCH("smoe_router_topk/f64");
+    return 0;
   }
-  SMOE_CHECK_LAUNCH("smoe_router_topk");
+  hipError_t me = hipMemsetAsync(redo_count, 0, 16, stream);
+  if (me != hipSuccess) {
+    smoe_set_error("smoe_router_topk: memset failed: %s", hipGetErrorString(me));
+    return (int)me;
+  }
+  if (w_lds) ROUTER_LAUNCH(true, 0, grid, redo_count, redo_list);
+  else ROUTER_LAUNCH(false, 0, grid, redo_count, redo_list);
+  SMOE_CHECK_LAUNCH("smoe_router_topk/f32");
+  const int redo_grid = grid < 32 ? grid : 32;  // the redo list is short (~1e-4 T); surplus waves exit at once
+  if (w_lds) ROUTER_LAUNCH(true, 1, redo_grid, redo_count, redo_list);
+  else ROUTER_LAUNCH(false, 1, redo_grid, redo_count, redo_list);
+  SMOE_CHECK_LAUNCH("smoe_router_topk/redo");
+#undef ROUTER_LAUNCH
   return 0;
 }
 
 template <typename XT>
 int dispatch_nch(const void* x, const float* wg, const float* bg, const float* noise, int64_t T, int d, int E,
-                 int k, int gate_kind, int f64, int64_t* idx, float* score, float* logits_out, float* probs,
-                 hipStream_t s) {
+                 int k, int gate_kind, int f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score,
+                 float* logits_out, float* probs, hipStream_t s) {
   const int nch = (d + 255) / 256;
   switch (nch) {
-    case 1: return launch_router<XT, 1>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
-    case 2: return launch_router<XT, 2>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
-    case 3: return launch_router<XT, 3>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
-    case 4: return launch_router<XT, 4>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
-    case 5: return launch_router<XT, 5>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
-    case 6: return launch_router<XT, 6>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
-    case 7: return launch_router<XT, 7>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
-    case 8: return launch_router<XT, 8>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, idx, score, logits_out, probs, s);
+    case 1: return launch_router<XT, 1>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, logits_out, probs, s);
+    case 2: return launch_router<XT, 2>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, logits_out, probs, s);
+    case 3: return launch_router<XT, 3>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, logits_out, probs, s);
+    case 4: return launch_router<XT, 4>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, logits_out, probs, s);
+    case 5: return launch_router<XT, 5>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, logits_out, probs, s);
+    case 6: return launch_router<XT, 6>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, logits_out, probs, s);
+    case 7: return launch_router<XT, 7>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, logits_out, probs, s);
+    case 8: return launch_router<XT, 8>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, logits_out, probs, s);
   }
   smoe_set_error("smoe_router_topk: d=%d unsupported (d <= 2048)", d);
   return 1;
@@ -335,14 +351,18 @@ int dispatch_nch(const void* x, const float* wg, const float* bg, const float* n
 
 }  // namespace
 
-// gate_kind bit 8 (0x100) forces the all-f64 path (test hook: every token through the fallback)
+// workspace: [16 B: redo counter][T x i32 redo list]
+extern "C" size_t smoe_router_workspace_bytes(int64_t T) { return T < 0 ? 0 : 16 + (((size_t)T * 4 + 15) & ~(size_t)15); }
+
+// gate_kind bit 8 (0x100) forces the all-f64 path (test hook: every token through the f64 kernel)
 extern "C" int smoe_router_topk(const void* x, int x_dtype, const float* wg, const float* bg, const float* noise,
                                 int64_t T, int d, int E, int k, int gate_kind, int64_t* idx, float* score,
-                                float* logits_out, float* probs, void* stream) {
+                                float* logits_out, float* probs, void* workspace, size_t workspace_bytes,
+                                void* stream) {
   const int force_f64 = (gate_kind & 0x100) ? 1 : 0;
   gate_kind &= 0xff;
   SMOE_REQUIRE(x && wg && idx && score, "smoe_router_topk: null pointer");
-  SMOE_REQUIRE(T >= 0 && d > 0 && E > 0, "smoe_router_topk: bad sizes T=%lld d=%d E=%d", (long long)T, d, E);
+  SMOE_REQUIRE(T >= 0 && T < (1ll << 31) && d > 0 && E > 0, "smoe_router_topk: bad sizes T=%lld d=%d E=%d", (long long)T, d, E);
   SMOE_REQUIRE(d % 8 == 0 && d <= 2048, "smoe_router_topk: d=%d must be a multiple of 8 and <= 2048", d);
   SMOE_REQUIRE(k >= 1 && k <= E && k <= ROUTER_MAX_K, "smoe_router_topk: k=%d out of range (E=%d, max %d)", k, E,
                ROUTER_MAX_K);
@@ -350,12 +370,15 @@ extern "C" int smoe_router_topk(const void* x, int x_dtype, const float* wg, con
   SMOE_REQUIRE(gate_kind == SMOE_GATE_NAIVE || gate_kind == SMOE_GATE_SWITCH, "smoe_router_topk: bad gate_kind %d",
                gate_kind);
   SMOE_REQUIRE(gate_kind != SMOE_GATE_SWITCH || k == 1, "smoe_router_topk: switch gate needs k == 1");
+  SMOE_REQUIRE(workspace && workspace_bytes >= smoe_router_workspace_bytes(T), "smoe_router_topk: workspace too small");
   if (T == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  int32_t* rc = reinterpret_cast<int32_t*>(workspace);
+  int32_t* rl = reinterpret_cast<int32_t*>((char*)workspace + 16);
   switch (x_dtype) {
-    case SMOE_F32: return dispatch_nch<float>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, idx, score, logits_out, probs, s);
-    case SMOE_F16: return dispatch_nch<f16>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, idx, score, logits_out, probs, s);
-    case SMOE_BF16: return dispatch_nch<bf16_bits>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, idx, score, logits_out, probs, s);
+    case SMOE_F32: return dispatch_nch<float>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
+    case SMOE_F16: return dispatch_nch<f16>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
+    case SMOE_BF16: return dispatch_nch<bf16_bits>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
   }
   smoe_set_error("smoe_router_topk: bad x_dtype %d", x_dtype);
   return 1;

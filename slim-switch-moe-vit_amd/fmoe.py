@@ -163,7 +163,7 @@ class FMoETransformerMLP(nn.Module):
     def __init__(self, num_expert: int = 32, d_model: int = 1024, d_hidden: int = 4096, activation=None,
                  expert_dp_comm: str = "none", expert_rank: int = 0, *, top_k: int = 2, world_size: int = 1,
                  moe_group=None, gate="naive", capacity_factor=None, capacity_mode: str = "switch",
-                 compute_dtype: Optional[torch.dtype] = None, gemm_variant: int = 0):
+                 compute_dtype: Optional[torch.dtype] = None, gemm_variant: int = 4):
         super().__init__()
         if activation is None:
             activation = nn.GELU()

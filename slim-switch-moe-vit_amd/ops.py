@@ -106,10 +106,12 @@ def router_topk(x: torch.Tensor, wg: torch.Tensor, bg: Optional[torch.Tensor], k
     logits = torch.empty((T, E), dtype=torch.float32, device=x.device) if want_logits else None
     probs = torch.empty((T, E), dtype=torch.float32, device=x.device) if want_probs else None
     lib = _lib.load()
+    ws_bytes = lib.smoe_router_workspace_bytes(T)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     with _timed("router", {"bytes": T * d * x.element_size()}, x):
         rc = lib.smoe_router_topk(_ptr(x), dtype_code(x.dtype), _ptr(wg), _ptr(bg), _ptr(noise), T, d, E, k,
                                   gate_kind | (0x100 if force_f64 else 0), _ptr(idx), _ptr(score), _ptr(logits),
-                                  _ptr(probs), _stream(x))
+                                  _ptr(probs), _ptr(ws), ws_bytes, _stream(x))
     _lib.check(rc, "smoe_router_topk")
     return idx, score, logits, probs
 

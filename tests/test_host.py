@@ -23,7 +23,7 @@ def _declared_symbols():
 
 def test_library_exports_every_declared_symbol():
     syms = _declared_symbols()
-    assert len(syms) >= 9
+    assert len(syms) >= 10
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for s in syms:
         assert hasattr(lib, s), f"libslimmoe_hip.so does not export {s}"
@@ -39,7 +39,7 @@ def test_library_loads_and_reports_abi():
 def test_argument_validation_errors_come_back_as_messages():
     lib = _lib.load()
     # null pointers / bad sizes are rejected before any launch (safe without a GPU)
-    rc = lib.smoe_router_topk(None, 0, None, None, None, 4, 12, 2, 1, 0, None, None, None, None, None)
+    rc = lib.smoe_router_topk(None, 0, None, None, None, 4, 12, 2, 1, 0, None, None, None, None, None, 0, None)
     assert rc != 0 and b"null" in lib.smoe_last_error()
     rc = lib.smoe_grouped_gemm(None, None, None, None, None, 0, 0, 8, 64, 64, 1, 0, None, None, None, 1, 0, None)
     assert rc != 0 and lib.smoe_last_error()
