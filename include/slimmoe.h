@@ -92,6 +92,8 @@ int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, cons
  * bias f32 [E,N] or NULL.  epilogue SMOE_EPI_GELU = exact-erf GELU (models/resMoE.py:23-25).
  * Optional fused combine for top-1 (row_map != NULL): row r is stored to out[row_map[r], :]
  * multiplied by row_scale[row_map[r]] if row_scale != NULL  (MOEGather + bmm for k = 1).
+ * Optional fused residual (residual != NULL, same dtype / shape as out): the stored value is
+ * residual[orow, :] + value -- the `x + mlp(norm2(x))` add of models/vision_transformer.py:321.
  * Optional group -> expert map (group_expert != NULL, i32 [G]): `offsets` then delimits G row groups and
  * group g uses W[group_expert[g]] / bias[group_expert[g]] (expert-parallel receive layout: one group per
  * (source rank, local expert)); n_experts = leading dimension of W / bias.
@@ -99,7 +101,7 @@ int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, cons
 int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int32_t* offsets,
                       const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
                       int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,
-                      void* out, int out_dtype, int variant, void* stream);
+                      const void* residual, void* out, int out_dtype, int variant, void* stream);
 
 /* ---- small helpers ------------------------------------------------------------------------------------
  * elementwise cast between dtypes (weight shadow copies; not on the per-step path)                  */

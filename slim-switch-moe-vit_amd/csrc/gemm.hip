@@ -80,6 +80,25 @@ template <> __device__ __forceinline__ u32x4 scale16<bf16_bits>(u32x4 raw, float
   return __builtin_bit_cast(u32x4, v);
 }
 
+// elementwise add of 16 bytes of output elements (fused residual)
+template <typename OT> __device__ __forceinline__ u32x4 add16(u32x4 a, u32x4 b);
+template <> __device__ __forceinline__ u32x4 add16<float>(u32x4 a, u32x4 b) {
+  return __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, a) + __builtin_bit_cast(f32x4, b));
+}
+template <> __device__ __forceinline__ u32x4 add16<f16>(u32x4 a, u32x4 b) {
+  f16x8 x = __builtin_bit_cast(f16x8, a), y = __builtin_bit_cast(f16x8, b);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = (f16)((float)x[i] + (float)y[i]);
+  return __builtin_bit_cast(u32x4, x);
+}
+template <> __device__ __forceinline__ u32x4 add16<bf16_bits>(u32x4 a, u32x4 b) {
+  s16x8 x = __builtin_bit_cast(s16x8, a), y = __builtin_bit_cast(s16x8, b);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    x[i] = (short)f32_to_bf16(bf16_to_f32((unsigned short)x[i]) + bf16_to_f32((unsigned short)y[i]));
+  return __builtin_bit_cast(u32x4, x);
+}
+
 // locate the (expert, row range) of global m-tile `mt`; returns false if there is no such tile
 __device__ __forceinline__ bool find_tile(const int32_t* __restrict__ offsets, int E, int mt, int& e_out, int& m0,
                                           int& m_end, int bm = BM) {
@@ -102,7 +121,7 @@ template <typename AB, typename OT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void grouped_gemm_t128(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
-    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, OT* __restrict__ out, int n_tiles_n,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* __restrict__ residual, OT* __restrict__ out, int n_tiles_n,
     int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(AB);
@@ -256,7 +275,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void grouped_gemm_t128(
           orow = row_map[m];
           if (row_scale) v = scale16<OT>(v, row_scale[orow]);
         }
-        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow * (int64_t)N + ncol) * OB) = v;
+        const int64_t ooff = (orow * (int64_t)N + ncol) * OB;
+        if (residual) v = add16<OT>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + ooff), v);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + ooff) = v;
       }
     }
   }
@@ -265,7 +286,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void grouped_gemm_t128(
 template <typename AB, typename OT>
 int launch_t128(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                 int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
-                void* out, hipStream_t s) {
+                const void* residual, void* out, hipStream_t s) {
   const int n_tiles_n = (N + BN - 1) / BN;
   const int max_m_tiles = (int)((m_rows_max + BM - 1) / BM) + E;
   const int group_m = 8;
@@ -286,7 +307,7 @@ int launch_t128(const void* A, const void* W, const float* bias, const int32_t* 
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert,
-                     E, K, N, epilogue, row_map, row_scale, (OT*)out, n_tiles_n, group_m);
+                     E, K, N, epilogue, row_map, row_scale, (const OT*)residual, (OT*)out, n_tiles_n, group_m);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
   return 0;
 }
@@ -301,7 +322,7 @@ template <typename AB, typename OT, int TBM, int TBN, int WM, int WN, int MINW>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void grouped_gemm_glds(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
-    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, OT* __restrict__ out, int n_tiles_n,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* __restrict__ residual, OT* __restrict__ out, int n_tiles_n,
     int group_m) {
   static_assert(sizeof(AB) == 2, "glds variants take 16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -453,7 +474,9 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void grouped_gemm_glds(
           orow = row_map[m];
           if (row_scale) v = scale16<OT>(v, row_scale[orow]);
         }
-        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow * (int64_t)N + ncol) * OB) = v;
+        const int64_t ooff = (orow * (int64_t)N + ncol) * OB;
+        if (residual) v = add16<OT>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + ooff), v);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + ooff) = v;
       }
     }
     if (p + 1 < NPASS) __syncthreads();
@@ -463,7 +486,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void grouped_gemm_glds(
 template <typename AB, typename OT, int TBM, int TBN, int WM, int WN, int MINW>
 int launch_glds(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                 int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
-                void* out, int group_m, hipStream_t s) {
+                const void* residual, void* out, int group_m, hipStream_t s) {
   const int n_tiles_n = (N + TBN - 1) / TBN;
   const int max_m_tiles = (int)((m_rows_max + TBM - 1) / TBM) + E;
   const int m_groups = (max_m_tiles + group_m - 1) / group_m;
@@ -480,7 +503,7 @@ int launch_glds(const void* A, const void* W, const float* bias, const int32_t* 
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert,
-                     E, K, N, epilogue, row_map, row_scale, (OT*)out, n_tiles_n, group_m);
+                     E, K, N, epilogue, row_map, row_scale, (const OT*)residual, (OT*)out, n_tiles_n, group_m);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
   return 0;
 }
@@ -514,7 +537,7 @@ template <typename AB, typename OT, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
-    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, OT* __restrict__ out, int n_tiles_n,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* __restrict__ residual, OT* __restrict__ out, int n_tiles_n,
     int group_m) {
   static_assert(sizeof(AB) == 2, "16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -732,7 +755,9 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
           orow = row_map[m];
           if (row_scale) v = scale16<OT>(v, row_scale[orow]);
         }
-        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow * (int64_t)N + ncol) * OB) = v;
+        const int64_t ooff = (orow * (int64_t)N + ncol) * OB;
+        if (residual) v = add16<OT>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + ooff), v);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + ooff) = v;
       }
     }
     if (p + 1 < NPASS) __syncthreads();
@@ -742,7 +767,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
 template <typename AB, typename OT, int ABL = 0>
 int launch_pp256(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                  int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
-                 void* out, int group_m, hipStream_t s) {
+                 const void* residual, void* out, int group_m, hipStream_t s) {
   constexpr int TBM = 256, TBN = 256;
   const int n_tiles_n = (N + TBN - 1) / TBN;
   const int max_m_tiles = (int)((m_rows_max + TBM - 1) / TBM) + E;
@@ -760,7 +785,7 @@ int launch_pp256(const void* A, const void* W, const float* bias, const int32_t*
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert, E, K, N,
-                     epilogue, row_map, row_scale, (OT*)out, n_tiles_n, group_m);
+                     epilogue, row_map, row_scale, (const OT*)residual, (OT*)out, n_tiles_n, group_m);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
   return 0;
 }
@@ -768,35 +793,35 @@ int launch_pp256(const void* A, const void* W, const float* bias, const int32_t*
 template <typename AB, typename OT>
 int launch_variant(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets,
                    const int32_t* group_expert, int E, int64_t m_rows_max, int K, int N, int epilogue,
-                   const int64_t* row_map, const float* row_scale, void* out, hipStream_t s) {
+                   const int64_t* row_map, const float* row_scale, const void* residual, void* out, hipStream_t s) {
   if constexpr (sizeof(AB) == 2) {
     switch (variant) {
-      case 1: return launch_glds<AB, OT, 128, 128, 2, 2, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 8, s);
-      case 2: return launch_glds<AB, OT, 256, 128, 2, 2, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
-      case 3: return launch_glds<AB, OT, 256, 256, 2, 4, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
-      case 4: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+      case 1: return launch_glds<AB, OT, 128, 128, 2, 2, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 8, s);
+      case 2: return launch_glds<AB, OT, 256, 128, 2, 2, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
+      case 3: return launch_glds<AB, OT, 256, 256, 2, 4, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
+      case 4: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
 #ifdef SMOE_DIAG
-      case 41: return launch_pp256<AB, OT, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
-      case 42: return launch_pp256<AB, OT, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
-      case 43: return launch_pp256<AB, OT, 3>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
-      case 44: return launch_pp256<AB, OT, 4>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
-      case 46: return launch_pp256<AB, OT, 6>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
-      case 47: return launch_pp256<AB, OT, 7>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, 4, s);
+      case 41: return launch_pp256<AB, OT, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
+      case 42: return launch_pp256<AB, OT, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
+      case 43: return launch_pp256<AB, OT, 3>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
+      case 44: return launch_pp256<AB, OT, 4>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
+      case 46: return launch_pp256<AB, OT, 6>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
+      case 47: return launch_pp256<AB, OT, 7>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
 #endif
       default: break;
     }
   }
-  return launch_t128<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
+  return launch_t128<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s);
 }
 
 template <typename AB>
 int dispatch_out(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                  int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
-                 void* out, int out_dtype, hipStream_t s) {
+                 const void* residual, void* out, int out_dtype, hipStream_t s) {
   switch (out_dtype) {
-    case SMOE_F32: return launch_variant<AB, float>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
-    case SMOE_F16: return launch_variant<AB, f16>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
-    case SMOE_BF16: return launch_variant<AB, bf16_bits>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, out, s);
+    case SMOE_F32: return launch_variant<AB, float>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s);
+    case SMOE_F16: return launch_variant<AB, f16>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s);
+    case SMOE_BF16: return launch_variant<AB, bf16_bits>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s);
   }
   smoe_set_error("smoe_grouped_gemm: bad out_dtype %d", out_dtype);
   return 1;
@@ -806,7 +831,7 @@ int dispatch_out(int variant, const void* A, const void* W, const float* bias, c
 
 extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int32_t* offsets,
                                  const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
-                                 int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale, void* out,
+                                 int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale, const void* residual, void* out,
                                  int out_dtype, int variant, void* stream) {
   SMOE_REQUIRE(offsets && G >= 1 && G <= 65536, "smoe_grouped_gemm: bad G=%d / offsets", G);
   SMOE_REQUIRE(n_experts >= 1 && (group_expert || n_experts == G), "smoe_grouped_gemm: n_experts=%d != G=%d without a group map", n_experts, G);
@@ -823,9 +848,9 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   if (K % 64 != 0 || smoe_dtype_size(ab_dtype) != 2) variant = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (ab_dtype) {
-    case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
-    case SMOE_F16: return dispatch_out<f16>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
-    case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, out, out_dtype, s);
+    case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s);
+    case SMOE_F16: return dispatch_out<f16>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s);
+    case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s);
   }
   return 1;
 }

@@ -67,7 +67,7 @@ def chunk_bounds(T: int, chunks: int) -> List[Tuple[int, int]]:
     return [((T * c) // chunks, (T * (c + 1)) // chunks) for c in range(chunks)]
 
 
-def ep_forward(mod, x: torch.Tensor, cd: torch.dtype) -> torch.Tensor:
+def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Expert-parallel FMoETransformerMLP forward for this rank's tokens x [T, d] -> [T, d]."""
     from . import ops
     from .fmoe import SwitchGate
@@ -130,7 +130,11 @@ def ep_forward(mod, x: torch.Tensor, cd: torch.dtype) -> torch.Tensor:
         if t1 > t0:
             inv_pos = plans[c][3]
             if back.shape[0] == 0:  # every entry of the chunk was dropped
-                out[t0:t1].zero_()
+                if residual is not None:
+                    out[t0:t1].copy_(residual[t0:t1])
+                else:
+                    out[t0:t1].zero_()
             else:
-                ops.gather_combine(back, inv_pos, score[t0:t1], t1 - t0, k, x.dtype, out=out[t0:t1])
+                ops.gather_combine(back, inv_pos, score[t0:t1], t1 - t0, k, x.dtype, out=out[t0:t1],
+                                   residual=None if residual is None else residual[t0:t1])
     return out

@@ -188,6 +188,16 @@ class FMoETransformerMLP(nn.Module):
         self.last_plan = None  # (idx, score, counts, offsets, pos, inv_pos) of the latest forward, for inspection
 
     # -- hot path ------------------------------------------------------------------------------------
+    def forward_add(self, inp: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+        """``residual + self(inp)`` with the add fused into the combine store (the ``x + mlp(norm2(x))`` of
+        models/vision_transformer.py:321); same arithmetic as the unfused form, one HBM pass fewer."""
+        if torch.is_grad_enabled() and (inp.requires_grad or residual.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            return residual + self.forward(inp)
+        if residual.shape != inp.shape or residual.dtype != inp.dtype:
+            return residual + self.forward(inp)
+        return self._forward_infer(inp, residual=residual)
+
     def forward(self, inp: torch.Tensor) -> torch.Tensor:
         if not inp.is_cuda:
             raise RuntimeError("FMoETransformerMLP: input must be on the GPU; this build has no CPU path "
@@ -212,7 +222,7 @@ class FMoETransformerMLP(nn.Module):
         return idx, score, probs, counts, offsets, pos, inv_pos, pruned
 
     def _experts_fwd(self, rows: torch.Tensor, offsets: torch.Tensor, cd: torch.dtype, out=None, row_map=None,
-                     row_scale=None, out_dtype=None, group_expert=None):
+                     row_scale=None, out_dtype=None, group_expert=None, residual=None):
         ex = self.experts
         w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
         b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
@@ -227,19 +237,24 @@ class FMoETransformerMLP(nn.Module):
                                  group_expert=group_expert)
             h = self._generic_act(h).to(cd).contiguous()
         return ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, out_dtype, row_map=row_map, row_scale=row_scale,
-                                out=out, variant=self.gemm_variant, group_expert=group_expert)
+                                out=out, variant=self.gemm_variant, group_expert=group_expert, residual=residual)
 
-    def _forward_infer(self, inp: torch.Tensor) -> torch.Tensor:
+    def _forward_infer(self, inp: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         shape = inp.shape
         d, k = self.d_model, self.top_k
         x = inp.reshape(-1, d)
         if not x.is_contiguous():
             x = x.contiguous()
+        res = None
+        if residual is not None:
+            res = residual.reshape(-1, d)
+            if not res.is_contiguous():
+                res = res.contiguous()
         T = x.shape[0]
         cd = self.compute_dtype or default_compute_dtype()
-        if self.world_size > 1:
+        if self.world_size > 1 or getattr(self, "force_ep", False):
             from .ep import ep_forward
-            return ep_forward(self, x, cd).reshape(shape)
+            return ep_forward(self, x, cd, residual=res).reshape(shape)
         idx, score, probs, counts, offsets, pos, inv_pos, pruned = self._route(x)
         self.last_plan = (idx, score, counts, offsets, pos, inv_pos)
         if isinstance(self.gate, SwitchGate):
@@ -249,10 +264,13 @@ class FMoETransformerMLP(nn.Module):
         if k == 1:
             # fused combine: GEMM-2 stores row s to out[pos[s]] * score[pos[s]]; dropped tokens stay 0
             dropping = self.gate.capacity(T) >= 0
-            out = (torch.zeros if dropping else torch.empty)((T, d), dtype=inp.dtype, device=inp.device)
+            if dropping:  # rows of dropped tokens are never stored by the GEMM: pre-fill them
+                out = res.clone() if res is not None else torch.zeros((T, d), dtype=inp.dtype, device=inp.device)
+            else:
+                out = torch.empty((T, d), dtype=inp.dtype, device=inp.device)
             self._experts_fwd(buf, offsets, cd, out=out, row_map=pos, row_scale=score.reshape(-1),
-                              out_dtype=inp.dtype)
+                              out_dtype=inp.dtype, residual=res)
         else:
             y = self._experts_fwd(buf, offsets, cd, out_dtype=cd)
-            out = ops.gather_combine(y, inv_pos, score, T, k, inp.dtype)
+            out = ops.gather_combine(y, inv_pos, score, T, k, inp.dtype, residual=res)
         return out.reshape(shape)

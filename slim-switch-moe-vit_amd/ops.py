@@ -188,7 +188,8 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
                  epilogue: int = EPI_NONE, out_dtype: Optional[torch.dtype] = None,
                  row_map: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
                  out: Optional[torch.Tensor] = None, variant: int = 0,
-                 group_expert: Optional[torch.Tensor] = None, rows_hint: Optional[int] = None) -> torch.Tensor:
+                 group_expert: Optional[torch.Tensor] = None, rows_hint: Optional[int] = None,
+                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[r] = epi(A[r] @ W[e]^T + bias[e]) for r in [offsets[g], offsets[g+1]), e = group_expert[g] (or g).
     W [E,N,K].  ``rows_hint`` = number of rows actually routed (for the profiler's FLOP count only)."""
     _chk(A, "A", ndim=2)
@@ -224,12 +225,16 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
         _chk(out, "out", out_dtype, 2)
         if out.shape[1] != N:
             raise RuntimeError("out: expected N columns")
+    if residual is not None:
+        _chk(residual, "residual", out_dtype, 2)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise RuntimeError("residual: expected the shape of out")
     lib = _lib.load()
     rows = M if rows_hint is None else rows_hint
     with _timed("grouped_gemm", {"flops": 2.0 * rows * K * N, "K": K, "N": N, "epilogue": epilogue}, A):
         rc = lib.smoe_grouped_gemm(_ptr(A), _ptr(W), _ptr(bias), _ptr(offsets), _ptr(group_expert), G, E, M, K, N,
-                                   dtype_code(A.dtype), epilogue, _ptr(row_map), _ptr(row_scale), _ptr(out),
-                                   dtype_code(out_dtype), variant, _stream(A))
+                                   dtype_code(A.dtype), epilogue, _ptr(row_map), _ptr(row_scale), _ptr(residual),
+                                   _ptr(out), dtype_code(out_dtype), variant, _stream(A))
     _lib.check(rc, "smoe_grouped_gemm")
     return out
 

@@ -117,6 +117,9 @@ class Block(nn.Module):
 
     def forward(self, x):
         x = x + self.drop_path(self.attn(self.norm1(x)))
+        fused = getattr(self.mlp, "forward_add", None)
+        if fused is not None and isinstance(self.drop_path, nn.Identity):
+            return fused(self.norm2(x), x)  # x + mlp(norm2(x)), add fused into the MoE combine store
         x = x + self.drop_path(self.mlp(self.norm2(x)))
         return x
 

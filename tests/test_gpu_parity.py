@@ -257,6 +257,20 @@ def test_moe_module_matches_oracle_vit_tiny_dims(E, k, skew, cd, tol):
     assert err <= tol, f"expert outputs differ by {err}"
 
 
+@pytest.mark.parametrize("k,gate,cap", [(1, "naive", None), (2, "naive", None), (1, "switch", 1.0)])
+def test_forward_add_equals_residual_plus_forward(k, gate, cap):
+    """forward_add(x, r) == r + forward(x) bit for bit (f32 output: same single add), incl. dropped tokens."""
+    d, h, E, T = 192, 768, 8, 3000
+    x, wg, bg, w1, b1, w2, b2 = _mk(T, d, h, E, seed=31 + k, skew=(gate == "switch"))
+    mod = sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=k, gate=gate, capacity_factor=cap)
+    mod = _load_module(mod, wg, bg, w1, b1, w2, b2)
+    r = torch.randn(T, d, generator=_gen(5)).to(DEV)
+    with torch.no_grad():
+        a = mod.forward_add(x.to(DEV), r)
+        b = r + mod(x.to(DEV))
+    assert torch.equal(a, b)
+
+
 def test_moe_module_e1_equals_reference_mlp_golden(golden_dir):
     """E = 1: the HIP path reproduces the REFERENCE's own dense Mlp (models/layers.py:391-414) outputs."""
     g = np.load(os.path.join(golden_dir, "ref_mlp_tiny.npz"))
@@ -357,3 +371,48 @@ def test_cfg2_full_size_properties():
     with torch.no_grad():
         out32 = mod32(xg[sel.to(DEV)].reshape(8, 256, d)).reshape(-1, d).cpu()
     assert (out32 - r.out).abs().max().item() <= 1e-4
+
+
+# ------------------------------------------------------------------------------------------ expert-parallel code path
+def test_expert_parallel_path_on_one_gpu():
+    """The expert-parallel forward (ep.py: chunked plans, count exchange, all-to-all-v over RCCL, grouped GEMM with
+    a group->expert map, gather_combine into output slices) driven on the real GPU with a world of ONE rank
+    (the multi-rank exchange logic itself is covered with gloo in test_ep_gloo.py)."""
+    import socket
+    import torch.distributed as dist
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        d, h, E, T = 192, 768, 8, 2500
+        for k, chunks, cd, tol in ((1, 1, torch.float32, 3e-5), (1, 3, torch.float32, 3e-5), (2, 2, torch.float32, 3e-5),
+                                   (1, 2, torch.float16, 2e-3)):
+            x, wg, bg, w1, b1, w2, b2 = _mk(T, d, h, E, seed=50 + k + chunks)
+            mod = _load_module(sm.CustomizedMoEMLP(d, h, E, k, 0.0, compute_dtype=cd), wg, bg, w1, b1, w2, b2)
+            r = torch.randn(T, d, generator=_gen(9)).to(DEV)
+            with torch.no_grad():
+                ref = mod(x.to(DEV))
+                ref_add = mod.forward_add(x.to(DEV), r)
+                mod.force_ep, mod.ep_chunks = True, chunks
+                got = mod(x.to(DEV))
+                got_add = mod.forward_add(x.to(DEV), r)
+            o = mo.moe_forward(x, wg, bg, w1, b1, w2, b2, k).out
+            assert (got.cpu() - o).abs().max().item() <= tol
+            assert (got - ref).abs().max().item() <= tol
+            assert (got_add - ref_add).abs().max().item() <= tol
+        # switch gate with drops runs un-chunked and keeps dropped rows at zero / at the residual
+        x, wg, bg, w1, b1, w2, b2 = _mk(T, d, h, E, seed=99, skew=True)
+        mod = sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=1, gate="switch", capacity_factor=1.0,
+                                    compute_dtype=torch.float32)
+        mod = _load_module(mod, wg, bg, w1, b1, w2, b2)
+        mod.force_ep = True
+        with torch.no_grad():
+            got = mod(x.to(DEV)).cpu()
+        o = mo.moe_forward(x, wg, bg, w1, b1, w2, b2, 1, mo.GATE_SWITCH, mo.switch_capacity(1.0, T, 1, E))
+        assert (got - o.out).abs().max().item() <= 3e-5
+        assert torch.all(got[torch.from_numpy(o.plan.idx_pruned < 0)] == 0)
+    finally:
+        dist.destroy_process_group()
