@@ -715,8 +715,12 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   constexpr int RP = (TBM * C_STRIDE <= LDS_BYTES) ? TBM : ((TBM / 2) * C_STRIDE <= LDS_BYTES ? TBM / 2 : TBM / 4);
   static_assert(RP * C_STRIDE <= LDS_BYTES, "epilogue pass does not fit in LDS");
   constexpr int NPASS = TBM / RP;
-  constexpr int CHUNKS = TBN * OB / 16;
-  constexpr int ROWS_PER_IT = NT / CHUNKS;
+  constexpr int CHUNKS = TBN * OB / 16;   // 16-B chunks per tile row
+  constexpr int TPR = 16;                 // threads per output row: 16 consecutive threads = 256 contiguous bytes
+  constexpr int CPT = CHUNKS / TPR;       // chunks per thread per row (strided by 256 B)
+  constexpr int ROWS_PER_IT = NT / TPR;   // 32
+  constexpr int ITS = RP / ROWS_PER_IT;
+  static_assert(CHUNKS % TPR == 0 && RP % ROWS_PER_IT == 0, "epilogue thread map");
   const float* bias_e = bias ? bias + (int64_t)e * N : nullptr;
   f32x4 bv[NI];
 #pragma unroll
@@ -725,10 +729,32 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     bv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (bias_e && n0 + nl < N) bv[ni] = *reinterpret_cast<const f32x4*>(bias_e + n0 + nl);
   }
-  const int ch = tid % CHUNKS, r0 = tid / CHUNKS;
-  const int ncol = n0 + ch * (16 / OB);
+  const int trow = tid / TPR, tcol = tid % TPR;
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
+    // (1) resolve this pass's output rows and start the residual loads: their latency hides under (2)
+    int64_t orow[ITS];
+    float oscale[ITS];
+    u32x4 resv[ITS][CPT];
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      const int m = m0 + p * RP + trow + it * ROWS_PER_IT;
+      orow[it] = -1;
+      oscale[it] = 1.f;
+      if (m < m_end) {
+        orow[it] = row_map ? row_map[m] : (int64_t)m;
+        if (row_map && row_scale) oscale[it] = row_scale[orow[it]];
+      }
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        resv[it][j] = u32x4{0u, 0u, 0u, 0u};
+        const int ncol = n0 + (tcol + j * TPR) * (16 / OB);
+        if (residual && orow[it] >= 0 && ncol < N)
+          resv[it][j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) +
+                                                        (orow[it] * (int64_t)N + ncol) * OB);
+      }
+    }
+    // (2) bias (+GELU), convert, stage this pass's rows in LDS
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int row = wr * TM + mi * 16;  // wave-uniform
@@ -745,19 +771,22 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
       }
     }
     __syncthreads();
-    if (ncol < N) {
-      for (int r = r0; r < RP; r += ROWS_PER_IT) {
-        const int m = m0 + p * RP + r;
-        if (m >= m_end) break;
-        u32x4 v = *reinterpret_cast<const u32x4*>(smem + r * C_STRIDE + ch * 16);
-        int64_t orow = m;
-        if (row_map) {
-          orow = row_map[m];
-          if (row_scale) v = scale16<OT>(v, row_scale[orow]);
+    // (3) whole-row-segment stores (combine scale and residual fused)
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+      if (orow[it] >= 0) {
+        const int r = trow + it * ROWS_PER_IT;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          const int ch = tcol + j * TPR;
+          const int ncol = n0 + ch * (16 / OB);
+          if (ncol < N) {
+            u32x4 v = *reinterpret_cast<const u32x4*>(smem + r * C_STRIDE + ch * 16);
+            if (row_map && row_scale) v = scale16<OT>(v, oscale[it]);
+            if (residual) v = add16<OT>(resv[it][j], v);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow[it] * (int64_t)N + ncol) * OB) = v;
+          }
         }
-        const int64_t ooff = (orow * (int64_t)N + ncol) * OB;
-        if (residual) v = add16<OT>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + ooff), v);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + ooff) = v;
       }
     }
     if (p + 1 < NPASS) __syncthreads();

@@ -68,7 +68,7 @@ class _timed:
             _PROFILE.append((self.name, self.meta, self.s, self.e))
 
 
-def _chk(t: torch.Tensor, name: str, dtype=None, ndim=None):
+def _chk(t: torch.Tensor, name: str, dtype=None, ndim=None, align: int = 16):
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
     if not t.is_cuda:
@@ -79,8 +79,8 @@ def _chk(t: torch.Tensor, name: str, dtype=None, ndim=None):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if ndim is not None and t.dim() != ndim:
         raise RuntimeError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
-    if t.data_ptr() % 16 != 0 and t.numel() > 0:
-        raise RuntimeError(f"{name}: data pointer must be 16-byte aligned")
+    if t.data_ptr() % align != 0 and t.numel() > 0:
+        raise RuntimeError(f"{name}: data pointer must be {align}-byte aligned")
 
 
 def router_topk(x: torch.Tensor, wg: torch.Tensor, bg: Optional[torch.Tensor], k: int, gate_kind: int = GATE_NAIVE,
@@ -118,7 +118,7 @@ def router_topk(x: torch.Tensor, wg: torch.Tensor, bg: Optional[torch.Tensor], k
 
 def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Optional[bool] = None):
     """(counts i32 [E], offsets i32 [E+1], pos i64 [n], inv_pos i64 [n], idx_pruned i64 [n] | None)."""
-    _chk(idx, "idx", torch.int64)
+    _chk(idx, "idx", torch.int64, align=8)  # read element-wise: slices of a [T,k] tensor are fine
     flat = idx.reshape(-1)
     n = flat.numel()
     dev = idx.device
@@ -143,7 +143,7 @@ def scatter_rows(x: torch.Tensor, pos: torch.Tensor, k: int, out_dtype: torch.dt
                  out: Optional[torch.Tensor] = None, zero_fill: bool = False) -> torch.Tensor:
     """buf[s] = cast(x[pos[s] // k]) for every slot with pos[s] >= 0 (MOEScatter local part)."""
     _chk(x, "x", ndim=2)
-    _chk(pos, "pos", torch.int64, 1)
+    _chk(pos, "pos", torch.int64, 1, align=8)
     n_slots = pos.numel()
     d = x.shape[1]
     if out is None:
@@ -163,8 +163,8 @@ def gather_combine(y: torch.Tensor, inv_pos: torch.Tensor, score: torch.Tensor, 
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[t] = sum_j score[t,j] * y[inv_pos[t*k+j]] (+ residual[t]); dropped entries contribute 0."""
     _chk(y, "y", ndim=2)
-    _chk(inv_pos, "inv_pos", torch.int64)
-    _chk(score, "score", torch.float32)
+    _chk(inv_pos, "inv_pos", torch.int64, align=8)
+    _chk(score, "score", torch.float32, align=4)
     d = y.shape[1]
     if inv_pos.numel() != T * k or score.numel() != T * k:
         raise RuntimeError("inv_pos / score: expected T*k entries")
@@ -214,11 +214,11 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     if out_dtype is None:
         out_dtype = out.dtype if out is not None else A.dtype
     if row_map is not None:
-        _chk(row_map, "row_map", torch.int64, 1)
+        _chk(row_map, "row_map", torch.int64, 1, align=8)
         if out is None:
             raise RuntimeError("row_map needs a caller-provided `out`")
         if row_scale is not None:
-            _chk(row_scale, "row_scale", torch.float32)
+            _chk(row_scale, "row_scale", torch.float32, align=4)
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
     else:
