@@ -27,7 +27,7 @@ extern "C" {
 
 enum { SMOE_F32 = 0, SMOE_F16 = 1, SMOE_BF16 = 2 };
 enum { SMOE_GATE_NAIVE = 0, SMOE_GATE_SWITCH = 1 };
-enum { SMOE_EPI_NONE = 0, SMOE_EPI_GELU = 1 };
+enum { SMOE_EPI_NONE = 0, SMOE_EPI_GELU = 1, SMOE_EPI_GELU_GRAD = 2 };
 
 /* library ABI version (bumped on any signature change) */
 int smoe_abi_version(void);
@@ -70,8 +70,9 @@ int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t capacity,
 
 /* ---- token scatter (MOEScatter.forward local part: index_select(x, 0, pos // k)) ----
  * buf[s,:] = cast(x[pos[s] / k, :]) for every slot s < n_slots with pos[s] >= 0; other rows untouched.
- * x [T,d], buf [n_slots,d]; d % 8 == 0.                                                            */
-int smoe_scatter_rows(const void* x, int x_dtype, const int64_t* pos, int64_t n_slots, int k, int d,
+ * x [T,d], buf [n_slots,d]; d % 8 == 0.  scale (f32 [T*k], may be NULL) multiplies row s by scale[pos[s]]
+ * (backward of the combine: dY[s] = score * dout[token]).                                           */
+int smoe_scatter_rows(const void* x, int x_dtype, const int64_t* pos, const float* scale, int64_t n_slots, int k, int d,
                       void* buf, int buf_dtype, void* stream);
 
 /* ---- gather + combine (MOEGather.forward + bmm(gate_score, y)) -------------------
@@ -94,6 +95,8 @@ int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, cons
  * multiplied by row_scale[row_map[r]] if row_scale != NULL  (MOEGather + bmm for k = 1).
  * Optional fused residual (residual != NULL, same dtype / shape as out): the stored value is
  * residual[orow, :] + value -- the `x + mlp(norm2(x))` add of models/vision_transformer.py:321.
+ * SMOE_EPI_GELU_GRAD (backward of the activation, fused into the dgrad GEMM): `residual` then holds the saved
+ * pre-activations H and the stored value is value * gelu'(H[r, :]).
  * Optional group -> expert map (group_expert != NULL, i32 [G]): `offsets` then delimits G row groups and
  * group g uses W[group_expert[g]] / bias[group_expert[g]] (expert-parallel receive layout: one group per
  * (source rank, local expert)); n_experts = leading dimension of W / bias.
@@ -102,6 +105,23 @@ int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int
                       const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
                       int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,
                       const void* residual, void* out, int out_dtype, int variant, void* stream);
+
+/* ---- backward pieces (fmoe_cuda.linear_backward and the adjoints of scatter / gather) ---------
+ * smoe_gelu:            dst = gelu_erf(src), n % 8 == 0 (training forward keeps the pre-activations)
+ * smoe_rowdot:          dscore[i] = <dout[i / k, :], y[inv_pos[i], :]>, 0 for dropped entries (i < n = T*k)
+ * smoe_pad_offsets:     offsets_pad[e] = sum_{e'<e} round_up(count[e'], 64)
+ * smoe_transpose_pad:   src [n_rows, C] expert-sorted -> dst [C, Lp] K-major, per-expert ranges at offsets_pad, zero pad
+ * smoe_grouped_wgrad:   out[e] (f32 [R1,R2]) = PT[:, range e] @ QT[:, range e]^T   (PT [R1,Lp], QT [R2,Lp], 16-bit)
+ * smoe_group_colsum:    out[e, c] = sum over expert e's rows of src[:, c]  (bias gradients)                       */
+int smoe_gelu(const void* src, void* dst, int dtype, int64_t n, void* stream);
+int smoe_rowdot(const void* dout, int dout_dtype, const void* y, int y_dtype, const int64_t* inv_pos,
+                int64_t n, int k, int d, float* dscore, void* stream);
+int smoe_pad_offsets(const int32_t* offsets, int E, int32_t* offsets_pad, void* stream);
+int smoe_transpose_pad(const void* src, int dtype, const int32_t* offsets, const int32_t* offsets_pad, int E,
+                       int64_t n_rows, int C, int Lp, void* dst, void* stream);
+int smoe_grouped_wgrad(const void* PT, const void* QT, int ab_dtype, const int32_t* offsets_pad, int E, int R1,
+                       int R2, int Lp, float* out, void* stream);
+int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int C, float* out, void* stream);
 
 /* ---- small helpers ------------------------------------------------------------------------------------
  * elementwise cast between dtypes (weight shadow copies; not on the per-step path)                  */

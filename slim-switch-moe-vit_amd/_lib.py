@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: the library resolves libamd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -25,7 +25,13 @@ SIGNATURES = {
     "smoe_dispatch_plan_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "smoe_dispatch_plan": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
-    "smoe_scatter_rows": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "smoe_scatter_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "smoe_gelu": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "smoe_rowdot": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "smoe_pad_offsets": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "smoe_transpose_pad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "smoe_grouped_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "smoe_group_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "smoe_gather_combine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                     c_int, c_void_p]),
     "smoe_grouped_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,

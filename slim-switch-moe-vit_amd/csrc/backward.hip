@@ -1,0 +1,211 @@
+// Backward-side helpers of the MoE operator (BASELINE cfg 5; SURVEY.md N5, Appendix B 'backward'):
+//   smoe_gelu            A = gelu(H)                      (training forward keeps the pre-activation)
+//   smoe_rowdot          dscore[i] = <dout[i/k], y[inv_pos[i]]>
+//   smoe_pad_offsets / smoe_transpose_pad
+//                        expert-sorted rows [n,C] -> K-major image [C, Lp] whose per-expert column ranges
+//                        start on multiples of 64 (zero padded) = the operand layout of the wgrad GEMM
+//   smoe_group_colsum    bias gradients: out[e,c] = sum of rows of expert e
+#include "smoe_common.h"
+#include <type_traits>
+
+namespace {
+
+__device__ __forceinline__ float gelu_fwd(float v) {
+  const float a = fabsf(v);
+  const float z = a * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float ex = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+  return 0.5f * fmaf(a, fmaf(-p, ex, 1.0f), v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i + 8 <= n; i += stride) {
+    float v[8];
+    load8(src + i, v);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = gelu_fwd(v[q]);
+    store8(dst + i, v);
+  }
+}
+
+template <typename DT, typename YT>
+__global__ __launch_bounds__(256) void rowdot_kernel(const DT* __restrict__ dout, const YT* __restrict__ y,
+                                                     const int64_t* __restrict__ inv_pos, int64_t n, int k, int d,
+                                                     float* __restrict__ dscore) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave_gid; i < n; i += nwaves) {
+    const int64_t slot = inv_pos[i];
+    float acc = 0.f;
+    if (slot >= 0) {
+      for (int c = lane * 8; c < d; c += 512) {
+        float a[8], b[8];
+        load8(dout + (i / k) * (int64_t)d + c, a);
+        load8(y + slot * (int64_t)d + c, b);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = fmaf(a[q], b[q], acc);
+      }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) dscore[i] = acc;
+  }
+}
+
+// offsets_pad[e] = sum_{e'<e} round_up(offsets[e'+1]-offsets[e'], 64)
+__global__ void pad_offsets_kernel(const int32_t* __restrict__ offsets, int E, int32_t* __restrict__ offsets_pad) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int run = 0;
+    for (int e = 0; e < E; ++e) {
+      offsets_pad[e] = run;
+      run += ((offsets[e + 1] - offsets[e]) + 63) & ~63;
+    }
+    offsets_pad[E] = run;
+  }
+}
+
+// 64 x 64 tiles: block (cb, rb) transposes padded columns [64 rb, +64) x source columns [64 cb, +64).
+// The grid covers the whole padded length Lp, so pad columns are written as zeros.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ src, const int32_t* __restrict__ offsets,
+                                                            const int32_t* __restrict__ offsets_pad, int E, int C, int Lp,
+                                                            T* __restrict__ dst) {
+  __shared__ T tile[64][66];
+  const int p0 = blockIdx.y * 64;  // padded-column tile
+  const int c0 = blockIdx.x * 64;
+  // padded ranges start on multiples of 64, so a 64-wide padded tile lies inside one expert's range
+  int e = -1, src_row0 = 0, valid = 0;
+  for (int q = 0; q < E; ++q) {
+    const int lo = offsets_pad[q], hi = offsets_pad[q + 1];
+    if (p0 >= lo && p0 < hi) {
+      e = q;
+      src_row0 = offsets[q] + (p0 - lo);
+      const int left = offsets[q + 1] - src_row0;
+      valid = left < 0 ? 0 : (left > 64 ? 64 : left);
+      break;
+    }
+  }
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 row groups
+  for (int r = ty; r < 64; r += 4) {
+    T v = (T)0;
+    if (e >= 0 && r < valid && c0 + tx < C) v = src[(int64_t)(src_row0 + r) * C + c0 + tx];
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4) {
+    if (c0 + c < C && p0 + tx < Lp) dst[(int64_t)(c0 + c) * Lp + p0 + tx] = tile[tx][c];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void group_colsum_kernel(const T* __restrict__ src, const int32_t* __restrict__ offsets,
+                                                           int C, float* __restrict__ out) {
+  // block (cb, e): 256 columns of expert e, 4 row phases... thread = column, loop over the expert's rows
+  const int e = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int lo = offsets[e], hi = offsets[e + 1];
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  int r = lo;
+  auto ld = [&](int row) -> float {
+    if constexpr (std::is_same<T, float>::value) return src[(int64_t)row * C + c];
+    else if constexpr (std::is_same<T, f16>::value) return (float)src[(int64_t)row * C + c];
+    else return bf16_to_f32(src[(int64_t)row * C + c]);
+  };
+  for (; r + 4 <= hi; r += 4) { acc0 += ld(r); acc1 += ld(r + 1); acc2 += ld(r + 2); acc3 += ld(r + 3); }
+  for (; r < hi; ++r) acc0 += ld(r);
+  out[(int64_t)e * C + c] = (acc0 + acc1) + (acc2 + acc3);
+}
+
+template <typename F> int by_dtype(int code, F&& f) {
+  switch (code) {
+    case SMOE_F32: return f((float*)nullptr);
+    case SMOE_F16: return f((f16*)nullptr);
+    case SMOE_BF16: return f((bf16_bits*)nullptr);
+  }
+  smoe_set_error("bad dtype %d", code);
+  return 1;
+}
+
+}  // namespace
+
+extern "C" int smoe_gelu(const void* src, void* dst, int dtype, int64_t n, void* stream) {
+  SMOE_REQUIRE(n >= 0 && n % 8 == 0, "smoe_gelu: n=%lld must be a multiple of 8", (long long)n);
+  if (n == 0) return 0;
+  SMOE_REQUIRE(src && dst, "smoe_gelu: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  return by_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL((gelu_kernel<T>), dim3((int)blocks), dim3(256), 0, s, (const T*)src, (T*)dst, n);
+    SMOE_CHECK_LAUNCH("smoe_gelu");
+    return 0;
+  });
+}
+
+extern "C" int smoe_rowdot(const void* dout, int dout_dtype, const void* y, int y_dtype, const int64_t* inv_pos,
+                           int64_t n, int k, int d, float* dscore, void* stream) {
+  SMOE_REQUIRE(n >= 0 && k >= 1 && d > 0 && d % 8 == 0, "smoe_rowdot: bad sizes");
+  if (n == 0) return 0;
+  SMOE_REQUIRE(dout && y && inv_pos && dscore, "smoe_rowdot: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = (n + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  return by_dtype(dout_dtype, [&](auto* t1) {
+    using DT = std::remove_pointer_t<decltype(t1)>;
+    return by_dtype(y_dtype, [&](auto* t2) {
+      using YT = std::remove_pointer_t<decltype(t2)>;
+      hipLaunchKernelGGL((rowdot_kernel<DT, YT>), dim3((int)blocks), dim3(256), 0, s, (const DT*)dout, (const YT*)y,
+                         inv_pos, n, k, d, dscore);
+      SMOE_CHECK_LAUNCH("smoe_rowdot");
+      return 0;
+    });
+  });
+}
+
+extern "C" int smoe_pad_offsets(const int32_t* offsets, int E, int32_t* offsets_pad, void* stream) {
+  SMOE_REQUIRE(offsets && offsets_pad && E >= 1, "smoe_pad_offsets: bad arguments");
+  hipLaunchKernelGGL(pad_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, offsets, E, offsets_pad);
+  SMOE_CHECK_LAUNCH("smoe_pad_offsets");
+  return 0;
+}
+
+extern "C" int smoe_transpose_pad(const void* src, int dtype, const int32_t* offsets, const int32_t* offsets_pad, int E,
+                                  int64_t n_rows, int C, int Lp, void* dst, void* stream) {
+  SMOE_REQUIRE(src && dst && offsets && offsets_pad, "smoe_transpose_pad: null pointer");
+  SMOE_REQUIRE(E >= 1 && C > 0 && Lp > 0 && Lp % 64 == 0 && (int64_t)Lp >= ((n_rows + 63) / 64) * 64,
+               "smoe_transpose_pad: bad sizes (Lp=%d must be a multiple of 64 and >= padded rows)", Lp);
+  SMOE_REQUIRE(dtype == SMOE_F16 || dtype == SMOE_BF16 || dtype == SMOE_F32, "smoe_transpose_pad: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((C + 63) / 64, Lp / 64);
+  if (dtype == SMOE_F32) {
+    hipLaunchKernelGGL((transpose_pad_kernel<float>), grid, dim3(256), 0, s, (const float*)src, offsets, offsets_pad, E, C, Lp, (float*)dst);
+  } else {
+    hipLaunchKernelGGL((transpose_pad_kernel<unsigned short>), grid, dim3(256), 0, s, (const unsigned short*)src, offsets,
+                       offsets_pad, E, C, Lp, (unsigned short*)dst);
+  }
+  SMOE_CHECK_LAUNCH("smoe_transpose_pad");
+  return 0;
+}
+
+extern "C" int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int C, float* out,
+                                 void* stream) {
+  SMOE_REQUIRE(src && offsets && out && E >= 1 && C > 0, "smoe_group_colsum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((C + 255) / 256, E);
+  return by_dtype(dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL((group_colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)src, offsets, C, out);
+    SMOE_CHECK_LAUNCH("smoe_group_colsum");
+    return 0;
+  });
+}

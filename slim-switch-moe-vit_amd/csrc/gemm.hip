@@ -99,6 +99,46 @@ template <> __device__ __forceinline__ u32x4 add16<bf16_bits>(u32x4 a, u32x4 b) 
   return __builtin_bit_cast(u32x4, x);
 }
 
+// d/dv gelu(v) = Phi(v) + v phi(v), same erf approximation as gelu_erf
+__device__ __forceinline__ float gelu_grad(float v) {
+  const float a = fabsf(v);
+  const float z = a * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float ex = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);  // exp(-v^2/2)
+  const float erf_abs = fmaf(-p, ex, 1.0f);
+  const float cdf = 0.5f + 0.5f * copysignf(erf_abs, v);
+  return fmaf(v * 0.3989422804014327f, ex, cdf);
+}
+// 16 bytes of output elements times gelu'(16 bytes of saved pre-activations)  (SMOE_EPI_GELU_GRAD)
+template <typename OT> __device__ __forceinline__ u32x4 mulgrad16(u32x4 aux, u32x4 val);
+template <> __device__ __forceinline__ u32x4 mulgrad16<float>(u32x4 aux, u32x4 val) {
+  f32x4 h = __builtin_bit_cast(f32x4, aux), v = __builtin_bit_cast(f32x4, val);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] *= gelu_grad(h[i]);
+  return __builtin_bit_cast(u32x4, v);
+}
+template <> __device__ __forceinline__ u32x4 mulgrad16<f16>(u32x4 aux, u32x4 val) {
+  f16x8 h = __builtin_bit_cast(f16x8, aux), v = __builtin_bit_cast(f16x8, val);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (f16)((float)v[i] * gelu_grad((float)h[i]));
+  return __builtin_bit_cast(u32x4, v);
+}
+template <> __device__ __forceinline__ u32x4 mulgrad16<bf16_bits>(u32x4 aux, u32x4 val) {
+  s16x8 h = __builtin_bit_cast(s16x8, aux), v = __builtin_bit_cast(s16x8, val);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    v[i] = (short)f32_to_bf16(bf16_to_f32((unsigned short)v[i]) * gelu_grad(bf16_to_f32((unsigned short)h[i])));
+  return __builtin_bit_cast(u32x4, v);
+}
+template <typename OT> __device__ __forceinline__ u32x4 fuse_aux(int epilogue, u32x4 aux, u32x4 val) {
+  return epilogue == SMOE_EPI_GELU_GRAD ? mulgrad16<OT>(aux, val) : add16<OT>(aux, val);
+}
+
 // locate the (expert, row range) of global m-tile `mt`; returns false if there is no such tile
 __device__ __forceinline__ bool find_tile(const int32_t* __restrict__ offsets, int E, int mt, int& e_out, int& m0,
                                           int& m_end, int bm = BM) {
@@ -276,7 +316,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void grouped_gemm_t128(
           if (row_scale) v = scale16<OT>(v, row_scale[orow]);
         }
         const int64_t ooff = (orow * (int64_t)N + ncol) * OB;
-        if (residual) v = add16<OT>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + ooff), v);
+        if (residual) v = fuse_aux<OT>(epilogue, *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + ooff), v);
         *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + ooff) = v;
       }
     }
@@ -475,7 +515,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void grouped_gemm_glds(
           if (row_scale) v = scale16<OT>(v, row_scale[orow]);
         }
         const int64_t ooff = (orow * (int64_t)N + ncol) * OB;
-        if (residual) v = add16<OT>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + ooff), v);
+        if (residual) v = fuse_aux<OT>(epilogue, *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + ooff), v);
         *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + ooff) = v;
       }
     }
@@ -533,12 +573,15 @@ int launch_glds(const void* A, const void* W, const float* bias, const int32_t* 
 
 // ABL: timing-only ablation bits (diagnostic variants 40-47; results are wrong by construction):
 //   1 = no DMA inside the K loop, 2 = no fragment ds_reads inside the K loop, 4 = no MFMA
-template <typename AB, typename OT, int ABL = 0>
+// MODE 1 = weight-gradient GEMM: C[e] = P^T[:, k-range e] (Q^T[:, k-range e])^T with both operands stored K-major
+// ([rows, Lp], per-expert column ranges padded to multiples of 64: smoe_transpose_pad); `offsets` are the
+// padded ranges, K = Lp (row stride), N = rows of Q^T, m_rows = rows of P^T, one [m_rows, N] output per expert.
+template <typename AB, typename OT, int ABL = 0, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
     const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* __restrict__ residual, OT* __restrict__ out, int n_tiles_n,
-    int group_m) {
+    int group_m, int m_rows) {
   static_assert(sizeof(AB) == 2, "16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TBM = 256, TBN = 256, NT = 512, NW = 8;
@@ -551,14 +594,27 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int per_group = group_m * n_tiles_n;
-  const int g = bid / per_group, rem = bid % per_group;
-  const int mt = g * group_m + rem % group_m;
-  const int nt = rem / group_m;
-  int e, m0, m_end;
-  if (!find_tile(offsets, E, mt, e, m0, m_end, TBM)) return;
-  if (group_expert) e = group_expert[e];
-  const int n0 = nt * TBN;
+  int e, m0, m_end, n0, k_base = 0, nk = K / 64;
+  if constexpr (MODE == 0) {
+    const int per_group = group_m * n_tiles_n;
+    const int g = bid / per_group, rem = bid % per_group;
+    const int mt = g * group_m + rem % group_m;
+    const int nt = rem / group_m;
+    if (!find_tile(offsets, E, mt, e, m0, m_end, TBM)) return;
+    if (group_expert) e = group_expert[e];
+    n0 = nt * TBN;
+  } else {
+    // wgrad: static grid E x m-tiles x n-tiles (group_m carries the number of m-tiles)
+    const int per_e = group_m * n_tiles_n;
+    e = bid / per_e;
+    const int rem = bid % per_e;
+    m0 = (rem % group_m) * TBM;
+    n0 = (rem / group_m) * TBN;
+    m_end = m_rows;
+    k_base = offsets[e];
+    nk = (offsets[e + 1] - k_base) / 64;
+    out += (int64_t)e * m_rows * N;
+  }
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -572,10 +628,10 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     const int r = 8 * (s * NW + wave) + l_row;
     int gr = m0 + r;
     if (gr >= m_end) gr = m_end - 1;
-    a_src[s] = A + (int64_t)gr * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+    a_src[s] = A + (int64_t)gr * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
     int gw = n0 + r;
     if (gw >= N) gw = N - 1;
-    w_src[s] = W + ((int64_t)e * N + gw) * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+    w_src[s] = W + ((int64_t)(MODE == 0 ? e : 0) * N + gw) * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
   }
   // DMA of pieces [s0, s0+2) of A or W of K-tile kt into buffer buf
   auto dma_a = [&](int kt, int buf, int s0) {
@@ -603,7 +659,6 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   u32x4 ar[4][2], br[2][2];  // current A-half (4 row fragments x 2 k-steps), B-half (2 col fragments x 2 k-steps)
 
   const int fr = lane & 15, fq = lane >> 4;
-  const int nk = K / 64;
 
   if (ABL & 2) {
 #pragma unroll
@@ -647,6 +702,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     __builtin_amdgcn_s_setprio(0);                                                                                   \
   } while (0)
 
+  if (nk > 0) {  // block-uniform (an expert without rows has an empty k-range in wgrad mode)
   // ---- prologue: tiles 0 and 1 -> buffers 0 and 1 ------------------------------------------------------
   dma_a(0, 0, 0); dma_a(0, 0, 2); dma_w(0, 0, 0); dma_w(0, 0, 2);
   if (nk > 1) {
@@ -705,6 +761,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     PP_BARRIER();
   }
   if (wr == 0) PP_BARRIER();  // equalise barrier counts; after it every wave is done with LDS
+  }
 #undef PP_MFMA
 
   // ---- epilogue in row passes through LDS (same as the glds variants) --------------------------------
@@ -783,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
           if (ncol < N) {
             u32x4 v = *reinterpret_cast<const u32x4*>(smem + r * C_STRIDE + ch * 16);
             if (row_map && row_scale) v = scale16<OT>(v, oscale[it]);
-            if (residual) v = add16<OT>(resv[it][j], v);
+            if (residual) v = fuse_aux<OT>(epilogue, resv[it][j], v);
             *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow[it] * (int64_t)N + ncol) * OB) = v;
           }
         }
@@ -814,8 +871,32 @@ int launch_pp256(const void* A, const void* W, const float* bias, const int32_t*
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert, E, K, N,
-                     epilogue, row_map, row_scale, (const OT*)residual, (OT*)out, n_tiles_n, group_m);
+                     epilogue, row_map, row_scale, (const OT*)residual, (OT*)out, n_tiles_n, group_m, 0);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
+  return 0;
+}
+
+template <typename AB>
+int launch_wgrad(const void* PT, const void* QT, const int32_t* offsets_pad, int E, int R1, int R2, int Lp, float* out,
+                 hipStream_t s) {
+  constexpr int TBM = 256, TBN = 256;
+  const int tm = (R1 + TBM - 1) / TBM, tn = (R2 + TBN - 1) / TBN;
+  const int grid = E * tm * tn;
+  const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
+  auto kern = grouped_gemm_pp256<AB, float, 0, 1>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ae != hipSuccess) {
+      smoe_set_error("smoe_grouped_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
+      return (int)ae;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)PT, (const AB*)QT, (const float*)nullptr, offsets_pad,
+                     (const int32_t*)nullptr, E, Lp, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, out, tn, tm, R1);
+  SMOE_CHECK_LAUNCH("smoe_grouped_wgrad");
   return 0;
 }
 
@@ -867,7 +948,10 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   SMOE_REQUIRE(m_rows_max >= 0 && m_rows_max < (1ll << 31), "smoe_grouped_gemm: m_rows_max=%lld out of range",
                (long long)m_rows_max);
   SMOE_REQUIRE(K > 0 && N > 0, "smoe_grouped_gemm: bad K=%d N=%d", K, N);
-  SMOE_REQUIRE(epilogue == SMOE_EPI_NONE || epilogue == SMOE_EPI_GELU, "smoe_grouped_gemm: bad epilogue %d", epilogue);
+  SMOE_REQUIRE(epilogue == SMOE_EPI_NONE || epilogue == SMOE_EPI_GELU || epilogue == SMOE_EPI_GELU_GRAD,
+               "smoe_grouped_gemm: bad epilogue %d", epilogue);
+  SMOE_REQUIRE(epilogue != SMOE_EPI_GELU_GRAD || (residual && !row_map),
+               "smoe_grouped_gemm: SMOE_EPI_GELU_GRAD needs the pre-activations in `residual` and no row_map");
   SMOE_REQUIRE(smoe_dtype_ok(ab_dtype) && smoe_dtype_ok(out_dtype), "smoe_grouped_gemm: bad dtype");
   const int bke = BK_BYTES / smoe_dtype_size(ab_dtype);
   SMOE_REQUIRE(K % bke == 0, "smoe_grouped_gemm: K=%d must be a multiple of %d for this dtype", K, bke);
@@ -881,5 +965,21 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
     case SMOE_F16: return dispatch_out<f16>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s);
     case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s);
   }
+  return 1;
+}
+
+// Weight gradients of a grouped linear (fmoe_cuda.linear_backward's grad_W):
+//   out[e] (f32 [R1,R2]) = PT[:, offsets_pad[e]:offsets_pad[e+1]] @ QT[:, same]^T
+// PT [R1,Lp], QT [R2,Lp] are the K-major, 64-padded images made by smoe_transpose_pad (e.g. PT = dY^T, QT = A^T
+// gives dW2[e] = dY_e^T A_e in W2's [d,h] layout).  16-bit operands, f32 result.
+extern "C" int smoe_grouped_wgrad(const void* PT, const void* QT, int ab_dtype, const int32_t* offsets_pad, int E, int R1,
+                                  int R2, int Lp, float* out, void* stream) {
+  SMOE_REQUIRE(PT && QT && offsets_pad && out, "smoe_grouped_wgrad: null pointer");
+  SMOE_REQUIRE(E >= 1 && R1 > 0 && R2 > 0 && Lp > 0 && Lp % 64 == 0 && R2 % 8 == 0,
+               "smoe_grouped_wgrad: bad sizes E=%d R1=%d R2=%d Lp=%d", E, R1, R2, Lp);
+  hipStream_t s = (hipStream_t)stream;
+  if (ab_dtype == SMOE_F16) return launch_wgrad<f16>(PT, QT, offsets_pad, E, R1, R2, Lp, out, s);
+  if (ab_dtype == SMOE_BF16) return launch_wgrad<bf16_bits>(PT, QT, offsets_pad, E, R1, R2, Lp, out, s);
+  smoe_set_error("smoe_grouped_wgrad: operands must be f16 or bf16");
   return 1;
 }

@@ -14,7 +14,7 @@ from . import _lib
 
 F32, F16, BF16 = 0, 1, 2
 GATE_NAIVE, GATE_SWITCH = 0, 1
-EPI_NONE, EPI_GELU = 0, 1
+EPI_NONE, EPI_GELU, EPI_GELU_GRAD = 0, 1, 2
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
@@ -140,8 +140,10 @@ def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Op
 
 
 def scatter_rows(x: torch.Tensor, pos: torch.Tensor, k: int, out_dtype: torch.dtype,
-                 out: Optional[torch.Tensor] = None, zero_fill: bool = False) -> torch.Tensor:
-    """buf[s] = cast(x[pos[s] // k]) for every slot with pos[s] >= 0 (MOEScatter local part)."""
+                 out: Optional[torch.Tensor] = None, zero_fill: bool = False,
+                 scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """buf[s] = cast(x[pos[s] // k]) (* scale[pos[s]]) for every slot with pos[s] >= 0 (MOEScatter local part;
+    with ``scale`` = the adjoint of the combine)."""
     _chk(x, "x", ndim=2)
     _chk(pos, "pos", torch.int64, 1, align=8)
     n_slots = pos.numel()
@@ -150,9 +152,13 @@ def scatter_rows(x: torch.Tensor, pos: torch.Tensor, k: int, out_dtype: torch.dt
         out = (torch.zeros if zero_fill else torch.empty)((n_slots, d), dtype=out_dtype, device=x.device)
     else:
         _chk(out, "out", out_dtype, 2)
+    if scale is not None:
+        _chk(scale, "scale", torch.float32, align=4)
+        if scale.numel() != x.shape[0] * k:
+            raise RuntimeError("scale: expected T*k entries")
     lib = _lib.load()
     with _timed("scatter", {"bytes": n_slots * d * (x.element_size() + out.element_size())}, x):
-        rc = lib.smoe_scatter_rows(_ptr(x), dtype_code(x.dtype), _ptr(pos), n_slots, k, d, _ptr(out),
+        rc = lib.smoe_scatter_rows(_ptr(x), dtype_code(x.dtype), _ptr(pos), _ptr(scale), n_slots, k, d, _ptr(out),
                                    dtype_code(out.dtype), _stream(x))
     _lib.check(rc, "smoe_scatter_rows")
     return out
@@ -246,3 +252,76 @@ def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     rc = lib.smoe_cast(_ptr(src), dtype_code(src.dtype), _ptr(dst), dtype_code(dtype), src.numel(), _stream(src))
     _lib.check(rc, "smoe_cast")
     return dst
+
+
+# ------------------------------------------------------------------------------------------ backward pieces
+def gelu(src: torch.Tensor) -> torch.Tensor:
+    _chk(src, "src")
+    dst = torch.empty_like(src)
+    rc = _lib.load().smoe_gelu(_ptr(src), _ptr(dst), dtype_code(src.dtype), src.numel(), _stream(src))
+    _lib.check(rc, "smoe_gelu")
+    return dst
+
+
+def rowdot(dout: torch.Tensor, y: torch.Tensor, inv_pos: torch.Tensor, k: int) -> torch.Tensor:
+    """dscore[i] = <dout[i // k], y[inv_pos[i]]> (0 for dropped entries)."""
+    _chk(dout, "dout", ndim=2)
+    _chk(y, "y", ndim=2)
+    _chk(inv_pos, "inv_pos", torch.int64, align=8)
+    n = inv_pos.numel()
+    out = torch.empty(n, dtype=torch.float32, device=dout.device)
+    rc = _lib.load().smoe_rowdot(_ptr(dout), dtype_code(dout.dtype), _ptr(y), dtype_code(y.dtype), _ptr(inv_pos), n, k,
+                                 dout.shape[1], _ptr(out), _stream(dout))
+    _lib.check(rc, "smoe_rowdot")
+    return out
+
+
+def pad_offsets(offsets: torch.Tensor) -> torch.Tensor:
+    _chk(offsets, "offsets", torch.int32, 1)
+    out = torch.empty_like(offsets)
+    rc = _lib.load().smoe_pad_offsets(_ptr(offsets), offsets.numel() - 1, _ptr(out), _stream(offsets))
+    _lib.check(rc, "smoe_pad_offsets")
+    return out
+
+
+def padded_len(n_rows: int, E: int) -> int:
+    """Static upper bound of offsets_pad[E]: every expert range rounded up to 64."""
+    return ((n_rows + 63) // 64) * 64 + 64 * E
+
+
+def transpose_pad(src: torch.Tensor, offsets: torch.Tensor, offsets_pad: torch.Tensor, Lp: int) -> torch.Tensor:
+    """[n, C] expert-sorted rows -> [C, Lp] K-major image with 64-aligned, zero-padded expert ranges."""
+    _chk(src, "src", ndim=2)
+    n, C = src.shape
+    dst = torch.empty((C, Lp), dtype=src.dtype, device=src.device)
+    rc = _lib.load().smoe_transpose_pad(_ptr(src), dtype_code(src.dtype), _ptr(offsets), _ptr(offsets_pad),
+                                        offsets.numel() - 1, n, C, Lp, _ptr(dst), _stream(src))
+    _lib.check(rc, "smoe_transpose_pad")
+    return dst
+
+
+def grouped_wgrad(PT: torch.Tensor, QT: torch.Tensor, offsets_pad: torch.Tensor) -> torch.Tensor:
+    """out[e] = PT[:, range e] @ QT[:, range e]^T, f32 [E, R1, R2]."""
+    _chk(PT, "PT", ndim=2)
+    _chk(QT, "QT", PT.dtype, 2)
+    E = offsets_pad.numel() - 1
+    R1, Lp = PT.shape
+    R2 = QT.shape[0]
+    if QT.shape[1] != Lp:
+        raise RuntimeError("PT / QT: padded lengths differ")
+    out = torch.empty((E, R1, R2), dtype=torch.float32, device=PT.device)
+    with _timed("grouped_wgrad", {"K": Lp}, PT):
+        rc = _lib.load().smoe_grouped_wgrad(_ptr(PT), _ptr(QT), dtype_code(PT.dtype), _ptr(offsets_pad), E, R1, R2, Lp,
+                                            _ptr(out), _stream(PT))
+    _lib.check(rc, "smoe_grouped_wgrad")
+    return out
+
+
+def group_colsum(src: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    _chk(src, "src", ndim=2)
+    E = offsets.numel() - 1
+    out = torch.empty((E, src.shape[1]), dtype=torch.float32, device=src.device)
+    rc = _lib.load().smoe_group_colsum(_ptr(src), dtype_code(src.dtype), _ptr(offsets), E, src.shape[1], _ptr(out),
+                                       _stream(src))
+    _lib.check(rc, "smoe_group_colsum")
+    return out
