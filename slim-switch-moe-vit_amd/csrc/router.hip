@@ -351,6 +351,10 @@ int dispatch_nch(const void* x, const float* wg, const float* bg, const float* n
 
 }  // namespace
 
+int smoe_router16_try(const void* x, int x_dtype, const float* wg, const float* bg, const float* noise, int64_t T,
+                      int d, int E, int k, int gate_kind, int force_f64, int32_t* rc, int32_t* rl, int64_t* idx,
+                      float* score, float* logits_out, float* probs, hipStream_t s);  // router16.hip
+
 // workspace: [16 B: redo counter][T x i32 redo list]
 extern "C" size_t smoe_router_workspace_bytes(int64_t T) { return T < 0 ? 0 : 16 + (((size_t)T * 4 + 15) & ~(size_t)15); }
 
@@ -375,6 +379,11 @@ extern "C" int smoe_router_topk(const void* x, int x_dtype, const float* wg, con
   hipStream_t s = (hipStream_t)stream;
   int32_t* rc = reinterpret_cast<int32_t*>(workspace);
   int32_t* rl = reinterpret_cast<int32_t*>((char*)workspace + 16);
+  {
+    const int r16 = smoe_router16_try(x, x_dtype, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score,
+                                      logits_out, probs, s);
+    if (r16 != -1) return r16;
+  }
   switch (x_dtype) {
     case SMOE_F32: return dispatch_nch<float>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
     case SMOE_F16: return dispatch_nch<f16>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
