@@ -53,6 +53,16 @@ int smoe_router_topk(const void* x, int x_dtype, const float* wg, const float* b
                      int64_t* idx, float* score, float* logits_out, float* probs,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* LayerNorm + router fused (block glue, models/vision_transformer.py:321 `mlp(norm2(x))`): xn = LN(x)*gamma+beta
+ * is written as a 16-bit image (xn16: f16/bf16, may be NULL) and / or f32 (xn32, may be NULL) and routed exactly
+ * as smoe_router_topk routes xn.  Shapes covered: smoe_ln_router_supported(d, E, k) (E <= 8, k <= 4,
+ * d in {192, 384, 768, 1024}); workspace as smoe_router_workspace_bytes(T).                          */
+int smoe_ln_router_supported(int d, int E, int k);
+int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                        void* xn16, int xn16_dtype, float* xn32, const float* wg, const float* bg, const float* noise,
+                        int64_t T, int d, int E, int k, int gate_kind, int64_t* idx, float* score,
+                        float* logits_out, float* probs, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- dispatch plan --------------------------------------------------------------------------------
  * Replaces fmoe_cuda.expert_count + cumsum + assign_pos (+ limit_by_capacity /
  * prune_gate_by_capacity) = fmoe count_by_gate / prepare_forward.
@@ -95,6 +105,8 @@ int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, cons
  * multiplied by row_scale[row_map[r]] if row_scale != NULL  (MOEGather + bmm for k = 1).
  * Optional fused residual (residual != NULL, same dtype / shape as out): the stored value is
  * residual[orow, :] + value -- the `x + mlp(norm2(x))` add of models/vision_transformer.py:321.
+ * Optional fused scatter (a_gather != NULL; variant 4 only): row r of the GEMM reads A[a_gather[r] / a_div, :]
+ * instead of A[r, :] -- MOEScatter's index_select(x, pos // k) folded into the operand DMA (A = the token matrix).
  * SMOE_EPI_GELU_GRAD (backward of the activation, fused into the dgrad GEMM): `residual` then holds the saved
  * pre-activations H and the stored value is value * gelu'(H[r, :]).
  * Optional group -> expert map (group_expert != NULL, i32 [G]): `offsets` then delimits G row groups and
@@ -104,7 +116,8 @@ int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, cons
 int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int32_t* offsets,
                       const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
                       int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,
-                      const void* residual, void* out, int out_dtype, int variant, void* stream);
+                      const void* residual, const int64_t* a_gather, int a_div,
+                      void* out, int out_dtype, int variant, void* stream);
 
 /* ---- backward pieces (fmoe_cuda.linear_backward and the adjoints of scatter / gather) ---------
  * smoe_gelu:            dst = gelu_erf(src), n % 8 == 0 (training forward keeps the pre-activations)

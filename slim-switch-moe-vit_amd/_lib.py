@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: the library resolves libamd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -35,7 +35,12 @@ SIGNATURES = {
     "smoe_gather_combine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                     c_int, c_void_p]),
     "smoe_grouped_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
-                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                  c_void_p]),
+    "smoe_ln_router_supported": (c_int, [c_int, c_int, c_int]),
+    "smoe_ln_router_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
 }
 

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
     const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* __restrict__ residual, OT* __restrict__ out, int n_tiles_n,
-    int group_m, int m_rows) {
+    int group_m, int m_rows, const int64_t* __restrict__ a_gather, int a_div) {
   static_assert(sizeof(AB) == 2, "16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TBM = 256, TBN = 256, NT = 512, NW = 8;
@@ -628,7 +628,9 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     const int r = 8 * (s * NW + wave) + l_row;
     int gr = m0 + r;
     if (gr >= m_end) gr = m_end - 1;
-    a_src[s] = A + (int64_t)gr * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
+    // optional row gather (fused MOEScatter): tile row gr reads source row a_gather[gr] / a_div
+    const int64_t arow = (MODE == 0 && a_gather) ? a_gather[gr] / a_div : (int64_t)gr;
+    a_src[s] = A + arow * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
     int gw = n0 + r;
     if (gw >= N) gw = N - 1;
     w_src[s] = W + ((int64_t)(MODE == 0 ? e : 0) * N + gw) * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
@@ -853,7 +855,8 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
 template <typename AB, typename OT, int ABL = 0>
 int launch_pp256(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                  int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
-                 const void* residual, void* out, int group_m, hipStream_t s) {
+                 const void* residual, void* out, int group_m, hipStream_t s, const int64_t* a_gather = nullptr,
+                 int a_div = 1) {
   constexpr int TBM = 256, TBN = 256;
   const int n_tiles_n = (N + TBN - 1) / TBN;
   const int max_m_tiles = (int)((m_rows_max + TBM - 1) / TBM) + E;
@@ -871,7 +874,7 @@ int launch_pp256(const void* A, const void* W, const float* bias, const int32_t*
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert, E, K, N,
-                     epilogue, row_map, row_scale, (const OT*)residual, (OT*)out, n_tiles_n, group_m, 0);
+                     epilogue, row_map, row_scale, (const OT*)residual, (OT*)out, n_tiles_n, group_m, 0, a_gather, a_div);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
   return 0;
 }
@@ -895,7 +898,7 @@ int launch_wgrad(const void* PT, const void* QT, const int32_t* offsets_pad, int
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)PT, (const AB*)QT, (const float*)nullptr, offsets_pad,
                      (const int32_t*)nullptr, E, Lp, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, out, tn, tm, R1);
+                     (const float*)nullptr, out, tn, tm, R1, (const int64_t*)nullptr, 1);
   SMOE_CHECK_LAUNCH("smoe_grouped_wgrad");
   return 0;
 }
@@ -903,13 +906,14 @@ int launch_wgrad(const void* PT, const void* QT, const int32_t* offsets_pad, int
 template <typename AB, typename OT>
 int launch_variant(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets,
                    const int32_t* group_expert, int E, int64_t m_rows_max, int K, int N, int epilogue,
-                   const int64_t* row_map, const float* row_scale, const void* residual, void* out, hipStream_t s) {
+                   const int64_t* row_map, const float* row_scale, const void* residual, void* out, hipStream_t s,
+                   const int64_t* a_gather, int a_div) {
   if constexpr (sizeof(AB) == 2) {
     switch (variant) {
       case 1: return launch_glds<AB, OT, 128, 128, 2, 2, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 8, s);
       case 2: return launch_glds<AB, OT, 256, 128, 2, 2, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
       case 3: return launch_glds<AB, OT, 256, 256, 2, 4, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
-      case 4: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
+      case 4: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
 #ifdef SMOE_DIAG
       case 41: return launch_pp256<AB, OT, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
       case 42: return launch_pp256<AB, OT, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
@@ -927,11 +931,11 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
 template <typename AB>
 int dispatch_out(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                  int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
-                 const void* residual, void* out, int out_dtype, hipStream_t s) {
+                 const void* residual, void* out, int out_dtype, hipStream_t s, const int64_t* a_gather, int a_div) {
   switch (out_dtype) {
-    case SMOE_F32: return launch_variant<AB, float>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s);
-    case SMOE_F16: return launch_variant<AB, f16>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s);
-    case SMOE_BF16: return launch_variant<AB, bf16_bits>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s);
+    case SMOE_F32: return launch_variant<AB, float>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div);
+    case SMOE_F16: return launch_variant<AB, f16>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div);
+    case SMOE_BF16: return launch_variant<AB, bf16_bits>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div);
   }
   smoe_set_error("smoe_grouped_gemm: bad out_dtype %d", out_dtype);
   return 1;
@@ -941,8 +945,9 @@ int dispatch_out(int variant, const void* A, const void* W, const float* bias, c
 
 extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int32_t* offsets,
                                  const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
-                                 int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale, const void* residual, void* out,
-                                 int out_dtype, int variant, void* stream) {
+                                 int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,
+                                 const void* residual, const int64_t* a_gather, int a_div, void* out, int out_dtype,
+                                 int variant, void* stream) {
   SMOE_REQUIRE(offsets && G >= 1 && G <= 65536, "smoe_grouped_gemm: bad G=%d / offsets", G);
   SMOE_REQUIRE(n_experts >= 1 && (group_expert || n_experts == G), "smoe_grouped_gemm: n_experts=%d != G=%d without a group map", n_experts, G);
   SMOE_REQUIRE(m_rows_max >= 0 && m_rows_max < (1ll << 31), "smoe_grouped_gemm: m_rows_max=%lld out of range",
@@ -959,11 +964,12 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   if (m_rows_max == 0) return 0;
   SMOE_REQUIRE(A && W && out, "smoe_grouped_gemm: null pointer");
   if (K % 64 != 0 || smoe_dtype_size(ab_dtype) != 2) variant = 0;
+  SMOE_REQUIRE(!a_gather || (variant == 4 && a_div >= 1), "smoe_grouped_gemm: a_gather needs variant 4 (16-bit operands, K %% 64 == 0)");
   hipStream_t s = (hipStream_t)stream;
   switch (ab_dtype) {
-    case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s);
-    case SMOE_F16: return dispatch_out<f16>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s);
-    case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s);
+    case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div);
+    case SMOE_F16: return dispatch_out<f16>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div);
+    case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div);
   }
   return 1;
 }

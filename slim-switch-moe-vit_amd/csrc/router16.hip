@@ -8,6 +8,7 @@
 // Same contract as router.hip: f32 logits with a rigorous error bound, tokens whose deciding gaps fall inside the
 // bound go to the redo list and are recomputed with f64 accumulation (MODE 1, same layout).
 #include "smoe_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -35,28 +36,44 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
-template <typename XT, int NJ, int MODE>
+// LN = fused LayerNorm in front of the router (models/vision_transformer.py:321 `mlp(norm2(x))`): the row is
+// normalised in registers (two-pass mean / variance over the 16-lane row, f32), written once as the 16-bit
+// operand image the expert GEMM gathers from (xn16) and optionally as f32 (xn32), and routed on its f32 value.
+// The f64 redo pass recomputes the same normalisation with the same lane layout, hence bit-identical inputs.
+template <typename XT, int NJ, int MODE, bool LN, typename NT>
 __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_kernel(
-    const XT* __restrict__ x, const float* __restrict__ wg, const float* __restrict__ bg,
+    const XT* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
+    NT* __restrict__ xn16, float* __restrict__ xn32, const float* __restrict__ wg, const float* __restrict__ bg,
     const float* __restrict__ noise, int64_t T, int d, int E, int k, int gate_kind,
     int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_list, int64_t* __restrict__ idx_out,
     float* __restrict__ score_out, float* __restrict__ logits_out, float* __restrict__ probs_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds_w = reinterpret_cast<float*>(smem);            // [R16_E][d], rows >= E zero
   float* lds_wn2 = lds_w + R16_E * d;                        // [R16_E]
+  float* lds_g = lds_wn2 + R16_E;                            // [d] LayerNorm weight, then [d] bias (LN only)
+  float* lds_be = lds_g + d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, u = lane & 15;
+  if (MODE == 1 && redo_list && *redo_count == 0) return;  // nothing to redo (the common case): exit before any setup
 
   for (int i = tid * 4; i < R16_E * d; i += R16_THREADS * 4) {
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (i / d < E) v = *reinterpret_cast<const f32x4*>(wg + i);
     *reinterpret_cast<f32x4*>(lds_w + i) = v;
   }
+  if (LN) {
+    for (int i = tid; i < d; i += R16_THREADS) {
+      lds_g[i] = ln_g ? ln_g[i] : 1.f;
+      lds_be[i] = ln_b ? ln_b[i] : 0.f;
+    }
+  }
   __syncthreads();
-  if (tid < R16_E) {
+  for (int e = wave; MODE == 0 && e < R16_E; e += R16_THREADS / 64) {  // squared row norms, one wave per expert row
     float s = 0.f;
-    for (int c = 0; c < d; ++c) s = fmaf(lds_w[tid * d + c], lds_w[tid * d + c], s);
-    lds_wn2[tid] = s;
+    for (int c = lane; c < d; c += 64) s = fmaf(lds_w[e * d + c], lds_w[e * d + c], s);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) lds_wn2[e] = s;
   }
   __syncthreads();
   float wmax2 = 0.f;
@@ -79,6 +96,45 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
       const int c = u + 16 * j;
       if (live && c < nchunk) load4(x + t * (int64_t)d + c * 4, xv[j]);
       else xv[j][0] = xv[j][1] = xv[j][2] = xv[j][3] = 0.f;
+    }
+    if constexpr (LN) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) s1 += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+      const float mean = row16_sum(s1) / (float)d;
+      float s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = u + 16 * j;
+        if (c < nchunk) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const float dv = xv[j][i] - mean; s2 = fmaf(dv, dv, s2); }
+        }
+      }
+      const float rstd = rsqrtf(row16_sum(s2) / (float)d + ln_eps);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = u + 16 * j;
+        if (c < nchunk) {
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(lds_g + c * 4);
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(lds_be + c * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xv[j][i] = fmaf((xv[j][i] - mean) * rstd, gg[i], bb[i]);
+          if (MODE == 0 && live) {
+            if (xn32) *reinterpret_cast<f32x4*>(xn32 + t * (int64_t)d + c * 4) = f32x4{xv[j][0], xv[j][1], xv[j][2], xv[j][3]};
+            if (xn16) {
+              if constexpr (std::is_same<NT, f16>::value) {
+                f16x4 o; o[0] = (f16)xv[j][0]; o[1] = (f16)xv[j][1]; o[2] = (f16)xv[j][2]; o[3] = (f16)xv[j][3];
+                *reinterpret_cast<f16x4*>(xn16 + t * (int64_t)d + c * 4) = o;
+              } else {
+                s16x4 o; o[0] = (short)f32_to_bf16(xv[j][0]); o[1] = (short)f32_to_bf16(xv[j][1]);
+                o[2] = (short)f32_to_bf16(xv[j][2]); o[3] = (short)f32_to_bf16(xv[j][3]);
+                *reinterpret_cast<s16x4*>(xn16 + t * (int64_t)d + c * 4) = o;
+              }
+            }
+          }
+        }
+      }
     }
     float lg[R16_E];
     if constexpr (MODE == 0) {
@@ -207,18 +263,23 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
   }
 }
 
-template <typename XT, int NJ>
-int launch16(const void* x, const float* wg, const float* bg, const float* noise, int64_t T, int d, int E, int k,
-             int gate_kind, int force_f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score, float* logits_out,
-             float* probs, hipStream_t s) {
-  const size_t smem = ((size_t)R16_E * d + R16_E) * 4;
+struct LnArgs {
+  const float* g; const float* b; float eps; void* xn16; int xn16_dtype; float* xn32; bool on;
+};
+
+template <typename XT, int NJ, bool LN, typename NT>
+int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, const float* noise, int64_t T, int d,
+             int E, int k, int gate_kind, int force_f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score,
+             float* logits_out, float* probs, hipStream_t s) {
+  const size_t smem = ((size_t)R16_E * d + R16_E + (LN ? 2 * (size_t)d : 0)) * 4;
   const int64_t tok_per_block = (R16_THREADS / 64) * 4;
   int64_t need = (T + tok_per_block - 1) / tok_per_block;
-  const int grid = (int)(need < 2048 ? (need < 1 ? 1 : need) : 2048);
-#define R16_LAUNCH(MODE, GRID, RC, RL)                                                                              \
-  hipLaunchKernelGGL((router16_kernel<XT, NJ, MODE>), dim3(GRID), dim3(R16_THREADS), smem, s, (const XT*)x, wg, bg, \
-                     noise, T, d, E, k, gate_kind, RC, RL, idx, score, logits_out, probs)
-  if (force_f64) {
+  const int grid = (int)(need < 768 ? (need < 1 ? 1 : need) : 768);  // 3 resident blocks per CU, ~4 row groups each
+#define R16_LAUNCH(MODE, GRID, RC, RL)                                                                               \
+  hipLaunchKernelGGL((router16_kernel<XT, NJ, MODE, LN, NT>), dim3(GRID), dim3(R16_THREADS), smem, s, (const XT*)x,  \
+                     ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, noise, T, d, E, k, gate_kind, RC, RL, idx,   \
+                     score, logits_out, probs)
+  if (force_f64 && !LN) {
     R16_LAUNCH(1, grid, nullptr, nullptr);
     SMOE_CHECK_LAUNCH("smoe_router_topk/f64");
     return 0;
@@ -228,6 +289,13 @@ int launch16(const void* x, const float* wg, const float* bg, const float* noise
     smoe_set_error("smoe_router_topk: memset failed: %s", hipGetErrorString(me));
     return (int)me;
   }
+  if (force_f64 && LN) {  // f64 mode still needs the normalised rows written: run the f32 pass for its stores first
+    R16_LAUNCH(0, grid, rc, rl);
+    SMOE_CHECK_LAUNCH("smoe_router_topk/f32");
+    R16_LAUNCH(1, grid, nullptr, nullptr);
+    SMOE_CHECK_LAUNCH("smoe_router_topk/f64");
+    return 0;
+  }
   R16_LAUNCH(0, grid, rc, rl);
   SMOE_CHECK_LAUNCH("smoe_router_topk/f32");
   R16_LAUNCH(1, (grid < 16 ? grid : 16), rc, rl);
@@ -236,30 +304,78 @@ int launch16(const void* x, const float* wg, const float* bg, const float* noise
   return 0;
 }
 
-template <typename XT>
-int dispatch16(const void* x, const float* wg, const float* bg, const float* noise, int64_t T, int d, int E, int k,
-               int gate_kind, int f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score, float* lo, float* pr,
-               hipStream_t s) {
+template <typename XT, bool LN, typename NT>
+int dispatch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, const float* noise, int64_t T, int d,
+               int E, int k, int gate_kind, int f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score, float* lo,
+               float* pr, hipStream_t s) {
   switch (d) {
-    case 192: return launch16<XT, 3>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
-    case 384: return launch16<XT, 6>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
-    case 768: return launch16<XT, 12>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
-    case 1024: return launch16<XT, 16>(x, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+    case 192: return launch16<XT, 3, LN, NT>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+    case 384: return launch16<XT, 6, LN, NT>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+    case 768: return launch16<XT, 12, LN, NT>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+    case 1024: return launch16<XT, 16, LN, NT>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
   }
   return -1;
 }
 
+template <typename XT>
+int dispatch16_ln(const void* x, const LnArgs& ln, const float* wg, const float* bg, const float* noise, int64_t T,
+                  int d, int E, int k, int gate_kind, int f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score,
+                  float* lo, float* pr, hipStream_t s) {
+  if (!ln.on) return dispatch16<XT, false, f16>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+  if (ln.xn16_dtype == SMOE_BF16)
+    return dispatch16<XT, true, bf16_bits>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+  return dispatch16<XT, true, f16>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+}
+
 }  // namespace
+
+static bool shape_ok16(int d, int E, int k) {
+  return E <= R16_E && k <= R16_MAX_K && (d == 192 || d == 384 || d == 768 || d == 1024);
+}
 
 // returns -1 when the shape is not covered by this fast path (caller falls back to router.hip)
 int smoe_router16_try(const void* x, int x_dtype, const float* wg, const float* bg, const float* noise, int64_t T,
                       int d, int E, int k, int gate_kind, int force_f64, int32_t* rc, int32_t* rl, int64_t* idx,
                       float* score, float* logits_out, float* probs, hipStream_t s) {
-  if (E > R16_E || k > R16_MAX_K || !(d == 192 || d == 384 || d == 768 || d == 1024)) return -1;
+  if (!shape_ok16(d, E, k)) return -1;
+  LnArgs ln{nullptr, nullptr, 0.f, nullptr, SMOE_F16, nullptr, false};
   switch (x_dtype) {
-    case SMOE_F32: return dispatch16<float>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
-    case SMOE_F16: return dispatch16<f16>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
-    case SMOE_BF16: return dispatch16<bf16_bits>(x, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
+    case SMOE_F32: return dispatch16_ln<float>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
+    case SMOE_F16: return dispatch16_ln<f16>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
+    case SMOE_BF16: return dispatch16_ln<bf16_bits>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
   }
   return -1;
+}
+
+extern "C" int smoe_ln_router_supported(int d, int E, int k) { return shape_ok16(d, E, k) ? 1 : 0; }
+
+// LayerNorm + router in one pass over x (block glue fusion): xn = LN(x) * gamma + beta is
+// written as the 16-bit operand image (xn16, f16 or bf16; may be NULL) and / or as f32 (xn32; may be NULL) and
+// routed exactly like smoe_router_topk routes xn.  Shapes: smoe_ln_router_supported(d, E, k).
+extern "C" int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                   void* xn16, int xn16_dtype, float* xn32, const float* wg, const float* bg,
+                                   const float* noise, int64_t T, int d, int E, int k, int gate_kind, int64_t* idx,
+                                   float* score, float* logits_out, float* probs, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  const int force_f64 = (gate_kind & 0x100) ? 1 : 0;
+  gate_kind &= 0xff;
+  SMOE_REQUIRE(x && wg && idx && score, "smoe_ln_router_topk: null pointer");
+  SMOE_REQUIRE(shape_ok16(d, E, k), "smoe_ln_router_topk: unsupported shape d=%d E=%d k=%d", d, E, k);
+  SMOE_REQUIRE(T >= 0 && T < (1ll << 31), "smoe_ln_router_topk: bad T");
+  SMOE_REQUIRE(k >= 1 && k <= E, "smoe_ln_router_topk: bad k");
+  SMOE_REQUIRE(gate_kind == SMOE_GATE_NAIVE || (gate_kind == SMOE_GATE_SWITCH && k == 1), "smoe_ln_router_topk: bad gate");
+  SMOE_REQUIRE(xn16_dtype == SMOE_F16 || xn16_dtype == SMOE_BF16, "smoe_ln_router_topk: xn16 must be f16 or bf16");
+  SMOE_REQUIRE(workspace && workspace_bytes >= 16 + (((size_t)T * 4 + 15) & ~(size_t)15), "smoe_ln_router_topk: workspace too small");
+  if (T == 0) return 0;
+  int32_t* rc = reinterpret_cast<int32_t*>(workspace);
+  int32_t* rl = reinterpret_cast<int32_t*>((char*)workspace + 16);
+  LnArgs ln{ln_gamma, ln_beta, ln_eps, xn16, xn16_dtype, xn32, true};
+  hipStream_t s = (hipStream_t)stream;
+  switch (x_dtype) {
+    case SMOE_F32: return dispatch16_ln<float>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
+    case SMOE_F16: return dispatch16_ln<f16>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
+    case SMOE_BF16: return dispatch16_ln<bf16_bits>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
+  }
+  smoe_set_error("smoe_ln_router_topk: bad x_dtype %d", x_dtype);
+  return 1;
 }

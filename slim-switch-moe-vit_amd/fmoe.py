@@ -198,6 +198,56 @@ class FMoETransformerMLP(nn.Module):
             return residual + self.forward(inp)
         return self._forward_infer(inp, residual=residual)
 
+    def forward_norm_add(self, x: torch.Tensor, norm: nn.Module) -> torch.Tensor:
+        """``x + self(norm(x))`` -- the whole MoE half of a ViT block (models/vision_transformer.py:321) -- with the
+        block glue fused: LayerNorm + router in one pass over x (smoe_ln_router_topk), the token scatter folded into
+        GEMM-1's operand DMA (a_gather) and the combine + residual add folded into GEMM-2's store.  Falls back to
+        the unfused composition whenever a precondition does not hold; results agree to rounding."""
+        cd = self.compute_dtype or default_compute_dtype()
+        g = self.gate
+        ok = (x.is_cuda and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine
+              and tuple(norm.normalized_shape) == (self.d_model,) and self._fused_gelu
+              and not (self._drop_p > 0 and self.training) and self.world_size == 1
+              and not getattr(self, "force_ep", False) and cd in (torch.float16, torch.bfloat16)
+              and self.gemm_variant == 4 and self.d_model % 64 == 0
+              and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())
+                                                    or any(p.requires_grad for p in norm.parameters())))
+              and ops.ln_router_supported(self.d_model, g.tot_expert, g.top_k))
+        if not ok:
+            return self.forward_add(norm(x), x)
+        shape = x.shape
+        d, k = self.d_model, self.top_k
+        x2 = x.reshape(-1, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T = x2.shape[0]
+        is_switch = isinstance(g, SwitchGate)
+        noise = g.make_noise(T, x2.device) if is_switch else None
+        gw = g.gate.weight.detach().float().contiguous()
+        gb = g.gate.bias.detach().float() if g.gate.bias is not None else None
+        xn16, _, idx, score, _, probs = ops.ln_router_topk(
+            x2, norm.weight.detach().float(), norm.bias.detach().float() if norm.bias is not None else None, norm.eps,
+            gw, gb, k, g.kind, noise, xn16_dtype=cd, want_probs=is_switch)
+        cap = g.capacity(T)
+        counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, g.tot_expert, cap)
+        self.last_plan = (idx, score, counts, offsets, pos, inv_pos)
+        if is_switch:
+            from .autograd import switch_aux_loss
+            g.set_loss(switch_aux_loss(pruned if pruned is not None else idx, probs, g.tot_expert))
+        ex = self.experts
+        w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
+        b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
+        b2 = ex.h4toh.bias.detach().float() if ex.h4toh.bias is not None else None
+        h = ops.grouped_gemm(xn16, w1, b1, offsets, ops.EPI_GELU, cd, variant=4, a_gather=pos, a_div=k)
+        if k == 1:
+            out = x2.clone() if cap >= 0 else torch.empty_like(x2)
+            ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, x2.dtype, row_map=pos, row_scale=score.reshape(-1),
+                             out=out, variant=4, residual=x2)
+        else:
+            y = ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, cd, variant=4)
+            out = ops.gather_combine(y, inv_pos, score, T, k, x2.dtype, residual=x2)
+        return out.reshape(shape)
+
     def forward(self, inp: torch.Tensor) -> torch.Tensor:
         if not inp.is_cuda:
             raise RuntimeError("FMoETransformerMLP: input must be on the GPU; this build has no CPU path "

@@ -116,6 +116,42 @@ def router_topk(x: torch.Tensor, wg: torch.Tensor, bg: Optional[torch.Tensor], k
     return idx, score, logits, probs
 
 
+def ln_router_supported(d: int, E: int, k: int) -> bool:
+    return bool(_lib.load().smoe_ln_router_supported(d, E, k))
+
+
+def ln_router_topk(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], eps: float,
+                   wg: torch.Tensor, bg: Optional[torch.Tensor], k: int, gate_kind: int = GATE_NAIVE,
+                   noise: Optional[torch.Tensor] = None, xn16_dtype: Optional[torch.dtype] = torch.float16,
+                   want_xn32: bool = False, want_probs: bool = False, want_logits: bool = False, force_f64: bool = False):
+    """LayerNorm + router in one pass: (xn16 | None, xn32 | None, idx, score, logits | None, probs | None)."""
+    _chk(x, "x", ndim=2)
+    _chk(wg, "wg", torch.float32, 2)
+    T, d = x.shape
+    E = wg.shape[0]
+    for t, nm in ((ln_weight, "ln_weight"), (ln_bias, "ln_bias"), (bg, "bg")):
+        if t is not None:
+            _chk(t, nm, torch.float32, 1)
+    dev = x.device
+    xn16 = torch.empty((T, d), dtype=xn16_dtype, device=dev) if xn16_dtype is not None else None
+    xn32 = torch.empty((T, d), dtype=torch.float32, device=dev) if want_xn32 else None
+    idx = torch.empty((T, k), dtype=torch.int64, device=dev)
+    score = torch.empty((T, k), dtype=torch.float32, device=dev)
+    logits = torch.empty((T, E), dtype=torch.float32, device=dev) if want_logits else None
+    probs = torch.empty((T, E), dtype=torch.float32, device=dev) if want_probs else None
+    lib = _lib.load()
+    ws_bytes = lib.smoe_router_workspace_bytes(T)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    nbytes = T * d * (x.element_size() + (2 if xn16 is not None else 0) + (4 if want_xn32 else 0))
+    with _timed("ln_router", {"bytes": nbytes}, x):
+        rc = lib.smoe_ln_router_topk(_ptr(x), dtype_code(x.dtype), _ptr(ln_weight), _ptr(ln_bias), float(eps), _ptr(xn16),
+                                     dtype_code(xn16_dtype) if xn16_dtype is not None else F16, _ptr(xn32), _ptr(wg),
+                                     _ptr(bg), _ptr(noise), T, d, E, k, gate_kind | (0x100 if force_f64 else 0),
+                                     _ptr(idx), _ptr(score), _ptr(logits), _ptr(probs), _ptr(ws), ws_bytes, _stream(x))
+    _lib.check(rc, "smoe_ln_router_topk")
+    return xn16, xn32, idx, score, logits, probs
+
+
 def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Optional[bool] = None):
     """(counts i32 [E], offsets i32 [E+1], pos i64 [n], inv_pos i64 [n], idx_pruned i64 [n] | None)."""
     _chk(idx, "idx", torch.int64, align=8)  # read element-wise: slices of a [T,k] tensor are fine
@@ -195,13 +231,17 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
                  row_map: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
                  out: Optional[torch.Tensor] = None, variant: int = 0,
                  group_expert: Optional[torch.Tensor] = None, rows_hint: Optional[int] = None,
-                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 residual: Optional[torch.Tensor] = None, a_gather: Optional[torch.Tensor] = None,
+                 a_div: int = 1) -> torch.Tensor:
     """out[r] = epi(A[r] @ W[e]^T + bias[e]) for r in [offsets[g], offsets[g+1]), e = group_expert[g] (or g).
     W [E,N,K].  ``rows_hint`` = number of rows actually routed (for the profiler's FLOP count only)."""
     _chk(A, "A", ndim=2)
     _chk(W, "W", A.dtype, 3)
     _chk(offsets, "offsets", torch.int32, 1)
     M, K = A.shape
+    if a_gather is not None:  # A is the un-permuted token matrix; the GEMM has one row per routed slot
+        _chk(a_gather, "a_gather", torch.int64, 1, align=8)
+        M = a_gather.numel()
     E, N, K2 = W.shape
     if K2 != K:
         raise RuntimeError(f"W: expected [E,N,{K}], got {tuple(W.shape)}")
@@ -240,7 +280,7 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     with _timed("grouped_gemm", {"flops": 2.0 * rows * K * N, "K": K, "N": N, "epilogue": epilogue}, A):
         rc = lib.smoe_grouped_gemm(_ptr(A), _ptr(W), _ptr(bias), _ptr(offsets), _ptr(group_expert), G, E, M, K, N,
                                    dtype_code(A.dtype), epilogue, _ptr(row_map), _ptr(row_scale), _ptr(residual),
-                                   _ptr(out), dtype_code(out_dtype), variant, _stream(A))
+                                   _ptr(a_gather), a_div, _ptr(out), dtype_code(out_dtype), variant, _stream(A))
     _lib.check(rc, "smoe_grouped_gemm")
     return out
 

@@ -66,7 +66,13 @@ class PatchEmbed(nn.Module):
 
     def forward(self, x):
         assert tuple(x.shape[-2:]) == self.img_size, f"input {tuple(x.shape[-2:])} != model {self.img_size}"
-        return self.proj(x).flatten(2).transpose(1, 2)
+        # Conv2d with kernel == stride is a per-patch linear map: same result as self.proj(x).flatten(2).transpose(1, 2),
+        # written as one GEMM (no MIOpen algorithm search on first use)
+        B, C, H, W = x.shape
+        ph, pw = self.patch_size
+        gh, gw = self.grid_size
+        patches = x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
+        return F.linear(patches, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
 
 
 class Mlp(nn.Module):
@@ -117,9 +123,13 @@ class Block(nn.Module):
 
     def forward(self, x):
         x = x + self.drop_path(self.attn(self.norm1(x)))
-        fused = getattr(self.mlp, "forward_add", None)
-        if fused is not None and isinstance(self.drop_path, nn.Identity):
-            return fused(self.norm2(x), x)  # x + mlp(norm2(x)), add fused into the MoE combine store
+        if isinstance(self.drop_path, nn.Identity):
+            fused2 = getattr(self.mlp, "forward_norm_add", None)
+            if fused2 is not None:
+                return fused2(x, self.norm2)  # x + mlp(norm2(x)): LN + router, scatter, combine + add all fused
+            fused = getattr(self.mlp, "forward_add", None)
+            if fused is not None:
+                return fused(self.norm2(x), x)  # x + mlp(norm2(x)), add fused into the MoE combine store
         x = x + self.drop_path(self.mlp(self.norm2(x)))
         return x
 

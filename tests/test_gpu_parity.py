@@ -271,6 +271,43 @@ def test_forward_add_equals_residual_plus_forward(k, gate, cap):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("d,h,E,k,gate", [(192, 768, 4, 1, "naive"), (768, 3072, 8, 1, "naive"), (384, 768, 8, 2, "naive"),
+                                          (1024, 1024, 5, 1, "switch")])
+def test_fused_layernorm_router_and_block_half(d, h, E, k, gate):
+    """smoe_ln_router_topk + a_gather GEMM-1 + fused combine/residual == x + mlp(LayerNorm(x)):
+    (a) the fused LayerNorm matches F.layer_norm, (b) routing equals the oracle's on the very same normalised rows,
+    (c) the fused block half is bit-identical to the unfused kernels fed with those rows."""
+    T = 3000
+    g = _gen(d + E)
+    x = torch.randn(T, d, generator=g) * 1.7 + 0.3
+    ln = torch.nn.LayerNorm(d, eps=1e-6)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(d, generator=g)); ln.bias.copy_(0.1 * torch.randn(d, generator=g))
+    _, wg, bg, w1, b1, w2, b2 = _mk(T, d, h, E, seed=3)
+    wg = wg * 5
+    mod = sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=k, gate=gate,
+                                capacity_factor=1.0 if gate == "switch" else None)
+    mod = _load_module(mod, wg, bg, w1, b1, w2, b2)
+    ln = ln.to(DEV)
+    xg = x.to(DEV)
+    with torch.no_grad():
+        xn16, xn32, idx, score, _, _ = ops.ln_router_topk(xg, ln.weight, ln.bias, ln.eps, wg.to(DEV), bg.to(DEV), k,
+                                                          mod.gate.kind, want_xn32=True)
+        ref_ln = torch.nn.functional.layer_norm(x, (d,), ln.weight.cpu(), ln.bias.cpu(), 1e-6)
+        assert (xn32.cpu() - ref_ln).abs().max().item() < 1e-5
+        assert torch.equal(xn16, xn32.half())
+        if gate == "naive":
+            o_idx, o_score, _ = mo.naive_gate(xn32.cpu(), wg, bg, k)
+        else:
+            o_idx, o_score, _ = mo.switch_gate(xn32.cpu(), wg, bg)
+        assert torch.equal(idx.cpu(), o_idx)
+        assert torch.allclose(score.cpu(), o_score, atol=5e-6)
+        fused = mod.forward_norm_add(xg, ln)
+        unfused = mod.forward_add(xn32, xg)
+        assert torch.equal(mod.last_plan[0], idx)
+        assert torch.equal(fused, unfused)
+
+
 def test_moe_module_e1_equals_reference_mlp_golden(golden_dir):
     """E = 1: the HIP path reproduces the REFERENCE's own dense Mlp (models/layers.py:391-414) outputs."""
     g = np.load(os.path.join(golden_dir, "ref_mlp_tiny.npz"))
