@@ -63,6 +63,11 @@ int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_gamma, const
                         int64_t T, int d, int E, int k, int gate_kind, int64_t* idx, float* score,
                         float* logits_out, float* probs, void* workspace, size_t workspace_bytes, void* stream);
 
+/* LayerNorm alone (same arithmetic as the fused form; the `norm1` of models/vision_transformer.py:320 feeding the
+ * attention GEMMs in 16 bit): d in {192, 384, 768, 1024}.                                              */
+int smoe_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, float eps, int64_t T, int d,
+                   void* out, int out_dtype, void* stream);
+
 /* ---- dispatch plan --------------------------------------------------------------------------------
  * Replaces fmoe_cuda.expert_count + cumsum + assign_pos (+ limit_by_capacity /
  * prune_gate_by_capacity) = fmoe count_by_gate / prepare_forward.

@@ -263,6 +263,87 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
   }
 }
 
+// LayerNorm alone, same 16-lanes-per-token layout and arithmetic as the fused router (block glue for the
+// attention half of the block: `attn(norm1(x))`, models/vision_transformer.py:320): one pass, 16-bit or f32 output.
+template <typename XT, int NJ, typename OT>
+__global__ __launch_bounds__(R16_THREADS, 4) void layernorm16_kernel(const XT* __restrict__ x, const float* __restrict__ g,
+                                                                     const float* __restrict__ b, float eps, int64_t T,
+                                                                     int d, OT* __restrict__ out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, u = lane & 15;
+  const int nchunk = d >> 2;
+  const int64_t slot_gid = ((int64_t)blockIdx.x * (R16_THREADS / 64) + wave) * 4 + q;
+  const int64_t slot_stride = (int64_t)gridDim.x * (R16_THREADS / 64) * 4;
+  f32x4 gg[NJ], bb[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = u + 16 * j;
+    gg[j] = (g && c < nchunk) ? *reinterpret_cast<const f32x4*>(g + c * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bb[j] = (b && c < nchunk) ? *reinterpret_cast<const f32x4*>(b + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t it0 = slot_gid - q; it0 < T; it0 += slot_stride) {
+    const int64_t t = it0 + q;
+    const bool live = t < T;
+    float xv[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = u + 16 * j;
+      if (live && c < nchunk) load4(x + t * (int64_t)d + c * 4, xv[j]);
+      else xv[j][0] = xv[j][1] = xv[j][2] = xv[j][3] = 0.f;
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s1 += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+    const float mean = row16_sum(s1) / (float)d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = u + 16 * j;
+      if (c < nchunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float dv = xv[j][i] - mean; s2 = fmaf(dv, dv, s2); }
+      }
+    }
+    const float rstd = rsqrtf(row16_sum(s2) / (float)d + eps);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = u + 16 * j;
+      if (live && c < nchunk) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = fmaf((xv[j][i] - mean) * rstd, gg[j][i], bb[j][i]);
+        OT* dst = out + t * (int64_t)d + c * 4;
+        if constexpr (std::is_same<OT, float>::value) {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+        } else if constexpr (std::is_same<OT, f16>::value) {
+          f16x4 v; v[0] = (f16)o[0]; v[1] = (f16)o[1]; v[2] = (f16)o[2]; v[3] = (f16)o[3];
+          *reinterpret_cast<f16x4*>(dst) = v;
+        } else {
+          s16x4 v; v[0] = (short)f32_to_bf16(o[0]); v[1] = (short)f32_to_bf16(o[1]); v[2] = (short)f32_to_bf16(o[2]); v[3] = (short)f32_to_bf16(o[3]);
+          *reinterpret_cast<s16x4*>(dst) = v;
+        }
+      }
+    }
+  }
+}
+
+template <typename XT, typename OT>
+int ln_dispatch_nj(const void* x, const float* g, const float* b, float eps, int64_t T, int d, void* out, hipStream_t s) {
+  int64_t need = (T + 15) / 16;
+  const int grid = (int)(need < 2048 ? (need < 1 ? 1 : need) : 2048);
+#define LN_LAUNCH(NJ) hipLaunchKernelGGL((layernorm16_kernel<XT, NJ, OT>), dim3(grid), dim3(R16_THREADS), 0, s, (const XT*)x, g, b, eps, T, d, (OT*)out)
+  switch (d) {
+    case 192: LN_LAUNCH(3); break;
+    case 384: LN_LAUNCH(6); break;
+    case 768: LN_LAUNCH(12); break;
+    case 1024: LN_LAUNCH(16); break;
+    default: smoe_set_error("smoe_layernorm: unsupported d=%d", d); return 1;
+  }
+#undef LN_LAUNCH
+  SMOE_CHECK_LAUNCH("smoe_layernorm");
+  return 0;
+}
+
 struct LnArgs {
   const float* g; const float* b; float eps; void* xn16; int xn16_dtype; float* xn32; bool on;
 };
@@ -377,5 +458,28 @@ extern "C" int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_g
     case SMOE_BF16: return dispatch16_ln<bf16_bits>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);
   }
   smoe_set_error("smoe_ln_router_topk: bad x_dtype %d", x_dtype);
+  return 1;
+}
+
+// LayerNorm over the last dimension, d in {192, 384, 768, 1024}; out dtype f32 / f16 / bf16.
+extern "C" int smoe_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, float eps, int64_t T,
+                              int d, void* out, int out_dtype, void* stream) {
+  SMOE_REQUIRE(T >= 0 && (d == 192 || d == 384 || d == 768 || d == 1024), "smoe_layernorm: unsupported shape T=%lld d=%d", (long long)T, d);
+  if (T == 0) return 0;
+  SMOE_REQUIRE(x && out, "smoe_layernorm: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+#define LN_OUT(XT)                                                                                   \
+  switch (out_dtype) {                                                                               \
+    case SMOE_F32: return ln_dispatch_nj<XT, float>(x, gamma, beta, eps, T, d, out, s);             \
+    case SMOE_F16: return ln_dispatch_nj<XT, f16>(x, gamma, beta, eps, T, d, out, s);               \
+    case SMOE_BF16: return ln_dispatch_nj<XT, bf16_bits>(x, gamma, beta, eps, T, d, out, s);        \
+  }
+  switch (x_dtype) {
+    case SMOE_F32: LN_OUT(float) break;
+    case SMOE_F16: LN_OUT(f16) break;
+    case SMOE_BF16: LN_OUT(bf16_bits) break;
+  }
+#undef LN_OUT
+  smoe_set_error("smoe_layernorm: bad dtype");
   return 1;
 }

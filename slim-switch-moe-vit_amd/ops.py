@@ -116,6 +116,23 @@ def router_topk(x: torch.Tensor, wg: torch.Tensor, bg: Optional[torch.Tensor], k
     return idx, score, logits, probs
 
 
+LN_DIMS = (192, 384, 768, 1024)
+
+
+def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float,
+              out_dtype: torch.dtype) -> torch.Tensor:
+    """LayerNorm over the last dim (d in LN_DIMS) with the output cast fused."""
+    _chk(x, "x")
+    d = x.shape[-1]
+    T = x.numel() // d
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    with _timed("layernorm", {"bytes": T * d * (x.element_size() + out.element_size())}, x):
+        rc = _lib.load().smoe_layernorm(_ptr(x), dtype_code(x.dtype), _ptr(weight), _ptr(bias), float(eps), T, d,
+                                        _ptr(out), dtype_code(out_dtype), _stream(x))
+    _lib.check(rc, "smoe_layernorm")
+    return out
+
+
 def ln_router_supported(d: int, E: int, k: int) -> bool:
     return bool(_lib.load().smoe_ln_router_supported(d, E, k))
 

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 _MODEL_REGISTRY: Dict[str, Callable] = {}
+_LN_DIMS = (192, 384, 768, 1024)
 
 
 def register_model(fn: Callable) -> Callable:
@@ -89,6 +90,27 @@ class Mlp(nn.Module):
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
+def _autocast_half_inference(x: torch.Tensor) -> bool:
+    return (x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled()
+            and torch.get_autocast_gpu_dtype() == torch.float16)
+
+
+class _HalfCache:
+    """fp16 shadow of a parameter (what autocast would re-create on every forward), refreshed on change."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, p: torch.Tensor) -> torch.Tensor:
+        key = id(p)
+        ver = (p._version, p.data_ptr())
+        hit = self._c.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, p.detach().half())
+            self._c[key] = hit
+        return hit[1]
+
+
 class Attention(nn.Module):
     """models/vision_transformer.py:248-280 (softmax(q k^T * scale) v, then proj)."""
 
@@ -103,6 +125,13 @@ class Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
+        if x.dtype == torch.float16 and _autocast_half_inference(x):
+            # same arithmetic as autocast (fp16 GEMM operands), without re-casting the weights on every call
+            hc = self.__dict__.setdefault("_half", _HalfCache())
+            qkv = F.linear(x, hc.get(self.qkv.weight), hc.get(self.qkv.bias) if self.qkv.bias is not None else None)
+            q, k, v = qkv.reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+            o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
+            return F.linear(o.transpose(1, 2).reshape(B, N, C), hc.get(self.proj.weight), hc.get(self.proj.bias))
         q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
         p = self.attn_drop.p if self.training else 0.0
         x = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
@@ -121,8 +150,19 @@ class Block(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
+    def _norm1(self, x):
+        """norm1 for the attention half; under fp16-autocast inference the LayerNorm writes fp16 directly (the cast
+        autocast would insert in front of the qkv GEMM), through the same HIP LayerNorm the MoE half uses."""
+        n = self.norm1
+        if (isinstance(n, nn.LayerNorm) and n.elementwise_affine and x.shape[-1] in _LN_DIMS and x.is_contiguous()
+                and x.dtype == torch.float32 and _autocast_half_inference(x)):
+            from . import ops
+            return ops.layernorm(x, n.weight.detach(), n.bias.detach() if n.bias is not None else None, n.eps,
+                                 torch.float16)
+        return n(x)
+
     def forward(self, x):
-        x = x + self.drop_path(self.attn(self.norm1(x)))
+        x = x + self.drop_path(self.attn(self._norm1(x)))
         if isinstance(self.drop_path, nn.Identity):
             fused2 = getattr(self.mlp, "forward_norm_add", None)
             if fused2 is not None:

@@ -308,6 +308,23 @@ def test_fused_layernorm_router_and_block_half(d, h, E, k, gate):
         assert torch.equal(fused, unfused)
 
 
+@pytest.mark.parametrize("d", [192, 384, 768, 1024])
+@pytest.mark.parametrize("odt", [torch.float32, torch.float16])
+def test_layernorm_kernel_matches_reference_layernorm(d, odt, golden_dir):
+    g = _gen(d)
+    x = torch.randn(777, d, generator=g) * 3 + 1
+    w, b = 1 + 0.3 * torch.randn(d, generator=g), 0.2 * torch.randn(d, generator=g)
+    got = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, odt).cpu()
+    ref = torch.nn.functional.layer_norm(x.double(), (d,), w.double(), b.double(), 1e-6)
+    tol = 2e-6 if odt == torch.float32 else 2e-3
+    assert (got.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    if d == 192:  # the reference's own manual LayerNorm outputs (models/layers.py:160-224)
+        gd = np.load(os.path.join(golden_dir, "ref_layernorm_tiny.npz"))
+        y = ops.layernorm(torch.from_numpy(gd["x"]).to(DEV), torch.from_numpy(gd["w"]).to(DEV),
+                          torch.from_numpy(gd["b"]).to(DEV), 1e-6, torch.float32).cpu()
+        assert (y - torch.from_numpy(gd["y"])).abs().max().item() < 1e-5
+
+
 def test_moe_module_e1_equals_reference_mlp_golden(golden_dir):
     """E = 1: the HIP path reproduces the REFERENCE's own dense Mlp (models/layers.py:391-414) outputs."""
     g = np.load(os.path.join(golden_dir, "ref_mlp_tiny.npz"))
