@@ -780,6 +780,12 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   constexpr int ROWS_PER_IT = NT / TPR;   // 32
   constexpr int ITS = RP / ROWS_PER_IT;
   static_assert(CHUNKS % TPR == 0 && RP % ROWS_PER_IT == 0, "epilogue thread map");
+  // A pass stages RP tile rows: RP/2 from each wave group (wr = 0 / 1), i.e. MPP row fragments of EVERY wave, so all
+  // eight waves share the bias / GELU / convert work of every pass (a pass made of consecutive tile rows would
+  // leave one wave group idle).  LDS row r <-> tile row (r / HALF) * 128 + p * HALF + r % HALF.
+  constexpr int HALF = RP / 2;
+  constexpr int MPP = HALF / 16;
+  static_assert(HALF % 16 == 0 && MPP * NPASS == MI, "epilogue pass split");
   const float* bias_e = bias ? bias + (int64_t)e * N : nullptr;
   f32x4 bv[NI];
 #pragma unroll
@@ -797,7 +803,8 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     u32x4 resv[ITS][CPT];
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
-      const int m = m0 + p * RP + trow + it * ROWS_PER_IT;
+      const int r = trow + it * ROWS_PER_IT;
+      const int m = m0 + (r / HALF) * TM + p * HALF + (r % HALF);
       orow[it] = -1;
       oscale[it] = 1.f;
       if (m < m_end) {
@@ -813,24 +820,22 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
                                                         (orow[it] * (int64_t)N + ncol) * OB);
       }
     }
-    // (2) bias (+GELU), convert, stage this pass's rows in LDS
+    // (2) bias (+GELU), convert, stage this pass's fragments in LDS
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int row = wr * TM + mi * 16;  // wave-uniform
-      if (row / RP == p) {
+    for (int mm = 0; mm < MPP; ++mm) {
+      const int mi = p * MPP + mm;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          f32x4 v = acc[mi][ni] + bv[ni];
-          if (epilogue == SMOE_EPI_GELU) {
-            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-          }
-          const int nl = wc * TN + ni * 16 + fq * 4;
-          OutPack<OT>::write4(smem + (row - p * RP + fr) * C_STRIDE + nl * OB, v);
+      for (int ni = 0; ni < NI; ++ni) {
+        f32x4 v = acc[mi][ni] + bv[ni];
+        if (epilogue == SMOE_EPI_GELU) {
+          v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
         }
+        const int nl = wc * TN + ni * 16 + fq * 4;
+        OutPack<OT>::write4(smem + (wr * HALF + mm * 16 + fr) * C_STRIDE + nl * OB, v);
       }
     }
     __syncthreads();
-    // (3) whole-row-segment stores (combine scale and residual fused)
+    // (3) whole-row-segment stores (combine scale and residual / gelu' fused)
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
       if (orow[it] >= 0) {

@@ -274,13 +274,6 @@ __global__ __launch_bounds__(R16_THREADS, 4) void layernorm16_kernel(const XT* _
   const int nchunk = d >> 2;
   const int64_t slot_gid = ((int64_t)blockIdx.x * (R16_THREADS / 64) + wave) * 4 + q;
   const int64_t slot_stride = (int64_t)gridDim.x * (R16_THREADS / 64) * 4;
-  f32x4 gg[NJ], bb[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int c = u + 16 * j;
-    gg[j] = (g && c < nchunk) ? *reinterpret_cast<const f32x4*>(g + c * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
-    bb[j] = (b && c < nchunk) ? *reinterpret_cast<const f32x4*>(b + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
   for (int64_t it0 = slot_gid - q; it0 < T; it0 += slot_stride) {
     const int64_t t = it0 + q;
     const bool live = t < T;
@@ -309,9 +302,13 @@ __global__ __launch_bounds__(R16_THREADS, 4) void layernorm16_kernel(const XT* _
     for (int j = 0; j < NJ; ++j) {
       const int c = u + 16 * j;
       if (live && c < nchunk) {
+        // gamma / beta come from L1/L2 at use (6 KB, shared by every wave): holding them in registers would cost
+        // 96 VGPRs and spill
+        const f32x4 gg = g ? *reinterpret_cast<const f32x4*>(g + c * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 bb = b ? *reinterpret_cast<const f32x4*>(b + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         float o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = fmaf((xv[j][i] - mean) * rstd, gg[j][i], bb[j][i]);
+        for (int i = 0; i < 4; ++i) o[i] = fmaf((xv[j][i] - mean) * rstd, gg[i], bb[i]);
         OT* dst = out + t * (int64_t)d + c * 4;
         if constexpr (std::is_same<OT, float>::value) {
           *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
@@ -329,8 +326,10 @@ __global__ __launch_bounds__(R16_THREADS, 4) void layernorm16_kernel(const XT* _
 
 template <typename XT, typename OT>
 int ln_dispatch_nj(const void* x, const float* g, const float* b, float eps, int64_t T, int d, void* out, hipStream_t s) {
+  // one 16-token group per workgroup (no loop): the dispatcher back-fills CUs as groups retire, so there is no
+  // 1-vs-2-iteration imbalance between resident workgroups
   int64_t need = (T + 15) / 16;
-  const int grid = (int)(need < 2048 ? (need < 1 ? 1 : need) : 2048);
+  const int grid = (int)(need < 1 ? 1 : (need > (1 << 20) ? (1 << 20) : need));
 #define LN_LAUNCH(NJ) hipLaunchKernelGGL((layernorm16_kernel<XT, NJ, OT>), dim3(grid), dim3(R16_THREADS), 0, s, (const XT*)x, g, b, eps, T, d, (OT*)out)
   switch (d) {
     case 192: LN_LAUNCH(3); break;
@@ -355,7 +354,10 @@ int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, 
   const size_t smem = ((size_t)R16_E * d + R16_E + (LN ? 2 * (size_t)d : 0)) * 4;
   const int64_t tok_per_block = (R16_THREADS / 64) * 4;
   int64_t need = (T + tok_per_block - 1) / tok_per_block;
-  const int grid = (int)(need < 768 ? (need < 1 ? 1 : need) : 768);  // 3 resident blocks per CU, ~4 row groups each
+  // <= 768 workgroups (3 resident per CU, the LDS weight image is loaded once per workgroup), every workgroup
+  // the same number of 16-token groups
+  const int64_t iters = (need + 767) / 768;
+  const int grid = (int)(need < 1 ? 1 : (need + iters - 1) / (iters < 1 ? 1 : iters));
 #define R16_LAUNCH(MODE, GRID, RC, RL)                                                                               \
   hipLaunchKernelGGL((router16_kernel<XT, NJ, MODE, LN, NT>), dim3(GRID), dim3(R16_THREADS), smem, s, (const XT*)x,  \
                      ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, noise, T, d, E, k, gate_kind, RC, RL, idx,   \
