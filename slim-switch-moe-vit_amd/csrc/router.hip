@@ -365,6 +365,7 @@ extern "C" int smoe_router_topk(const void* x, int x_dtype, const float* wg, con
                                 void* stream) {
   const int force_f64 = (gate_kind & 0x100) ? 1 : 0;
   gate_kind &= 0xff;
+  if (T == 0) return 0;  // empty batch: nothing to route (zero-sized tensors have null data pointers)
   SMOE_REQUIRE(x && wg && idx && score, "smoe_router_topk: null pointer");
   SMOE_REQUIRE(T >= 0 && T < (1ll << 31) && d > 0 && E > 0, "smoe_router_topk: bad sizes T=%lld d=%d E=%d", (long long)T, d, E);
   SMOE_REQUIRE(d % 8 == 0 && d <= 2048, "smoe_router_topk: d=%d must be a multiple of 8 and <= 2048", d);

@@ -442,6 +442,7 @@ extern "C" int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_g
                                    size_t workspace_bytes, void* stream) {
   const int force_f64 = (gate_kind & 0x100) ? 1 : 0;
   gate_kind &= 0xff;
+  if (T == 0) return 0;
   SMOE_REQUIRE(x && wg && idx && score, "smoe_ln_router_topk: null pointer");
   SMOE_REQUIRE(shape_ok16(d, E, k), "smoe_ln_router_topk: unsupported shape d=%d E=%d k=%d", d, E, k);
   SMOE_REQUIRE(T >= 0 && T < (1ll << 31), "smoe_ln_router_topk: bad T");

@@ -383,6 +383,40 @@ def test_zero_token_rows_from_skip_gate_route_by_bias():
     assert torch.allclose(out[::3], const.expand(len(out[::3]), -1), atol=3e-5)
 
 
+@pytest.mark.parametrize("T", [0, 1, 3, 64])
+def test_moe_module_tiny_and_empty_batches(T):
+    d, h, E = 192, 768, 4
+    _, wg, bg, w1, b1, w2, b2 = _mk(8, d, h, E, seed=1)
+    x = torch.randn(T, d, generator=_gen(T))
+    for k in (1, 2):
+        mod = _load_module(sm.CustomizedMoEMLP(d, h, E, k, 0.0, compute_dtype=torch.float32), wg, bg, w1, b1, w2, b2)
+        ln = torch.nn.LayerNorm(d, eps=1e-6).to(DEV)
+        with torch.no_grad():
+            out = mod(x.to(DEV))
+            out2 = mod.forward_norm_add(x.to(DEV), ln)
+        assert out.shape == (T, d) and out2.shape == (T, d)
+        if T:
+            r = mo.moe_forward(x, wg, bg, w1, b1, w2, b2, k)
+            assert (out.cpu() - r.out).abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize("d,h,E,k,T", [(768, 3072, 16, 1, 3000), (1024, 4096, 32, 1, 2500), (1024, 4096, 32, 2, 1500)])
+def test_moe_module_cfg3_cfg4_dims(d, h, E, k, T):
+    """BASELINE cfg 3 / cfg 4 operator shapes (ViT-B E=16; ViT-L d 1024 / h 4096, E=32): general router path
+    (E > 8) + the default GEMM variant, f16 operands."""
+    x, wg, bg, w1, b1, w2, b2 = _mk(T, d, h, E, seed=E + k)
+    wg = wg * 4
+    mod = _load_module(sm.CustomizedMoEMLP(d, h, E, k, 0.0), wg, bg, w1, b1, w2, b2)
+    with torch.no_grad():
+        out = mod(x.to(DEV)).cpu()
+    r = mo.moe_forward(x, wg, bg, w1, b1, w2, b2, k)
+    assert torch.equal(mod.last_plan[0].cpu(), r.idx)
+    assert np.array_equal(mod.last_plan[4].cpu().numpy(), r.plan.pos)
+    diff = out - r.out
+    assert (diff.norm() / r.out.norm()).item() <= 1e-3
+    assert diff.abs().max().item() <= 2.5e-3
+
+
 # ------------------------------------------------------------------------------------------ full size (cfg 2)
 def test_cfg2_full_size_properties():
     """ViT-B/16 E=8 top-1, batch 256 x 197 tokens (BASELINE cfg 2): size-independent properties + a sampled
