@@ -101,6 +101,14 @@ class _HalfCache:
     def __init__(self):
         self._c = {}
 
+    def offsets(self, rows: int, device) -> torch.Tensor:
+        key = ("offs", rows, str(device))
+        hit = self._c.get(key)
+        if hit is None:
+            hit = torch.tensor([0, rows], dtype=torch.int32, device=device)
+            self._c[key] = hit
+        return hit
+
     def get(self, p: torch.Tensor) -> torch.Tensor:
         key = id(p)
         ver = (p._version, p.data_ptr())
@@ -123,15 +131,32 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """``residual`` (optional, inference fast path only): returns (residual + attn(x), True) when the add was
+        fused into the projection, else (attn(x), False)."""
         B, N, C = x.shape
+        if residual is None:
+            return self._forward(x)
         if x.dtype == torch.float16 and _autocast_half_inference(x):
             # same arithmetic as autocast (fp16 GEMM operands), without re-casting the weights on every call
             hc = self.__dict__.setdefault("_half", _HalfCache())
             qkv = F.linear(x, hc.get(self.qkv.weight), hc.get(self.qkv.bias) if self.qkv.bias is not None else None)
             q, k, v = qkv.reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
-            o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
-            return F.linear(o.transpose(1, 2).reshape(B, N, C), hc.get(self.proj.weight), hc.get(self.proj.bias))
+            o = F.scaled_dot_product_attention(q, k, v, scale=self.scale).transpose(1, 2).reshape(B * N, C)
+            if residual is not None and C % 64 == 0 and residual.dtype == torch.float32 and residual.is_contiguous():
+                # projection + bias + residual add in one launch of the grouped MFMA GEMM (a single group):
+                # residual + proj(o), f32 out -- the same arithmetic as the unfused `x + attn(...)`
+                from . import ops
+                offs = hc.offsets(B * N, x.device)
+                pb = self.proj.bias.detach().float()[None] if self.proj.bias is not None else None
+                out = ops.grouped_gemm(o, hc.get(self.proj.weight)[None], pb, offs, ops.EPI_NONE, torch.float32,
+                                       residual=residual.reshape(B * N, C), variant=4)
+                return out.reshape(B, N, C), True
+            return F.linear(o, hc.get(self.proj.weight), hc.get(self.proj.bias)).reshape(B, N, C), False
+        return self._forward(x), False
+
+    def _forward(self, x):
+        B, N, C = x.shape
         q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
         p = self.attn_drop.p if self.training else 0.0
         x = F.scaled_dot_product_attention(q, k, v, dropout_p=p, scale=self.scale)
@@ -162,7 +187,11 @@ class Block(nn.Module):
         return n(x)
 
     def forward(self, x):
-        x = x + self.drop_path(self.attn(self._norm1(x)))
+        if isinstance(self.drop_path, nn.Identity) and x.is_contiguous() and isinstance(self.attn, Attention):
+            a, added = self.attn(self._norm1(x), residual=x)
+            x = a if added else x + a
+        else:
+            x = x + self.drop_path(self.attn(self._norm1(x)))
         if isinstance(self.drop_path, nn.Identity):
             fused2 = getattr(self.mlp, "forward_norm_add", None)
             if fused2 is not None:

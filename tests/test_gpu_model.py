@@ -1,0 +1,66 @@
+"""Model-level parity on the GPU: BASELINE cfg 1 (ViT-Ti/16, E=4, top-1, 224^2, batch 8) through the eval harness,
+HIP path vs the CPU oracle's vit_forward on the same weights and images; plus the resmoe (token-skip gate) variant."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import moe_oracle as mo  # noqa: E402
+import slim_switch_moe_vit_amd as sm  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _init(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for blk in model.blocks:
+            m = blk.mlp
+            m.gate.gate.weight.copy_(torch.randn(m.gate.gate.weight.shape, generator=g) * 0.1)
+            m.gate.gate.bias.zero_()
+            m.experts.htoh4.weight.copy_(torch.randn(m.experts.htoh4.weight.shape, generator=g) * 0.02)
+            m.experts.h4toh.weight.copy_(torch.randn(m.experts.h4toh.weight.shape, generator=g) * 0.02)
+        model.head.weight.copy_(torch.randn(model.head.weight.shape, generator=g) * 0.02)
+    return model
+
+
+@pytest.mark.parametrize("autocast,cd,tol", [(False, torch.float32, 2e-3), (True, None, 5e-2)])
+def test_cfg1_vit_tiny_e4_top1_through_eval_harness(autocast, cd, tol):
+    torch.manual_seed(0)
+    kw = {"compute_dtype": cd} if cd is not None else {}
+    model = _init(sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=100, **kw), 1).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    images = torch.randn(8, 3, 224, 224, generator=g)
+    target = torch.randint(0, 100, (8,), generator=g)
+    ref = mo.vit_forward(images, sd, depth=12, num_heads=3, k=1, residual_moe=False)
+    model = model.to(DEV)
+    stats = sm.evaluate([(images, target)], model, DEV, autocast=autocast)
+    assert set(stats) >= {"loss", "acc1", "acc5", "images_per_sec"}
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
+        out = model(images.to(DEV)).float().cpu()
+    err = (out - ref).abs().max().item()
+    assert err <= tol, err
+    ref_loss = torch.nn.functional.cross_entropy(ref, target).item()
+    assert abs(stats["loss"] - ref_loss) < 10 * tol
+
+
+def test_resmoe_factory_forward_matches_oracle_block_semantics():
+    """resmoe_tiny_patch16_224_expert8 (E=8, top-2, token-skip gates, residual on the normed activations):
+    eval forward on the GPU vs the oracle with the same state dict; gates at the reference defaults
+    (target threshold 0.9) skip only a few tokens but those must route as all-zero rows."""
+    torch.manual_seed(0)
+    model = _init(sm.create_model("resmoe_tiny_patch16_224_expert8", num_classes=10, compute_dtype=torch.float32,
+                                  starting_threshold=1.0, target_threshold=0.9), 3).eval()
+    with torch.no_grad():
+        for blk in model.blocks:  # make the skip gates fire on a visible fraction of tokens
+            blk.moe_gate.head[1].bias.fill_(1.5)
+            blk.dense_gate.head[1].bias.fill_(1.5)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    images = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    ref = mo.vit_forward(images, sd, depth=12, num_heads=3, k=2, residual_moe=True)
+    model = model.to(DEV)
+    with torch.no_grad():
+        out = model(images.to(DEV)).cpu()
+    assert model.blocks[0].moe_gate._skipped_tokens > 0
+    assert (out - ref).abs().max().item() <= 5e-3
