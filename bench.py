@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=4)
+    ap.add_argument("--force-ep", action="store_true",
+                    help="diagnostic: drive the expert-parallel code path on one GPU (world of one rank)")
     return ap.parse_args()
 
 
@@ -73,6 +75,7 @@ def build_model(args, world, rank, device):
             blk.mlp.experts.htoh4.weight.copy_(w1[sl]); blk.mlp.experts.htoh4.bias.zero_()
             blk.mlp.experts.h4toh.weight.copy_(w2[sl]); blk.mlp.experts.h4toh.bias.zero_()
             blk.mlp.ep_chunks = args.ep_chunks
+            blk.mlp.force_ep = bool(getattr(args, "force_ep", False))
             # the head is zero-initialised in the reference (vision_transformer.py:859-861); give it signal
         torch.nn.init.trunc_normal_(model.head.weight, std=0.02, a=-2, b=2, generator=g)
     sd_cpu = None
@@ -136,6 +139,8 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+    elif args.force_ep:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=device)
 
     from slim_switch_moe_vit_amd import ops
 
@@ -225,7 +230,7 @@ def main():
             "config": {"workload": f"ViT-B/16 Switch-MoE E={args.experts} top-1, 224^2, batch {args.batch}/GPU, "
                                    f"full eval forward (12 blocks: attention + MoE MLP), fp16 autocast",
                        "global_batch": args.batch * world, "tokens_per_image": 197,
-                       "parallelism": "single" if world == 1 else f"ep{world} (experts/{world} per rank, all-to-all, {args.ep_chunks} chunks)"},
+                       "parallelism": ("single" if not args.force_ep else "single (EP code path forced)") if world == 1 else f"ep{world} (experts/{world} per rank, all-to-all, {args.ep_chunks} chunks)"},
             "roofline": roofline,
             "kernels": kernels,
         }
@@ -244,7 +249,7 @@ def main():
             out["parity"] = hot_path_parity(model, sd_cpu, device)
             out["parity"]["model_logits_max_abs_diff_vs_cpu_fp32"] = float((gl - cpu_logits).abs().max())
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_ep:
         dist.destroy_process_group()
 
 

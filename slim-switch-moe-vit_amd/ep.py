@@ -67,8 +67,11 @@ def chunk_bounds(T: int, chunks: int) -> List[Tuple[int, int]]:
     return [((T * c) // chunks, (T * (c + 1)) // chunks) for c in range(chunks)]
 
 
-def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Expert-parallel FMoETransformerMLP forward for this rank's tokens x [T, d] -> [T, d]."""
+def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.Tensor] = None,
+               norm: Optional[torch.nn.Module] = None) -> torch.Tensor:
+    """Expert-parallel FMoETransformerMLP forward for this rank's tokens x [T, d] -> [T, d].
+    With ``norm`` (a LayerNorm whose shape the fused kernel covers) the operator computes ``moe(norm(x))``: LayerNorm
+    and router run as one pass over x and the send buffers are gathered from the normalised 16-bit image."""
     from . import ops
     from .fmoe import SwitchGate
 
@@ -86,7 +89,14 @@ def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.T
     noise = g.make_noise(T, x.device) if isinstance(g, SwitchGate) else None
     gw = g.gate.weight.detach().float().contiguous()
     gb = g.gate.bias.detach().float() if g.gate.bias is not None else None
-    idx, score, _, probs = ops.router_topk(x, gw, gb, k, g.kind, noise, want_probs=isinstance(g, SwitchGate))
+    src = x  # rows the send buffers are gathered from
+    if norm is not None:
+        xn16, _, idx, score, _, probs = ops.ln_router_topk(
+            x, norm.weight.detach().float(), norm.bias.detach().float() if norm.bias is not None else None, norm.eps,
+            gw, gb, k, g.kind, noise, xn16_dtype=cd, want_probs=isinstance(g, SwitchGate))
+        src = xn16
+    else:
+        idx, score, _, probs = ops.router_topk(x, gw, gb, k, g.kind, noise, want_probs=isinstance(g, SwitchGate))
     plans = []
     for (t0, t1) in bounds:
         plans.append(ops.dispatch_plan(idx[t0:t1], g.tot_expert, cap))
@@ -103,7 +113,7 @@ def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.T
     inflight = []
     for c, (t0, t1) in enumerate(bounds):
         counts, offsets, pos, inv_pos, _ = plans[c]
-        send = ops.scatter_rows(x[t0:t1], pos, k, cd)
+        send = ops.scatter_rows(src[t0:t1], pos, k, cd)
         send_rows = lec[c].sum(1).tolist()
         recv_rows = gec[c].sum(1).tolist()
         recv, work = all_to_all_rows(send, send_rows, recv_rows, group, async_op=True)

@@ -207,14 +207,19 @@ class FMoETransformerMLP(nn.Module):
         g = self.gate
         ok = (x.is_cuda and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine
               and tuple(norm.normalized_shape) == (self.d_model,) and self._fused_gelu
-              and not (self._drop_p > 0 and self.training) and self.world_size == 1
-              and not getattr(self, "force_ep", False) and cd in (torch.float16, torch.bfloat16)
+              and not (self._drop_p > 0 and self.training) and cd in (torch.float16, torch.bfloat16)
               and self.gemm_variant == 4 and self.d_model % 64 == 0
               and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())
                                                     or any(p.requires_grad for p in norm.parameters())))
               and ops.ln_router_supported(self.d_model, g.tot_expert, g.top_k))
         if not ok:
             return self.forward_add(norm(x), x)
+        if self.world_size > 1 or getattr(self, "force_ep", False):
+            from .ep import ep_forward
+            x2 = x.reshape(-1, self.d_model)
+            if not x2.is_contiguous():
+                x2 = x2.contiguous()
+            return ep_forward(self, x2, cd, residual=x2, norm=norm).reshape(x.shape)
         shape = x.shape
         d, k = self.d_model, self.top_k
         x2 = x.reshape(-1, d)

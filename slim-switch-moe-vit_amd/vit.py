@@ -92,7 +92,7 @@ class Mlp(nn.Module):
 
 def _autocast_half_inference(x: torch.Tensor) -> bool:
     return (x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled()
-            and torch.get_autocast_gpu_dtype() == torch.float16)
+            and torch.get_autocast_dtype("cuda") == torch.float16)
 
 
 class _HalfCache:

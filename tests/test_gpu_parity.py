@@ -491,6 +491,13 @@ def test_expert_parallel_path_on_one_gpu():
             assert (got.cpu() - o).abs().max().item() <= tol
             assert (got - ref).abs().max().item() <= tol
             assert (got_add - ref_add).abs().max().item() <= tol
+            # block half with the fused LayerNorm + router in front of the expert-parallel exchange
+            ln = torch.nn.LayerNorm(d, eps=1e-6).to(DEV)
+            with torch.no_grad():
+                ep_ln = mod.forward_norm_add(x.to(DEV), ln)
+                mod.force_ep = False
+                ref_ln = mod.forward_norm_add(x.to(DEV), ln)
+            assert (ep_ln - ref_ln).abs().max().item() <= max(tol, 2e-3 if cd == torch.float16 else tol)
         # switch gate with drops runs un-chunked and keeps dropped rows at zero / at the residual
         x, wg, bg, w1, b1, w2, b2 = _mk(T, d, h, E, seed=99, skew=True)
         mod = sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=1, gate="switch", capacity_factor=1.0,
