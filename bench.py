@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--experts", type=int, default=8, help="global number of experts")
     ap.add_argument("--compute-dtype", default=os.environ.get("SLIMMOE_COMPUTE_DTYPE", "f16"), choices=["f16", "bf16", "f32"])
-    ap.add_argument("--ep-chunks", type=int, default=2)
+    ap.add_argument("--ep-chunks", type=int, default=1)
     ap.add_argument("--cpu-batch", type=int, default=16, help="images in the CPU-oracle sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

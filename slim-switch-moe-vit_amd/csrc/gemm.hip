@@ -644,6 +644,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s0 + s] + kt * 64),
                                        (__attribute__((address_space(3))) void*)(sa + ((s0 + s) * NW + wave) * 1024), 16, 0, 0);
   };
+  auto dma_a1 = [&](int kt, int buf, int s1) {  // one 1-KiB piece
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s1] + kt * 64),
+                                     (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (s1 * NW + wave) * 1024), 16, 0, 0);
+  };
+  auto dma_w1 = [&](int kt, int buf, int s1) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[s1] + kt * 64),
+                                     (__attribute__((address_space(3))) void*)(smem + buf * STAGE + TBM * BK_BYTES + (s1 * NW + wave) * 1024), 16, 0, 0);
+  };
   auto dma_w = [&](int kt, int buf, int s0) {
     if ((ABL & 1) && kt >= 2) return;
     char* sw = smem + buf * STAGE + TBM * BK_BYTES;
@@ -723,6 +731,49 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   // at the head of the reader's next MFMA interval) at least one barrier before the issue; the data is
   // needed >= 3 intervals later, and every wave drains all but its 2 newest DMAs before the barrier that
   // closes tile t (counted vmcnt: the newest two belong to tile t+2).
+  if constexpr ((ABL & 8) != 0) {
+    // experimental schedule: ONE DMA piece per interval per wave (read intervals: behind the ds_reads; MFMA
+    // intervals: behind the MFMA cluster), so no wave ever queues two DMA issues back to back
+    for (int t = 0; t < nk; ++t) {
+      const int cur = t & 1, nxt = cur ^ 1;
+      const bool pre1 = (t >= 1) && (t + 1 < nk);
+      const bool pre2 = (t + 2 < nk);
+      read_b(cur, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(cur, 0);
+      if (pre1) dma_a1(t + 1, nxt, 2);
+      PP_BARRIER();
+      PP_MFMA(0, 0);
+      if (pre1) dma_a1(t + 1, nxt, 3);
+      PP_BARRIER();
+      read_b(cur, 1);
+      if (pre1) dma_w1(t + 1, nxt, 0);
+      PP_BARRIER();
+      PP_MFMA(0, 1);
+      if (pre1) dma_w1(t + 1, nxt, 1);
+      PP_BARRIER();
+      read_a(cur, 1);
+      if (pre1) dma_w1(t + 1, nxt, 2);
+      PP_BARRIER();
+      PP_MFMA(1, 1);
+      if (pre1) dma_w1(t + 1, nxt, 3);
+      PP_BARRIER();
+      read_b(cur, 0);
+      if (pre2) dma_a1(t + 2, cur, 0);
+      if (wr == 1) {  // newest outstanding for group 1 here: only A_lo piece 0 of tile t+2
+        if (pre2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      PP_BARRIER();
+      PP_MFMA(1, 0);
+      if (pre2) dma_a1(t + 2, cur, 1);
+      if (wr == 0) {
+        if (pre2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      PP_BARRIER();
+    }
+  } else {
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1, nxt = cur ^ 1;
     const bool pre1 = (t >= 1) && (t + 1 < nk);
@@ -761,6 +812,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     PP_BARRIER();
+  }
   }
   if (wr == 0) PP_BARRIER();  // equalise barrier counts; after it every wave is done with LDS
   }
@@ -925,6 +977,7 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
       case 43: return launch_pp256<AB, OT, 3>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
       case 44: return launch_pp256<AB, OT, 4>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
       case 46: return launch_pp256<AB, OT, 6>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
+      case 48: return launch_pp256<AB, OT, 8>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
       case 47: return launch_pp256<AB, OT, 7>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
 #endif
       default: break;

@@ -11,9 +11,12 @@ Receive layout: rows arrive rank-major ([source rank][local expert][token]).  In
 expert-major (an extra HBM pass) the grouped GEMM takes one row group per (source rank, local expert) with
 a group -> expert map (``group_expert`` in include/slimmoe.h).
 
-Overlap: the local tokens are cut into ``ep_chunks`` micro-batches; the all-to-all of chunk c+1 runs on
+Overlap: the local tokens can be cut into ``ep_chunks`` micro-batches; the all-to-all of chunk c+1 then runs on
 RCCL's stream under the expert GEMMs of chunk c (and the return all-to-all of chunk c under the GEMMs of
 chunk c+1).  Only ONE host sync per layer: every chunk's count matrix travels in a single small all-to-all.
+Default is one chunk: measured on one GPU (bench.py --force-ep) every extra chunk costs ~0.3 ms per layer in
+extra launches and in tile quantisation of the halved GEMMs, which the overlap only repays when the exchange
+is slower than that.
 The functions that only move data (exchange_counts, segment_table, all_to_all_rows) are device-agnostic and
 are exercised on CPU with the gloo backend in tests/test_ep_gloo.py.
 """
@@ -81,7 +84,7 @@ def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.T
     T = x.shape[0]
     cap = g.capacity(T)
     # capacity is defined over the whole local batch, so dropping gates run un-chunked
-    n_chunks = 1 if cap >= 0 else max(1, int(getattr(mod, "ep_chunks", 2)))
+    n_chunks = 1 if cap >= 0 else max(1, int(getattr(mod, "ep_chunks", 1)))
     bounds = chunk_bounds(T, n_chunks) if T > 0 else [(0, 0)] * n_chunks
     if len(bounds) < n_chunks:  # tiny batches: keep the collective count identical on every rank
         bounds = bounds + [(T, T)] * (n_chunks - len(bounds))

@@ -183,7 +183,7 @@ class FMoETransformerMLP(nn.Module):
         self.experts = _Expert(num_expert, d_model, d_hidden, activation, rank=expert_rank)
         self.compute_dtype = compute_dtype
         self.gemm_variant = gemm_variant
-        self.ep_chunks = 2  # micro-batches of the expert-parallel pipeline (ep.py)
+        self.ep_chunks = 1  # micro-batches of the expert-parallel pipeline (ep.py); > 1 overlaps a2a with GEMMs
         self._fused_gelu, self._drop_p, self._generic_act = _parse_activation(activation)
         self.last_plan = None  # (idx, score, counts, offsets, pos, inv_pos) of the latest forward, for inspection
 
