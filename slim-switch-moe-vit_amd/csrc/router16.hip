@@ -56,7 +56,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
   const int q = lane >> 4, u = lane & 15;
   if (MODE == 1 && redo_list && *redo_count == 0) return;  // nothing to redo (the common case): exit before any setup
 
-  for (int i = tid * 4; MODE == 0 && i < R16_E * d; i += R16_THREADS * 4) {  // the redo pass reads wg through L2
+  for (int i = tid * 4; i < R16_E * d; i += R16_THREADS * 4) {
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (i / d < E) v = *reinterpret_cast<const f32x4*>(wg + i);
     *reinterpret_cast<f32x4*>(lds_w + i) = v;
@@ -167,8 +167,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
         if (c < nchunk) {
 #pragma unroll
           for (int e = 0; e < R16_E; ++e) {
-            f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (e < E) w = *reinterpret_cast<const f32x4*>(wg + e * d + c * 4);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds_w + e * d + c * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[e] = fma((double)xv[j][i], (double)w[i], acc[e]);
           }
