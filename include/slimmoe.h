@@ -68,6 +68,13 @@ int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_gamma, const
 int smoe_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, float eps, int64_t T, int d,
                    void* out, int out_dtype, void* stream);
 
+/* Self-attention forward of the block's attention half (models/vision_transformer.py:248-280), N <= 256 tokens,
+ * head dim 64: out[b,n,h*64+:] = softmax(q k^T * scale) v with qkv [B,N,3,H,64] as the fused qkv projection
+ * writes it; f16 / bf16.  Caller-side kernel, not part of the MoE operator.       */
+int smoe_attention_supported(int N, int head_dim);
+int smoe_attention_fwd(const void* qkv, void* out, int dtype, int B, int N, int H, int head_dim, float scale,
+                       void* stream);
+
 /* ---- dispatch plan --------------------------------------------------------------------------------
  * Replaces fmoe_cuda.expert_count + cumsum + assign_pos (+ limit_by_capacity /
  * prune_gate_by_capacity) = fmoe count_by_gate / prepare_forward.

@@ -133,6 +133,23 @@ def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[to
     return out
 
 
+def attention_supported(N: int, head_dim: int) -> bool:
+    return bool(_lib.load().smoe_attention_supported(N, head_dim))
+
+
+def attention(qkv: torch.Tensor, B: int, N: int, H: int, head_dim: int, scale: float) -> torch.Tensor:
+    """qkv [B*N, 3*H*head_dim] (or [B,N,3,H,hd]) 16-bit -> softmax(q k^T * scale) v as [B, N, H*head_dim]."""
+    _chk(qkv, "qkv")
+    if qkv.dtype not in (torch.float16, torch.bfloat16) or qkv.numel() != B * N * 3 * H * head_dim:
+        raise RuntimeError("qkv: expected a 16-bit [B,N,3,H,hd] tensor")
+    out = torch.empty((B, N, H * head_dim), dtype=qkv.dtype, device=qkv.device)
+    with _timed("attention", {"flops": 4.0 * B * H * N * N * head_dim}, qkv):
+        rc = _lib.load().smoe_attention_fwd(_ptr(qkv), _ptr(out), dtype_code(qkv.dtype), B, N, H, head_dim, float(scale),
+                                            _stream(qkv))
+    _lib.check(rc, "smoe_attention_fwd")
+    return out
+
+
 def ln_router_supported(d: int, E: int, k: int) -> bool:
     return bool(_lib.load().smoe_ln_router_supported(d, E, k))
 

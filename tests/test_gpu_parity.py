@@ -325,6 +325,18 @@ def test_layernorm_kernel_matches_reference_layernorm(d, odt, golden_dir):
         assert (y - torch.from_numpy(gd["y"])).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("B,N,H", [(3, 197, 12), (2, 197, 3), (1, 16, 2), (2, 50, 4), (1, 256, 2), (5, 1, 1), (2, 224, 3)])
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
+def test_attention_kernel_matches_reference_attention(B, N, H, dt, tol):
+    """softmax(q k^T * scale) v of models/vision_transformer.py:248-280, from the fused qkv layout [B,N,3,H,64]."""
+    g = _gen(B * 1000 + N + H)
+    qkv = (torch.randn(B, N, 3, H, 64, generator=g) * 1.5).to(dt)
+    got = ops.attention(qkv.to(DEV), B, N, H, 64, 64 ** -0.5).cpu().float()
+    q, k, v = qkv.double().permute(2, 0, 3, 1, 4).unbind(0)
+    ref = (torch.softmax(q @ k.transpose(-2, -1) * 64 ** -0.5, -1) @ v).transpose(1, 2).reshape(B, N, H * 64)
+    assert (got.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
 def test_moe_module_e1_equals_reference_mlp_golden(golden_dir):
     """E = 1: the HIP path reproduces the REFERENCE's own dense Mlp (models/layers.py:391-414) outputs."""
     g = np.load(os.path.join(golden_dir, "ref_mlp_tiny.npz"))
