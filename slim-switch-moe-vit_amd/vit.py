@@ -141,8 +141,14 @@ class Attention(nn.Module):
             # same arithmetic as autocast (fp16 GEMM operands), without re-casting the weights on every call
             hc = self.__dict__.setdefault("_half", _HalfCache())
             qkv = F.linear(x, hc.get(self.qkv.weight), hc.get(self.qkv.bias) if self.qkv.bias is not None else None)
-            q, k, v = qkv.reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
-            o = F.scaled_dot_product_attention(q, k, v, scale=self.scale).transpose(1, 2).reshape(B * N, C)
+            from . import ops
+            hd = C // self.num_heads
+            if ops.attention_supported(N, hd) and qkv.is_contiguous():
+                # hand-written attention on the fused qkv layout [B,N,3,H,hd] (no q/k/v transposes)
+                o = ops.attention(qkv, B, N, self.num_heads, hd, self.scale).reshape(B * N, C)
+            else:
+                q, k, v = qkv.reshape(B, N, 3, self.num_heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
+                o = F.scaled_dot_product_attention(q, k, v, scale=self.scale).transpose(1, 2).reshape(B * N, C)
             if residual is not None and C % 64 == 0 and residual.dtype == torch.float32 and residual.is_contiguous():
                 # projection + bias + residual add in one launch of the grouped MFMA GEMM (a single group):
                 # residual + proj(o), f32 out -- the same arithmetic as the unfused `x + attn(...)`
