@@ -25,11 +25,14 @@ __device__ __forceinline__ int k_lds_off(int row, int chunk) { return row * 128 
 // consecutive rows hit 8 different 32-byte slots of the 256-byte bank row
 __device__ __forceinline__ int v_lds_off(int row, int dt) { return row * 128 + ((dt ^ ((row >> 1) & 3)) << 5); }
 
-template <typename HT, int NT>  // NT = key tiles of 16 (even, padded)
+// NKT = key tiles of 16 held in LDS (compile-time, >= ceil(N/16): every loop below is static, so the compiler can
+// batch the LDS reads ahead of the MFMAs); NT = NKT rounded up to even (k-steps of 32 keys)
+template <typename HT, int NKT>
 __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
                                                                   int H, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int nkt = (N + 15) >> 4;  // real key tiles (<= NT); LDS holds exactly nkt * 16 rows of K and of V
+  constexpr int NT = NKT + (NKT & 1);
+  constexpr int nkt = NKT;
   char* Ks = smem;
   char* Vs = smem + nkt * 16 * 128;
   const int bh = blockIdx.x;
@@ -38,66 +41,101 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __re
   const int64_t tok_stride = (int64_t)3 * H * ATT_D;  // elements between consecutive tokens
   const HT* base = qkv + (int64_t)b * N * tok_stride + h * ATT_D;
 
-  // ---- stage K and V of this head: rows >= N are zero ------------------------------------------------
-  for (int i = tid; i < nkt * 16 * 8; i += ATT_THREADS) {
-    const int row = i >> 3, c = i & 7;
-    u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
-    if (row < N) {
-      const HT* p = base + (int64_t)row * tok_stride + c * 8;
-      kv = *reinterpret_cast<const u32x4*>(p + H * ATT_D);
-      vv = *reinterpret_cast<const u32x4*>(p + 2 * H * ATT_D);
+  // ---- stage K and V of this head by LDS DMA (global_load_lds, 1 KiB = 8 rows per wave-instruction; the source
+  //      address carries the swizzle, cdna_hip_programming.md rule 21).  Rows >= N duplicate row N-1: their scores
+  //      are masked and their probabilities are exactly 0, so they never contribute. ------------------------------
+  {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int l_row = lane >> 3, l_pos = lane & 7;
+    const int npieces = nkt * 2;  // 8-row pieces per operand
+    for (int pc = wave_u; pc < npieces; pc += ATT_THREADS / 64) {
+      const int row = pc * 8 + l_row;
+      const int srow = row < N ? row : N - 1;
+      const HT* p = base + (int64_t)srow * tok_stride;
+      const int kc = l_pos ^ ((row >> 1) & 7);                           // K: 16-byte chunk swizzle
+      const int vc = (((l_pos >> 1) ^ ((row >> 1) & 3)) << 1) | (l_pos & 1);  // V: 32-byte segment swizzle
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + H * ATT_D + kc * 8),
+                                       (__attribute__((address_space(3))) void*)(Ks + pc * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 2 * H * ATT_D + vc * 8),
+                                       (__attribute__((address_space(3))) void*)(Vs + pc * 1024), 16, 0, 0);
     }
-    *reinterpret_cast<u32x4*>(Ks + k_lds_off(row, c)) = kv;
-    *reinterpret_cast<u32x4*>(Vs + v_lds_off(row, c >> 1) + (c & 1) * 16) = vv;
   }
-  __syncthreads();
-
   const int g = lane >> 4, qi = lane & 15;
   const int nqt = (N + 15) >> 4;
-  for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
-    const int q0 = qt * 16;
-    int qrow = q0 + qi;
+  auto load_q = [&](int qt, u32x4& f0, u32x4& f1) {
+    int qrow = qt * 16 + qi;
     if (qrow >= N) qrow = N - 1;
     const HT* qp = base + (int64_t)qrow * tok_stride + g * 8;
-    const u32x4 qf0 = *reinterpret_cast<const u32x4*>(qp);
-    const u32x4 qf1 = *reinterpret_cast<const u32x4*>(qp + 32);
+    f0 = *reinterpret_cast<const u32x4*>(qp);
+    f1 = *reinterpret_cast<const u32x4*>(qp + 32);
+  };
+  u32x4 qn0 = u32x4{0u, 0u, 0u, 0u}, qn1 = qn0;
+  if (wave < nqt) load_q(wave, qn0, qn1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
+    const int q0 = qt * 16;
+    const u32x4 qf0 = qn0, qf1 = qn1;
+    if (qt + ATT_THREADS / 64 < nqt) load_q(qt + ATT_THREADS / 64, qn0, qn1);  // next tile's Q under this tile's math
 
-    // ---- S^T tiles ---------------------------------------------------------------------------------------
+    // ---- S^T tiles: fragment reads in batches of 4 key tiles (8 ds_read_b128) ahead of their 8 MFMAs; the
+    //      sched_barrier keeps hipcc from either sinking each read next to its MFMA (one exposed LDS latency per
+    //      MFMA) or hoisting all 26 reads (104 VGPRs, spills) --------------------------------------------------
     f32x4 sacc[NT];
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      sacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kt < nkt) {
-        const u32x4 kf0 = *reinterpret_cast<const u32x4*>(Ks + k_lds_off(kt * 16 + qi, g));
-        const u32x4 kf1 = *reinterpret_cast<const u32x4*>(Ks + k_lds_off(kt * 16 + qi, 4 + g));
-        if constexpr (std::is_same<HT, f16>::value) {
-          sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf0), __builtin_bit_cast(f16x8, qf0), sacc[kt], 0, 0, 0);
-          sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf1), __builtin_bit_cast(f16x8, qf1), sacc[kt], 0, 0, 0);
-        } else {
-          sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf0), __builtin_bit_cast(bf16x8_t, qf0), sacc[kt], 0, 0, 0);
-          sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf1), __builtin_bit_cast(bf16x8_t, qf1), sacc[kt], 0, 0, 0);
+    for (int kt = 0; kt < NT; ++kt) sacc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NKG = (nkt + 3) / 4;
+    u32x4 kf[2][4][2];  // double-buffered: group gi+1 is read while group gi feeds the MFMAs
+    auto read_k = [&](int buf, int kg) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (kg + i < nkt) {
+          kf[buf][i][0] = *reinterpret_cast<const u32x4*>(Ks + k_lds_off((kg + i) * 16 + qi, g));
+          kf[buf][i][1] = *reinterpret_cast<const u32x4*>(Ks + k_lds_off((kg + i) * 16 + qi, 4 + g));
         }
       }
+    };
+    read_k(0, 0);
+#pragma unroll
+    for (int gi = 0; gi < NKG; ++gi) {
+      const int kg = gi * 4;
+      if (gi + 1 < NKG) read_k((gi + 1) & 1, kg + 4);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (kg + i < nkt) {
+          if constexpr (std::is_same<HT, f16>::value) {
+            sacc[kg + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[gi & 1][i][0]), __builtin_bit_cast(f16x8, qf0), sacc[kg + i], 0, 0, 0);
+            sacc[kg + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[gi & 1][i][1]), __builtin_bit_cast(f16x8, qf1), sacc[kg + i], 0, 0, 0);
+          } else {
+            sacc[kg + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[gi & 1][i][0]), __builtin_bit_cast(bf16x8_t, qf0), sacc[kg + i], 0, 0, 0);
+            sacc[kg + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[gi & 1][i][1]), __builtin_bit_cast(bf16x8_t, qf1), sacc[kg + i], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- softmax over keys (scores of one query live in the 4 lanes g = 0..3 with equal qi) -------------------
+    // mask only the tiles that can hold keys >= N (wave-uniform test per static tile index)
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      if (kt * 16 + 16 > N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kt * 16 + g * 4 + r >= N) sacc[kt][r] = -INFINITY;
+      }
+    }
     float m = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + g * 4 + r;
-        const float s = (key < N) ? sacc[kt][r] * scale_log2e : -INFINITY;
-        sacc[kt][r] = s;
-        m = fmaxf(m, s);
-      }
+    for (int kt = 0; kt < NT; ++kt) m = fmaxf(fmaxf(m, fmaxf(sacc[kt][0], sacc[kt][1])), fmaxf(sacc[kt][2], sacc[kt][3]));
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float nmc = -m * scale_log2e;  // exp2(s*c - m*c): scale folded into one FMA per score
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(sacc[kt][r] - m);
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], scale_log2e, nmc));
         sacc[kt][r] = p;
         l += p;
       }
@@ -105,44 +143,58 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __re
     l += __shfl_xor(l, 32, 64);
     const float inv_l = 1.0f / l;
 
-    // ---- O^T = V^T P^T --------------------------------------------------------------------------------------
-    f32x4 oacc[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int tq = qi >> 2, tp = qi & 3;  // transposed-read address roles inside the 16-lane group
+    // ---- O^T = V^T P^T: P packed to 16 bit first (frees the f32 scores), then per k-step 8 transposed reads issued
+    //      together ahead of their 4 MFMAs --------------------------------------------------------------------------
+    u32x4 pf[NT / 2];
 #pragma unroll
     for (int ks = 0; ks < NT / 2; ++ks) {
-      u32x4 pf;
       if constexpr (std::is_same<HT, f16>::value) {
         f16x8 t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { t[r] = (f16)sacc[2 * ks][r]; t[4 + r] = (f16)sacc[2 * ks + 1][r]; }
-        pf = __builtin_bit_cast(u32x4, t);
+        pf[ks] = __builtin_bit_cast(u32x4, t);
       } else {
         s16x8 t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { t[r] = (short)f32_to_bf16(sacc[2 * ks][r]); t[4 + r] = (short)f32_to_bf16(sacc[2 * ks + 1][r]); }
-        pf = __builtin_bit_cast(u32x4, t);
+        pf[ks] = __builtin_bit_cast(u32x4, t);
       }
+    }
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tq = qi >> 2, tp = qi & 3;  // transposed-read address roles inside the 16-lane group
+    s16x4 v0[2][4], v1[2][4];  // double-buffered transposed V fragments
+    auto read_v = [&](int buf, int ks) {
       const int row1 = 32 * ks + 4 * g + tq;  // row this lane addresses in block 1; block 2 is 16 rows further
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        s16x4 v0 = s16x4{0, 0, 0, 0};
-        if (2 * ks < nkt)  // wave-uniform: tiles past the real key count have no rows in LDS
-          v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        v0[buf][dt] = s16x4{0, 0, 0, 0};
+        v1[buf][dt] = s16x4{0, 0, 0, 0};
+        if (2 * ks < nkt)  // static
+          v0[buf][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4*)(Vs + v_lds_off(row1, dt) + tp * 8));
-        s16x4 v1 = s16x4{0, 0, 0, 0};
-        if (2 * ks + 1 < nkt)  // wave-uniform: the padding tile has no rows in LDS (its P entries are zero anyway)
-          v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        if (2 * ks + 1 < nkt)  // static: the padding tile has no rows in LDS (its P entries are zero anyway)
+          v1[buf][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4*)(Vs + v_lds_off(row1 + 16, dt) + tp * 8));
+      }
+    };
+    read_v(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < NT / 2; ++ks) {
+      if (ks + 1 < NT / 2) read_v((ks + 1) & 1, ks + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
         s16x8 vf;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { vf[r] = v0[r]; vf[4 + r] = v1[r]; }
+        for (int r = 0; r < 4; ++r) { vf[r] = v0[ks & 1][dt][r]; vf[4 + r] = v1[ks & 1][dt][r]; }
         if constexpr (std::is_same<HT, f16>::value)
-          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf), __builtin_bit_cast(f16x8, pf), oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf), __builtin_bit_cast(f16x8, pf[ks]), oacc[dt], 0, 0, 0);
         else
-          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf), oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[ks]), oacc[dt], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- store: lane (g, qi) holds head-dim elements 16 dt + 4 g + r of query q0 + qi ----------------------------
     if (q0 + qi < N) {
@@ -165,10 +217,10 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __re
   }
 }
 
-template <typename HT, int NT>
+template <typename HT, int NKT>
 int launch_attn(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s) {
-  const size_t smem = 2 * (size_t)((N + 15) / 16) * 16 * 128;
-  auto kern = attn_fwd_kernel<HT, NT>;
+  const size_t smem = 2 * (size_t)NKT * 16 * 128;
+  auto kern = attn_fwd_kernel<HT, NKT>;
   static bool attr_done = false;
   if (!attr_done && smem > 48 * 1024) {
     hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -186,12 +238,11 @@ int launch_attn(const void* qkv, void* out, int B, int N, int H, float scale, hi
 
 template <typename HT>
 int attn_dispatch(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s) {
-  const int nt = ((N + 15) / 16 + 1) & ~1;
-  switch (nt) {
-    case 2: case 4: case 6: case 8: return launch_attn<HT, 8>(qkv, out, B, N, H, scale, s);
-    case 10: case 12: case 14: return launch_attn<HT, 14>(qkv, out, B, N, H, scale, s);
-    case 16: return launch_attn<HT, 16>(qkv, out, B, N, H, scale, s);
-  }
+  const int nkt = (N + 15) / 16;
+  if (nkt <= 4) return launch_attn<HT, 4>(qkv, out, B, N, H, scale, s);
+  if (nkt <= 8) return launch_attn<HT, 8>(qkv, out, B, N, H, scale, s);
+  if (nkt <= 13) return launch_attn<HT, 13>(qkv, out, B, N, H, scale, s);   // N = 197 (ViT @224, +cls): 13 tiles
+  if (nkt <= 16) return launch_attn<HT, 16>(qkv, out, B, N, H, scale, s);
   smoe_set_error("smoe_attention_fwd: N=%d unsupported (N <= 256)", N);
   return 1;
 }
