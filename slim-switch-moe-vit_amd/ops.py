@@ -266,7 +266,7 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
                  out: Optional[torch.Tensor] = None, variant: int = 0,
                  group_expert: Optional[torch.Tensor] = None, rows_hint: Optional[int] = None,
                  residual: Optional[torch.Tensor] = None, a_gather: Optional[torch.Tensor] = None,
-                 a_div: int = 1) -> torch.Tensor:
+                 a_div: int = 1, prof_name: str = "grouped_gemm") -> torch.Tensor:
     """out[r] = epi(A[r] @ W[e]^T + bias[e]) for r in [offsets[g], offsets[g+1]), e = group_expert[g] (or g).
     W [E,N,K].  ``rows_hint`` = number of rows actually routed (for the profiler's FLOP count only)."""
     _chk(A, "A", ndim=2)
@@ -311,7 +311,7 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
             raise RuntimeError("residual: expected the shape of out")
     lib = _lib.load()
     rows = M if rows_hint is None else rows_hint
-    with _timed("grouped_gemm", {"flops": 2.0 * rows * K * N, "K": K, "N": N, "epilogue": epilogue}, A):
+    with _timed(prof_name, {"flops": 2.0 * rows * K * N, "K": K, "N": N, "epilogue": epilogue}, A):
         rc = lib.smoe_grouped_gemm(_ptr(A), _ptr(W), _ptr(bias), _ptr(offsets), _ptr(group_expert), G, E, M, K, N,
                                    dtype_code(A.dtype), epilogue, _ptr(row_map), _ptr(row_scale), _ptr(residual),
                                    _ptr(a_gather), a_div, _ptr(out), dtype_code(out_dtype), variant, _stream(A))

@@ -156,7 +156,7 @@ class Attention(nn.Module):
                 offs = hc.offsets(B * N, x.device)
                 pb = self.proj.bias.detach().float()[None] if self.proj.bias is not None else None
                 out = ops.grouped_gemm(o, hc.get(self.proj.weight)[None], pb, offs, ops.EPI_NONE, torch.float32,
-                                       residual=residual.reshape(B * N, C), variant=4)
+                                       residual=residual.reshape(B * N, C), variant=4, prof_name="attn_proj_gemm")
                 return out.reshape(B, N, C), True
             return F.linear(o, hc.get(self.proj.weight), hc.get(self.proj.bias)).reshape(B, N, C), False
         return self._forward(x), False
