@@ -1,21 +1,23 @@
 """Training side of the MoE operator (BASELINE cfg 5: capacity + token dropping + aux loss, fwd + bwd).
 
-Forward keeps what backward needs (expert-sorted inputs S, pre-activations H, activations A, expert outputs
-Y when the gate score carries gradient); backward is the adjoint chain of SURVEY.md Appendix B:
+The differentiable forward is a chain of four autograd Functions, each the adjoint pair SURVEY.md Appendix B
+('backward') names; single-rank and expert-parallel training share them:
 
-    dY  = score * dout[pos // k]                      smoe_scatter_rows(scale=score)
-    dsc = <dout[t], Y[inv_pos]>                       smoe_rowdot
-    dH  = (dY W2) * gelu'(H)                          smoe_grouped_gemm(W2^T shadow, SMOE_EPI_GELU_GRAD)
-    dW2 = dY_e^T A_e, db2 = colsum(dY_e)              smoe_transpose_pad x2 + smoe_grouped_wgrad, smoe_group_colsum
-    dW1 = dH_e^T S_e, db1 = colsum(dH_e)              same
-    dS  = dH W1                                       smoe_grouped_gemm(W1^T shadow)
-    dx  = sum_j dS[inv_pos[t k + j]]                  smoe_gather_combine(score = 1)
+    _Scatter   S = x[pos // k]                      <->  dx = sum_j dS[inv_pos[t k + j]]        (smoe_scatter_rows / smoe_gather_combine)
+    _AllToAll  rows exchanged by (send, recv) splits <->  the same exchange with the splits swapped (RCCL; expert parallel only)
+    _GroupFFN  Y = gelu(R W1^T + b1) W2^T + b2       <->  dH = (dY W2) gelu'(H)   smoe_grouped_gemm(W^T shadows, SMOE_EPI_GELU_GRAD)
+               per row group (group -> expert map)        dW2 = dY_e^T A_e, dW1 = dH_e^T R_e   smoe_transpose_pad + smoe_grouped_wgrad
+                                                          db = column sums                      smoe_group_colsum
+                                                          dR = dH W1
+    _Combine   out[t] = sum_j score[t,j] Y[inv_pos]  <->  dY = score * dout[pos // k] (smoe_scatter_rows(scale)),
+                                                          dscore = <dout[t], Y[inv_pos]>        (smoe_rowdot)
 
 The router's own gradient (through the gate score and the aux loss) is a skinny [T, E] computation; it runs as
 ordinary differentiable torch ops on logits recomputed from x, with the ROUTING (idx) taken from the HIP router.
-Expert-parallel training (world_size > 1) is not built yet.
 """
 from __future__ import annotations
+
+from typing import List, Optional
 
 import torch
 import torch.nn.functional as F
@@ -35,87 +37,133 @@ def switch_aux_loss(idx_pruned: torch.Tensor, probs: torch.Tensor, E: int) -> to
     return E * (frac * prob).sum()
 
 
-class _ExpertFFN(torch.autograd.Function):
-    """x [T,d], score [T,k] -> out [T,d] through the grouped expert FFN; plan tensors are constants."""
-
-    @staticmethod
-    def forward(ctx, x, score, w1, b1, w2, b2, mod, offsets, pos, inv_pos, drop_mask):
-        k, d = mod.top_k, mod.d_model
-        T = x.shape[0]
-        cd = mod.compute_dtype or _default_cd()
-        ex = mod.experts
-        w1c, w2c = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
-        S = ops.scatter_rows(x, pos, k, cd, zero_fill=True)
-        Hp = ops.grouped_gemm(S, w1c, b1.detach().float() if b1 is not None else None, offsets, ops.EPI_NONE, cd,
-                              variant=mod.gemm_variant)
-        A = ops.gelu(Hp)
-        if drop_mask is not None:
-            A = A * drop_mask
-        Y = ops.grouped_gemm(A, w2c, b2.detach().float() if b2 is not None else None, offsets, ops.EPI_NONE, cd,
-                             variant=mod.gemm_variant)
-        out = ops.gather_combine(Y, inv_pos, score.detach().float().contiguous(), T, k, x.dtype)
-        ctx.mod, ctx.cd = mod, cd
-        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
-        ctx.save_for_backward(S, Hp, A, Y, score.detach(), offsets, pos, inv_pos, drop_mask if drop_mask is not None else torch.empty(0))
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        S, Hp, A, Y, score, offsets, pos, inv_pos, drop_mask = ctx.saved_tensors
-        mod, cd = ctx.mod, ctx.cd
-        k, d, h, E = mod.top_k, mod.d_model, mod.d_hidden, offsets.numel() - 1
-        T = dout.shape[0]
-        n = pos.numel()
-        dout = dout.contiguous()
-        ex = mod.experts
-        sc = score.float().contiguous().reshape(-1)
-        dY = ops.scatter_rows(dout, pos, k, cd, zero_fill=True, scale=sc)               # [n, d]
-        dscore = ops.rowdot(dout, Y, inv_pos, k).view(T, k) if ctx.needs_input_grad[1] else None
-        w2t = ex.h4toh.weight_as(cd).transpose(1, 2).contiguous()                        # [E, h, d]  (N = h, K = d)
-        if drop_mask.numel():
-            dA = ops.grouped_gemm(dY, w2t, None, offsets, ops.EPI_NONE, cd, variant=mod.gemm_variant)
-            dA = dA * drop_mask
-            # gelu'(H) unfused on this (rare) path
-            hp = Hp.float()
-            cdf = 0.5 * (1 + torch.erf(hp * 0.7071067811865476))
-            dH = (dA.float() * (cdf + hp * torch.exp(-0.5 * hp * hp) * 0.3989422804014327)).to(cd)
-        else:
-            dH = ops.grouped_gemm(dY, w2t, None, offsets, ops.EPI_GELU_GRAD, cd, variant=mod.gemm_variant, residual=Hp)
-        offp = ops.pad_offsets(offsets)
-        Lp = ops.padded_len(n, E)
-        dW2 = ops.grouped_wgrad(ops.transpose_pad(dY, offsets, offp, Lp), ops.transpose_pad(A, offsets, offp, Lp), offp)
-        dW1 = ops.grouped_wgrad(ops.transpose_pad(dH, offsets, offp, Lp), ops.transpose_pad(S, offsets, offp, Lp), offp)
-        db2 = ops.group_colsum(dY, offsets) if ctx.has_b2 else None
-        db1 = ops.group_colsum(dH, offsets) if ctx.has_b1 else None
-        dx = None
-        if ctx.needs_input_grad[0]:
-            w1t = ex.htoh4.weight_as(cd).transpose(1, 2).contiguous()                    # [E, d, h]  (N = d, K = h)
-            dS = ops.grouped_gemm(dH, w1t, None, offsets, ops.EPI_NONE, torch.float32, variant=mod.gemm_variant)
-            ones = torch.ones(T * k, dtype=torch.float32, device=dout.device)
-            dx = ops.gather_combine(dS, inv_pos, ones, T, k, dout.dtype)
-        return dx, dscore, dW1, db1, dW2, db2, None, None, None, None, None
-
-
 def _default_cd():
     from .fmoe import default_compute_dtype
     return default_compute_dtype()
 
 
-def moe_forward_train(mod, inp: torch.Tensor) -> torch.Tensor:
-    """FMoETransformerMLP.forward with autograd (single rank)."""
+class _Scatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos, inv_pos, k, cd):
+        ctx.k, ctx.T, ctx.dtype = k, x.shape[0], x.dtype
+        ctx.save_for_backward(inv_pos)
+        return ops.scatter_rows(x, pos, k, cd, zero_fill=True)
+
+    @staticmethod
+    def backward(ctx, dS):
+        (inv_pos,) = ctx.saved_tensors
+        ones = torch.ones(ctx.T * ctx.k, dtype=torch.float32, device=dS.device)
+        dx = ops.gather_combine(dS.contiguous(), inv_pos, ones, ctx.T, ctx.k, ctx.dtype)
+        return dx, None, None, None, None
+
+
+class _Combine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, score, pos, inv_pos, k, out_dtype):
+        T = score.shape[0]
+        ctx.k, ctx.ydtype = k, y.dtype
+        ctx.save_for_backward(y, score, pos, inv_pos)
+        return ops.gather_combine(y, inv_pos, score.detach().float().contiguous(), T, k, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, score, pos, inv_pos = ctx.saved_tensors
+        dout = dout.contiguous()
+        T, k = score.shape[0], ctx.k
+        dy = ops.scatter_rows(dout, pos, k, ctx.ydtype, zero_fill=True, scale=score.float().contiguous().reshape(-1))
+        dscore = ops.rowdot(dout, y, inv_pos, k).view(T, k) if ctx.needs_input_grad[1] else None
+        return dy, dscore, None, None, None, None
+
+
+class _AllToAll(torch.autograd.Function):
+    """all-to-all-v of whole rows; backward is the same exchange with the split lists swapped."""
+
+    @staticmethod
+    def forward(ctx, rows, send_rows: List[int], recv_rows: List[int], group):
+        from .ep import all_to_all_rows
+        ctx.send_rows, ctx.recv_rows, ctx.group, ctx.n_in = send_rows, recv_rows, group, rows.shape[0]
+        out, _ = all_to_all_rows(rows.contiguous(), send_rows, recv_rows, group)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .ep import all_to_all_rows
+        back, _ = all_to_all_rows(dout.contiguous(), ctx.recv_rows, ctx.send_rows, ctx.group)
+        if back.shape[0] < ctx.n_in:  # rows past the kept slots were never sent
+            pad = torch.zeros((ctx.n_in - back.shape[0], back.shape[1]), dtype=back.dtype, device=back.device)
+            back = torch.cat([back, pad], 0)
+        return back, None, None, None
+
+
+class _GroupFFN(torch.autograd.Function):
+    """rows [n, d] in G groups (group g uses expert group_expert[g], or g) -> Y [n, d]."""
+
+    @staticmethod
+    def forward(ctx, rows, w1, b1, w2, b2, mod, offsets, group_expert, drop_mask):
+        cd = rows.dtype
+        ex = mod.experts
+        w1c, w2c = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
+        Hp = ops.grouped_gemm(rows, w1c, b1.detach().float() if b1 is not None else None, offsets, ops.EPI_NONE, cd,
+                              variant=mod.gemm_variant, group_expert=group_expert)
+        A = ops.gelu(Hp)
+        if drop_mask is not None:
+            A = A * drop_mask
+        Y = ops.grouped_gemm(A, w2c, b2.detach().float() if b2 is not None else None, offsets, ops.EPI_NONE, cd,
+                             variant=mod.gemm_variant, group_expert=group_expert)
+        ctx.mod = mod
+        ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
+        ctx.has_map, ctx.has_drop = group_expert is not None, drop_mask is not None
+        ctx.save_for_backward(rows, Hp, A, offsets,
+                              group_expert if group_expert is not None else torch.empty(0, device=rows.device),
+                              drop_mask if drop_mask is not None else torch.empty(0, device=rows.device))
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        rows, Hp, A, offsets, gmap, drop_mask = ctx.saved_tensors
+        mod = ctx.mod
+        cd = rows.dtype
+        gexp = gmap if ctx.has_map else None
+        ex = mod.experts
+        E_local = ex.htoh4.weight.shape[0]
+        G = offsets.numel() - 1
+        n = rows.shape[0]
+        dY = dY.contiguous()
+        w2t = ex.h4toh.weight_as(cd).transpose(1, 2).contiguous()                        # [E, h, d]  (N = h, K = d)
+        if ctx.has_drop:
+            dA = ops.grouped_gemm(dY, w2t, None, offsets, ops.EPI_NONE, cd, variant=mod.gemm_variant, group_expert=gexp)
+            dA = dA * drop_mask
+            hp = Hp.float()  # gelu'(H) unfused on this (rare) path
+            cdf = 0.5 * (1 + torch.erf(hp * 0.7071067811865476))
+            dH = (dA.float() * (cdf + hp * torch.exp(-0.5 * hp * hp) * 0.3989422804014327)).to(cd)
+        else:
+            dH = ops.grouped_gemm(dY, w2t, None, offsets, ops.EPI_GELU_GRAD, cd, variant=mod.gemm_variant,
+                                  group_expert=gexp, residual=Hp)
+        offp = ops.pad_offsets(offsets)
+        Lp = ops.padded_len(n, G)
+        dW2 = ops.grouped_wgrad(ops.transpose_pad(dY, offsets, offp, Lp), ops.transpose_pad(A, offsets, offp, Lp), offp)
+        dW1 = ops.grouped_wgrad(ops.transpose_pad(dH, offsets, offp, Lp), ops.transpose_pad(rows, offsets, offp, Lp), offp)
+        db2 = ops.group_colsum(dY, offsets) if ctx.has_b2 else None
+        db1 = ops.group_colsum(dH, offsets) if ctx.has_b1 else None
+        if G != E_local:  # rank-major groups (source rank, local expert): fold the source ranks
+            dW2, dW1 = dW2.view(-1, E_local, *dW2.shape[1:]).sum(0), dW1.view(-1, E_local, *dW1.shape[1:]).sum(0)
+            db2 = db2.view(-1, E_local, db2.shape[1]).sum(0) if db2 is not None else None
+            db1 = db1.view(-1, E_local, db1.shape[1]).sum(0) if db1 is not None else None
+        drows = None
+        if ctx.needs_input_grad[0]:
+            w1t = ex.htoh4.weight_as(cd).transpose(1, 2).contiguous()                    # [E, d, h]  (N = d, K = h)
+            drows = ops.grouped_gemm(dH, w1t, None, offsets, ops.EPI_NONE, cd, variant=mod.gemm_variant,
+                                     group_expert=gexp)
+        return drows, dW1, db1, dW2, db2, None, None, None, None
+
+
+def _route_train(mod, x):
+    """HIP routing + the differentiable gate score; returns (idx, score, plan tensors)."""
     from .fmoe import SwitchGate
 
-    if mod.world_size > 1 or getattr(mod, "force_ep", False):
-        raise NotImplementedError("expert-parallel training is not built yet; use world_size=1 for backward")
-    if mod._generic_act is not None or not mod._fused_gelu:
-        raise NotImplementedError("training path supports the reference's GELU(+Dropout) activation only")
-    shape = inp.shape
-    d, k = mod.d_model, mod.top_k
-    x = inp.reshape(-1, d)
-    if not x.is_contiguous():
-        x = x.contiguous()
-    T = x.shape[0]
     g = mod.gate
+    k = mod.top_k
+    T = x.shape[0]
     is_switch = isinstance(g, SwitchGate)
     noise = g.make_noise(T, x.device) if is_switch else None
     gw = g.gate.weight.detach().float().contiguous()
@@ -125,8 +173,7 @@ def moe_forward_train(mod, inp: torch.Tensor) -> torch.Tensor:
         cap = g.capacity(T)
         counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, g.tot_expert, cap)
     mod.last_plan = (idx, score_c, counts, offsets, pos, inv_pos)
-    # differentiable gate score (tiny [T,E] work) -- the routing itself stays the HIP router's
-    if is_switch or k > 1:
+    if is_switch or k > 1:  # tiny [T,E] work -- the routing itself stays the HIP router's
         logits = F.linear(x.float(), g.gate.weight.float(), g.gate.bias.float() if g.gate.bias is not None else None)
         if is_switch:
             if noise is not None:
@@ -138,12 +185,47 @@ def moe_forward_train(mod, inp: torch.Tensor) -> torch.Tensor:
             score = torch.softmax(logits.gather(1, idx), dim=-1)
     else:
         score = score_c  # top-1 naive gate: softmax over one logit == 1, no gradient (SURVEY.md 'DDP + top-1')
+    return score, counts, offsets, pos, inv_pos
+
+
+def moe_forward_train(mod, inp: torch.Tensor) -> torch.Tensor:
+    """FMoETransformerMLP.forward with autograd: single rank, or expert parallel (one exchange each way)."""
+    if mod._generic_act is not None or not mod._fused_gelu:
+        raise NotImplementedError("training path supports the reference's GELU(+Dropout) activation only")
+    cd = mod.compute_dtype or _default_cd()
+    if cd == torch.float32:
+        raise NotImplementedError("training needs a 16-bit compute dtype (the wgrad GEMM takes f16 / bf16 operands)")
+    shape = inp.shape
+    d, k = mod.d_model, mod.top_k
+    x = inp.reshape(-1, d)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    T = x.shape[0]
+    score, counts, offsets, pos, inv_pos = _route_train(mod, x)
+    ex = mod.experts
+    ep = mod.world_size > 1 or getattr(mod, "force_ep", False)
+    S = _Scatter.apply(x, pos, inv_pos, k, cd)
+    if ep:
+        from .ep import exchange_counts, segment_table
+        lec, gec = exchange_counts([counts], mod.world_size, mod.moe_group)
+        send_rows, recv_rows = lec[0].sum(1).tolist(), gec[0].sum(1).tolist()
+        rows = _AllToAll.apply(S, send_rows, recv_rows, mod.moe_group)
+        offs, gexp = segment_table(gec[0])
+        g_offsets = torch.tensor(offs, dtype=torch.int32, device=x.device)
+        g_map = torch.tensor(gexp, dtype=torch.int32, device=x.device)
+    else:
+        rows, g_offsets, g_map = S, offsets, None
     drop_mask = None
     if mod._drop_p > 0 and mod.training:
-        cd = mod.compute_dtype or _default_cd()
         keep = 1.0 - mod._drop_p
-        drop_mask = (torch.rand(pos.numel(), mod.d_hidden, device=x.device) < keep).to(cd) / keep
-    ex = mod.experts
-    out = _ExpertFFN.apply(x, score, ex.htoh4.weight, ex.htoh4.bias, ex.h4toh.weight, ex.h4toh.bias, mod, offsets, pos,
-                           inv_pos, drop_mask)
+        drop_mask = (torch.rand(rows.shape[0], mod.d_hidden, device=x.device) < keep).to(cd) / keep
+    Y = _GroupFFN.apply(rows, ex.htoh4.weight, ex.htoh4.bias, ex.h4toh.weight, ex.h4toh.bias, mod, g_offsets, g_map,
+                        drop_mask)
+    if ep:
+        back = _AllToAll.apply(Y, recv_rows, send_rows, mod.moe_group)
+        if back.shape[0] < pos.numel():  # slots past the kept count carry no row
+            back = torch.cat([back, back.new_zeros(pos.numel() - back.shape[0], d)], 0)
+    else:
+        back = Y
+    out = _Combine.apply(back, score, pos, inv_pos, k, x.dtype)
     return out.reshape(shape)

@@ -128,6 +128,40 @@ def test_cfg5_switch_capacity_aux_backward():
     assert _rel(xg.grad.cpu()[dropped], leaves[0].grad[dropped]) < 5e-3
 
 
+def test_expert_parallel_training_path_on_one_gpu():
+    """fwd + bwd through the expert-parallel code path (count exchange, all-to-all-v each way and their adjoints,
+    grouped GEMMs / wgrad with the group -> expert map) on a world of one rank == the single-rank training path."""
+    import socket
+    import torch.distributed as dist
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        T, d, h, E = 900, 128, 256, 4
+        x, wg, bg, w1, b1, w2, b2, gout = _params(T, d, h, E, seed=5, skew=True)
+        grads = {}
+        for mode in ("single", "ep"):
+            mod = sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=1, gate="switch", capacity_factor=1.0).to(DEV)
+            mod.gate.switch_eps = 0.0
+            with torch.no_grad():
+                mod.gate.gate.weight.copy_(wg); mod.gate.gate.bias.copy_(bg)
+                mod.experts.htoh4.weight.copy_(w1); mod.experts.htoh4.bias.copy_(b1)
+                mod.experts.h4toh.weight.copy_(w2); mod.experts.h4toh.bias.copy_(b2)
+            mod.train()
+            mod.force_ep = mode == "ep"
+            xg = x.to(DEV).requires_grad_(True)
+            out = mod(xg)
+            ((out * gout.to(DEV)).sum() + 2.0 * mod.gate.get_loss()).backward()
+            grads[mode] = [out.detach(), xg.grad] + [p.grad for p in mod.parameters()]
+        for a, b in zip(grads["single"], grads["ep"]):
+            assert _rel(b.cpu(), a.cpu()) < 1e-3
+    finally:
+        dist.destroy_process_group()
+
+
 def test_block_level_training_step_runs():
     m = sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=10).to(DEV).train()
     opt = torch.optim.SGD(m.parameters(), lr=0.01)
