@@ -113,3 +113,43 @@ def test_segment_table_and_chunk_bounds():
     assert ep.chunk_bounds(10, 3) == [(0, 3), (3, 6), (6, 10)]
     assert ep.chunk_bounds(2, 4) == [(0, 1), (1, 2)]
     assert ep.chunk_bounds(0, 2) == [(0, 0)]
+
+
+def _a2a_grad_worker(rank, W, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        from slim_switch_moe_vit_amd.autograd import _AllToAll
+
+        g = torch.Generator().manual_seed(7)
+        counts = torch.randint(0, 5, (W, W), generator=g)           # counts[src, dst] rows
+        send = counts[rank].tolist()
+        recv = counts[:, rank].tolist()
+        rows = torch.arange(sum(send) * 3, dtype=torch.float32).reshape(-1, 3) + 100 * rank
+        rows.requires_grad_(True)
+        out = _AllToAll.apply(rows, send, recv, None)
+        w = torch.arange(out.numel(), dtype=torch.float32).reshape(out.shape) + 7 * rank  # d(out): known per receiver
+        (out * w).sum().backward()
+        # the gradient of a row is the weight it met at its destination: send it back with a plain exchange
+        from slim_switch_moe_vit_amd.ep import all_to_all_rows
+        back, _ = all_to_all_rows(w, recv, send)
+        q.put((rank, bool(torch.equal(rows.grad, back)), out.shape[0] == sum(recv)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_to_all_autograd_adjoint_is_the_reverse_exchange():
+    W = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_a2a_grad_worker, args=(r, W, port, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    for p in procs:
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(W))
+    assert all(ok and shp for _, ok, shp in got)
