@@ -64,3 +64,21 @@ def test_resmoe_factory_forward_matches_oracle_block_semantics():
         out = model(images.to(DEV)).cpu()
     assert model.blocks[0].moe_gate._skipped_tokens > 0
     assert (out - ref).abs().max().item() <= 5e-3
+
+
+def test_cfg4_vit_large_384_e32_shapes_run_and_match_oracle():
+    """BASELINE cfg 4 shapes (ViT-L/16 @384: 577 tokens, d 1024, h 4096, E=32, top-1) on a 1-block copy of the model:
+    general router (E > 8), SDPA fallback for N > 256, default GEMM variant; vs the oracle in fp32 mode."""
+    torch.manual_seed(0)
+    model = _init(sm.create_model("moe_large_patch16_384_expert32_top1", num_classes=10, depth=1,
+                                  compute_dtype=torch.float32), 9).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    images = torch.randn(2, 3, 384, 384, generator=torch.Generator().manual_seed(4))
+    ref = mo.vit_forward(images, sd, depth=1, num_heads=16, k=1, residual_moe=False)
+    model = model.to(DEV)
+    with torch.no_grad():
+        out = model(images.to(DEV)).cpu()
+        with torch.autocast("cuda", dtype=torch.float16):
+            out16 = model(images.to(DEV)).float().cpu()
+    assert (out - ref).abs().max().item() <= 2e-3
+    assert (out16 - ref).abs().max().item() <= 5e-2
