@@ -267,10 +267,10 @@ class VisionTransformer(nn.Module):
         return self.head(self.forward_features(x))
 
 
-def _deit(embed_dim, depth, num_heads, pretrained=False, **kwargs):
+def _deit(embed_dim, default_depth, num_heads, pretrained=False, **kwargs):
     if pretrained:
         raise RuntimeError("pretrained weights need network access (torch.hub); not available offline")
-    depth = kwargs.pop("depth", depth)  # tests build shallow copies of the big configurations
+    depth = kwargs.pop("depth", default_depth)  # tests build shallow copies of the big configurations
     return VisionTransformer(patch_size=16, embed_dim=embed_dim, depth=depth, num_heads=num_heads, mlp_ratio=4,
                              qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
 
