@@ -24,7 +24,9 @@ def main():
         counts = [M]
     else:
         E, M = 8, 256 * 197
-        K, N = (768, 3072) if shape == "fc1" else (3072, 768)
+        K, N = (768, 3072) if shape in ("fc1", "fc1n") else ((768, 2304) if shape == "qkv" else (3072, 768))
+        if shape == "qkv":
+            E = 1
         base = M // E
         counts = [base] * E
         counts[-1] += M - base * E
