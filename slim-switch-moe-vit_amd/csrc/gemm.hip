@@ -591,7 +591,9 @@ int launch_glds(const void* A, const void* W, const float* bias, const int32_t* 
 // MODE 1 = weight-gradient GEMM: C[e] = P^T[:, k-range e] (Q^T[:, k-range e])^T with both operands stored K-major
 // ([rows, Lp], per-expert column ranges padded to multiples of 64: smoe_transpose_pad); `offsets` are the
 // padded ranges, K = Lp (row stride), N = rows of Q^T, m_rows = rows of P^T, one [m_rows, N] output per expert.
-template <typename AB, typename OT, int ABL = 0, int MODE = 0>
+// AFR = A row fragments per wave per A-half: tile height TBM = 64 * AFR (256 or 320 rows).  The taller tile cuts the
+// tile count (fc2 / proj at cfg 2: 600 -> 480 tiles = 2 instead of 3 rounds on 256 CUs) and raises FLOP per LDS-fill byte.
+template <typename AB, typename OT, int ABL = 0, int MODE = 0, int AFR = 4>
 __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
@@ -599,9 +601,12 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     int group_m, int m_rows, const int64_t* __restrict__ a_gather, int a_div) {
   static_assert(sizeof(AB) == 2, "16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int TBM = 256, TBN = 256, NT = 512, NW = 8;
-  constexpr int STAGE = (TBM + TBN) * BK_BYTES;  // 64 KiB
-  constexpr int SLOTS = 4;                       // 1-KiB DMA pieces per wave per operand per K-tile
+  constexpr int TBM = 64 * AFR, TBN = 256, NT = 512, NW = 8;
+  constexpr int STAGE = (TBM + TBN) * BK_BYTES;  // 64 KiB (72 KiB for the 320-row tile)
+  constexpr int ASLOTS = TBM / 8 / NW;           // 1-KiB DMA pieces per wave per K-tile: A (= AFR)
+  constexpr int SLOTS = 4;                       //                                        W
+  static_assert(AFR == 4 || AFR == 5, "tile height 256 or 320");
+  static_assert(AFR == 4 || (ABL & 8) == 0, "the experimental schedule is written for the 256-row tile");
 
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
@@ -636,28 +641,41 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   const int wr = wave >> 2, wc = wave & 3;
 
   const int l_row = lane >> 3, l_pos = lane & 7;
-  const AB* a_src[SLOTS];
+  const AB* a_src[ASLOTS];
   const AB* w_src[SLOTS];
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) {
+  for (int s = 0; s < ASLOTS; ++s) {
     const int r = 8 * (s * NW + wave) + l_row;
     int gr = m0 + r;
     if (gr >= m_end) gr = m_end - 1;
     // optional row gather (fused MOEScatter): tile row gr reads source row a_gather[gr] / a_div
     const int64_t arow = (MODE == 0 && a_gather) ? a_gather[gr] / a_div : (int64_t)gr;
     a_src[s] = A + arow * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int r = 8 * (s * NW + wave) + l_row;
     int gw = n0 + r;
     if (gw >= N) gw = N - 1;
     w_src[s] = W + ((int64_t)(MODE == 0 ? e : 0) * N + gw) * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
   }
-  // DMA of pieces [s0, s0+2) of A or W of K-tile kt into buffer buf
+  // DMA of A pieces of K-tile kt into buffer buf: "lo" (s0 == 0) = slots 0,1 (tile rows 0-127, read by wave group 0
+  // only), "hi" = slots 2.. (the rest; for the 320-row tile slot 2 straddles the two groups' rows and is re-staged
+  // with the group-1 region, after BOTH groups' last reads of it have retired)
   auto dma_a = [&](int kt, int buf, int s0) {
     if ((ABL & 1) && kt >= 2) return;
     char* sa = smem + buf * STAGE;
+    if (s0 == 0) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s0 + s] + kt * 64),
-                                       (__attribute__((address_space(3))) void*)(sa + ((s0 + s) * NW + wave) * 1024), 16, 0, 0);
+      for (int s = 0; s < 2; ++s)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s] + kt * 64),
+                                         (__attribute__((address_space(3))) void*)(sa + (s * NW + wave) * 1024), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int s = 2; s < ASLOTS; ++s)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s] + kt * 64),
+                                         (__attribute__((address_space(3))) void*)(sa + (s * NW + wave) * 1024), 16, 0, 0);
+    }
   };
   auto dma_a1 = [&](int kt, int buf, int s1) {  // one 1-KiB piece
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s1] + kt * 64),
@@ -676,18 +694,18 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
                                        (__attribute__((address_space(3))) void*)(sw + ((s0 + s) * NW + wave) * 1024), 16, 0, 0);
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[2 * AFR][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * AFR; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 ar[4][2], br[2][2];  // current A-half (4 row fragments x 2 k-steps), B-half (2 col fragments x 2 k-steps)
+  u32x4 ar[AFR][2], br[2][2];  // current A-half (AFR row fragments x 2 k-steps), B-half (2 col fragments x 2 k-steps)
 
   const int fr = lane & 15, fq = lane >> 4;
 
   if (ABL & 2) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < AFR; ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) ar[i][kk] = u32x4{0x3c003800u + lane, 0xbc003400u, 0x38003c00u, 0x3400b800u + i};
 #pragma unroll
@@ -697,9 +715,9 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   }
   auto read_a = [&](int buf, int half) {
     if (ABL & 2) { asm volatile("" : "+v"(ar[0][0]), "+v"(ar[1][1])); return; }
-    const char* sa = smem + buf * STAGE + (wr * 128 + half * 64) * BK_BYTES;
+    const char* sa = smem + buf * STAGE + (wr * (TBM / 2) + half * (16 * AFR)) * BK_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < AFR; ++i)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) ar[i][kk] = *reinterpret_cast<const u32x4*>(sa + swz(i * 16 + fr, kk * 4 + fq));
   };
@@ -713,16 +731,16 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   };
 #define PP_MFMA(AH, BH)                                                                                              \
   do {                                                                                                               \
-    if (ABL & 4) { asm volatile("" :: "v"(ar[0][0]), "v"(ar[3][1]), "v"(br[0][0]), "v"(br[1][1])); break; }          \
+    if (ABL & 4) { asm volatile("" :: "v"(ar[0][0]), "v"(ar[AFR - 1][1]), "v"(br[0][0]), "v"(br[1][1])); break; }          \
     __builtin_amdgcn_s_setprio(1);                                                                                   \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < 4; ++i)                   \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < AFR; ++i)                 \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
       if constexpr (std::is_same<AB, f16>::value)                                                                    \
-        acc[(AH)*4 + i][(BH)*2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                        \
-            __builtin_bit_cast(f16x8, br[j][kk]), __builtin_bit_cast(f16x8, ar[i][kk]), acc[(AH)*4 + i][(BH)*2 + j], 0, 0, 0); \
+        acc[(AH)*AFR + i][(BH)*2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                        \
+            __builtin_bit_cast(f16x8, br[j][kk]), __builtin_bit_cast(f16x8, ar[i][kk]), acc[(AH)*AFR + i][(BH)*2 + j], 0, 0, 0); \
       else                                                                                                           \
-        acc[(AH)*4 + i][(BH)*2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                       \
-            __builtin_bit_cast(bf16x8_t, br[j][kk]), __builtin_bit_cast(bf16x8_t, ar[i][kk]), acc[(AH)*4 + i][(BH)*2 + j], 0, 0, 0); \
+        acc[(AH)*AFR + i][(BH)*2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                       \
+            __builtin_bit_cast(bf16x8_t, br[j][kk]), __builtin_bit_cast(bf16x8_t, ar[i][kk]), acc[(AH)*AFR + i][(BH)*2 + j], 0, 0, 0); \
     }                                                                                                                \
     __builtin_amdgcn_s_setprio(0);                                                                                   \
   } while (0)
@@ -732,7 +750,8 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   dma_a(0, 0, 0); dma_a(0, 0, 2); dma_w(0, 0, 0); dma_w(0, 0, 2);
   if (nk > 1) {
     dma_a(1, 1, 0); dma_a(1, 1, 2); dma_w(1, 1, 0); dma_w(1, 1, 2);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (AFR == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 1's pieces may stay in flight
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -834,13 +853,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
 #undef PP_MFMA
 
   // ---- epilogue in row passes through LDS (same as the glds variants) --------------------------------
-  constexpr int TM = 128, TN = 64, MI = 8, NI = 4;
+  constexpr int TM = TBM / 2, TN = 64, MI = 2 * AFR, NI = 4;
   constexpr int OB = OutPack<OT>::bytes;
   constexpr int C_STRIDE = TBN * OB + C_PAD;
   constexpr int LDS_BYTES = 2 * STAGE;
-  constexpr int RP = (TBM * C_STRIDE <= LDS_BYTES) ? TBM : ((TBM / 2) * C_STRIDE <= LDS_BYTES ? TBM / 2 : TBM / 4);
+  // passes: the smallest divisor of MI / 2 .. whose row block fits in LDS
+  constexpr int NPASS = (TBM * C_STRIDE <= LDS_BYTES) ? 1 : ((TBM / 2) * C_STRIDE <= LDS_BYTES ? 2 : (AFR == 4 ? 4 : 5));
+  constexpr int RP = TBM / NPASS;
   static_assert(RP * C_STRIDE <= LDS_BYTES, "epilogue pass does not fit in LDS");
-  constexpr int NPASS = TBM / RP;
   constexpr int CHUNKS = TBN * OB / 16;   // 16-B chunks per tile row
   constexpr int TPR = 16;                 // threads per output row: 16 consecutive threads = 256 contiguous bytes
   constexpr int CPT = CHUNKS / TPR;       // chunks per thread per row (strided by 256 B)
@@ -924,18 +944,18 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   }
 }
 
-template <typename AB, typename OT, int ABL = 0>
+template <typename AB, typename OT, int ABL = 0, int AFR = 4>
 int launch_pp256(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                  int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
                  const void* residual, void* out, int group_m, hipStream_t s, const int64_t* a_gather = nullptr,
                  int a_div = 1) {
-  constexpr int TBM = 256, TBN = 256;
+  constexpr int TBM = 64 * AFR, TBN = 256;
   const int n_tiles_n = (N + TBN - 1) / TBN;
   const int max_m_tiles = (int)((m_rows_max + TBM - 1) / TBM) + E;
   const int m_groups = (max_m_tiles + group_m - 1) / group_m;
   const int grid = m_groups * group_m * n_tiles_n;
   const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
-  auto kern = grouped_gemm_pp256<AB, OT, ABL>;
+  auto kern = grouped_gemm_pp256<AB, OT, ABL, 0, AFR>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -975,6 +995,16 @@ int launch_wgrad(const void* PT, const void* QT, const int32_t* offsets_pad, int
   return 0;
 }
 
+inline int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
 template <typename AB, typename OT>
 int launch_variant(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets,
                    const int32_t* group_expert, int E, int64_t m_rows_max, int K, int N, int epilogue,
@@ -985,7 +1015,17 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
       case 1: return launch_glds<AB, OT, 128, 128, 2, 2, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 8, s);
       case 2: return launch_glds<AB, OT, 256, 128, 2, 2, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
       case 3: return launch_glds<AB, OT, 256, 256, 2, 4, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
-      case 4: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+      case 4: {  // auto: 256- or 320-row tiles, whichever needs fewer (cost-weighted) rounds of workgroups
+        const int ntn = (N + 255) / 256;
+        const int64_t t256 = ((m_rows_max + 255) / 256 + E) * ntn, t320 = ((m_rows_max + 319) / 320 + E) * ntn;
+        const int cus = num_cus();
+        const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c320 = (double)((t320 + cus - 1) / cus) * 1.25;
+        if (c320 < c256)
+          return launch_pp256<AB, OT, 0, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+        return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+      }
+      case 5: return launch_pp256<AB, OT, 0, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+      case 6: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
 #ifdef SMOE_DIAG
       case 41: return launch_pp256<AB, OT, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
       case 42: return launch_pp256<AB, OT, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
@@ -1037,7 +1077,8 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   if (m_rows_max == 0) return 0;
   SMOE_REQUIRE(A && W && out, "smoe_grouped_gemm: null pointer");
   if (K % 64 != 0 || smoe_dtype_size(ab_dtype) != 2) variant = 0;
-  SMOE_REQUIRE(!a_gather || (variant == 4 && a_div >= 1), "smoe_grouped_gemm: a_gather needs variant 4 (16-bit operands, K %% 64 == 0)");
+  SMOE_REQUIRE(!a_gather || ((variant == 4 || variant == 5 || variant == 6) && a_div >= 1),
+               "smoe_grouped_gemm: a_gather needs variant 4-6 (16-bit operands, K %% 64 == 0)");
   hipStream_t s = (hipStream_t)stream;
   switch (ab_dtype) {
     case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div);

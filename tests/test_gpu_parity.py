@@ -169,7 +169,7 @@ def _gemm_ref(A, W, bias, offsets, gelu):
                                         ([700, 650, 600, 800, 655, 690, 710, 640], 768, 3072)])
 @pytest.mark.parametrize("cd,tol", [(torch.float32, 2e-5), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("gelu", [False, True])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu, variant):
     if variant and (cd == torch.float32 or K % 64):
         pytest.skip("glds variants take 16-bit operands and K % 64 == 0")
@@ -191,7 +191,8 @@ def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu, varian
 
 
 @pytest.mark.parametrize("variant,cd", [(0, torch.float32), (0, torch.float16), (1, torch.float16), (3, torch.float16),
-                                        (3, torch.bfloat16), (4, torch.float16), (4, torch.bfloat16)])
+                                        (3, torch.bfloat16), (4, torch.float16), (4, torch.bfloat16), (5, torch.float16),
+                                        (5, torch.bfloat16), (6, torch.float16)])
 def test_grouped_gemm_fused_combine_row_map(variant, cd):
     E, K, N, T = 4, 128, 64, 1000
     g = _gen(3)
@@ -213,7 +214,7 @@ def test_grouped_gemm_fused_combine_row_map(variant, cd):
     assert (out.cpu().double() - ref).abs().max() < (2e-5 if cd == torch.float32 else 1e-4)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6])
 def test_grouped_gemm_variants_are_race_free_and_agree_bitwise(variant):
     """The staged variants hand tiles between waves through LDS DMA + barriers; a missing wait shows up as
     rare wrong tiles.  Same inputs, 15 launches, ragged groups, long K: every launch must be bit-identical
