@@ -1020,7 +1020,7 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
         const int64_t t256 = ((m_rows_max + 255) / 256 + E) * ntn, t320 = ((m_rows_max + 319) / 320 + E) * ntn;
         const int cus = num_cus();
         const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c320 = (double)((t320 + cus - 1) / cus) * 1.25;
-        if (c320 < c256)
+        if (c320 <= c256)  // ties go to the taller tile (more FLOP per LDS-fill byte)
           return launch_pp256<AB, OT, 0, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
         return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
       }
