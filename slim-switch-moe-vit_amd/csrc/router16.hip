@@ -36,12 +36,15 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
+__device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+
 // LN = fused LayerNorm in front of the router (models/vision_transformer.py:321 `mlp(norm2(x))`): the row is
 // normalised in registers (two-pass mean / variance over the 16-lane row, f32), written once as the 16-bit
 // operand image the expert GEMM gathers from (xn16) and optionally as f32 (xn32), and routed on its f32 value.
 // The f64 redo pass recomputes the same normalisation with the same lane layout, hence bit-identical inputs.
 template <typename XT, int NJ, int MODE, bool LN, typename NT>
-__global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_kernel(
+__global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_kernel(
     const XT* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
     NT* __restrict__ xn16, float* __restrict__ xn32, const float* __restrict__ wg, const float* __restrict__ bg,
     const float* __restrict__ noise, int64_t T, int d, int E, int k, int gate_kind,
@@ -50,8 +53,10 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds_w = reinterpret_cast<float*>(smem);            // [R16_E][d], rows >= E zero
   float* lds_wn2 = lds_w + R16_E * d;                        // [R16_E]
-  float* lds_g = lds_wn2 + R16_E;                            // [d] LayerNorm weight, then [d] bias (LN only)
+  float* lds_bias = lds_wn2 + R16_E;                         // [R16_E] gate bias, zero where absent (branch-free add)
+  float* lds_g = lds_bias + R16_E;                           // [d] LayerNorm weight, then [d] bias (LN only)
   float* lds_be = lds_g + d;
+  d = 64 * NJ;  // the launcher only dispatches exact multiples: makes every chunk bound below compile-time
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, u = lane & 15;
   if (MODE == 1 && redo_list && *redo_count == 0) return;  // nothing to redo (the common case): exit before any setup
@@ -61,6 +66,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
     if (i / d < E) v = *reinterpret_cast<const f32x4*>(wg + i);
     *reinterpret_cast<f32x4*>(lds_w + i) = v;
   }
+  if (tid < R16_E) lds_bias[tid] = (bg && tid < E) ? bg[tid] : 0.f;
   if (LN) {
     for (int i = tid; i < d; i += R16_THREADS) {
       lds_g[i] = ln_g ? ln_g[i] : 1.f;
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
 #pragma unroll
   for (int e = 0; e < R16_E; ++e) wmax2 = fmaxf(wmax2, lds_wn2[e]);
 
-  const int nchunk = d >> 2;  // float4 chunks per row
+  constexpr int nchunk = 16 * NJ;  // float4 chunks per row (d = 64 NJ)
   int64_t n_items = T;
   if (MODE == 1 && redo_list) n_items = *redo_count;
   const int64_t slot_gid = ((int64_t)blockIdx.x * (R16_THREADS / 64) + wave) * 4 + q;
@@ -89,48 +95,59 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
   for (int64_t it0 = slot_gid - q; it0 < n_items; it0 += slot_stride) {
     const int64_t it = it0 + q;
     const bool live = it < n_items;
-    const int64_t t = live ? ((MODE == 1 && redo_list) ? (int64_t)redo_list[it] : it) : 0;
-    float xv[NJ][4];
+    // dead slots of the last group re-read the last item (no predication on the loads; only stores are guarded)
+    const int64_t itc = live ? it : n_items - 1;
+    const int64_t t = (MODE == 1 && redo_list) ? (int64_t)redo_list[itc] : itc;
+    const int64_t rowoff = t * (int64_t)d + u * 4;  // this lane's first chunk; chunk j sits 64 j elements further
+    // LDS offset of this lane's first chunk through a per-iteration opaque zero: otherwise the loop-invariant
+    // LDS reads (gamma, beta, all weights) are hoisted out of the token loop and spilled
+    int lz = 0;
+    asm volatile("" : "+v"(lz));
+    const int ub = u * 4 + lz;
+    f32x4 xv[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int c = u + 16 * j;
-      if (live && c < nchunk) load4(x + t * (int64_t)d + c * 4, xv[j]);
-      else xv[j][0] = xv[j][1] = xv[j][2] = xv[j][3] = 0.f;
+      float tmp[4];
+      load4(x + rowoff + 64 * j, tmp);
+      xv[j] = f32x4{tmp[0], tmp[1], tmp[2], tmp[3]};
     }
     if constexpr (LN) {
-      float s1 = 0.f;
+      constexpr float inv_d = 1.0f / (float)(64 * NJ);
+      f32x2 s1 = f32x2{0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) s1 += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
-      const float mean = row16_sum(s1) / (float)d;
-      float s2 = 0.f;
+      for (int j = 0; j < NJ; ++j) s1 += lo2(xv[j]) + hi2(xv[j]);
+      const float mean = row16_sum(s1[0] + s1[1]) * inv_d;
+      const f32x2 mean2 = f32x2{mean, mean};
+      f32x2 s2 = f32x2{0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int c = u + 16 * j;
-        if (c < nchunk) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { const float dv = xv[j][i] - mean; s2 = fmaf(dv, dv, s2); }
-        }
+        const f32x2 a = lo2(xv[j]) - mean2, b = hi2(xv[j]) - mean2;
+        s2 = __builtin_elementwise_fma(a, a, s2);
+        s2 = __builtin_elementwise_fma(b, b, s2);
       }
-      const float rstd = rsqrtf(row16_sum(s2) / (float)d + ln_eps);
+      const float rstd = rsqrtf(row16_sum(s2[0] + s2[1]) * inv_d + ln_eps);
+      const f32x4 mean4 = f32x4{mean, mean, mean, mean}, rstd4 = f32x4{rstd, rstd, rstd, rstd};
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int c = u + 16 * j;
-        if (c < nchunk) {
-          const f32x4 gg = *reinterpret_cast<const f32x4*>(lds_g + c * 4);
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(lds_be + c * 4);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(lds_g + ub + 64 * j);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(lds_be + ub + 64 * j);
+        xv[j] = __builtin_elementwise_fma((xv[j] - mean4) * rstd4, gg, bb);
+      }
+      if (MODE == 0 && live) {
+        if (xn32) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) xv[j][i] = fmaf((xv[j][i] - mean) * rstd, gg[i], bb[i]);
-          if (MODE == 0 && live) {
-            if (xn32) *reinterpret_cast<f32x4*>(xn32 + t * (int64_t)d + c * 4) = f32x4{xv[j][0], xv[j][1], xv[j][2], xv[j][3]};
-            if (xn16) {
-              if constexpr (std::is_same<NT, f16>::value) {
-                f16x4 o; o[0] = (f16)xv[j][0]; o[1] = (f16)xv[j][1]; o[2] = (f16)xv[j][2]; o[3] = (f16)xv[j][3];
-                *reinterpret_cast<f16x4*>(xn16 + t * (int64_t)d + c * 4) = o;
-              } else {
-                s16x4 o; o[0] = (short)f32_to_bf16(xv[j][0]); o[1] = (short)f32_to_bf16(xv[j][1]);
-                o[2] = (short)f32_to_bf16(xv[j][2]); o[3] = (short)f32_to_bf16(xv[j][3]);
-                *reinterpret_cast<s16x4*>(xn16 + t * (int64_t)d + c * 4) = o;
-              }
+          for (int j = 0; j < NJ; ++j) *reinterpret_cast<f32x4*>(xn32 + rowoff + 64 * j) = xv[j];
+        }
+        if (xn16) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            if constexpr (std::is_same<NT, f16>::value) {
+              f16x4 o; o[0] = (f16)xv[j][0]; o[1] = (f16)xv[j][1]; o[2] = (f16)xv[j][2]; o[3] = (f16)xv[j][3];
+              *reinterpret_cast<f16x4*>(xn16 + rowoff + 64 * j) = o;
+            } else {
+              s16x4 o; o[0] = (short)f32_to_bf16(xv[j][0]); o[1] = (short)f32_to_bf16(xv[j][1]);
+              o[2] = (short)f32_to_bf16(xv[j][2]); o[3] = (short)f32_to_bf16(xv[j][3]);
+              *reinterpret_cast<s16x4*>(xn16 + rowoff + 64 * j) = o;
             }
           }
         }
@@ -138,43 +155,38 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
     }
     float lg[R16_E];
     if constexpr (MODE == 0) {
-      float acc[R16_E];
+      // two partial sums per expert (even / odd element pairs): packed f32 FMAs, half the issue slots
+      f32x2 acc[R16_E];
 #pragma unroll
-      for (int e = 0; e < R16_E; ++e) acc[e] = 0.f;
+      for (int e = 0; e < R16_E; ++e) acc[e] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int c = u + 16 * j;
-        if (c < nchunk) {
 #pragma unroll
-          for (int e = 0; e < R16_E; ++e) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(lds_w + e * d + c * 4);
-            acc[e] = fmaf(xv[j][0], w[0], acc[e]);
-            acc[e] = fmaf(xv[j][1], w[1], acc[e]);
-            acc[e] = fmaf(xv[j][2], w[2], acc[e]);
-            acc[e] = fmaf(xv[j][3], w[3], acc[e]);
-          }
+        for (int e = 0; e < R16_E; ++e) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(lds_w + ub + (e * d + 64 * j));
+          acc[e] = __builtin_elementwise_fma(lo2(xv[j]), lo2(w), acc[e]);
+          acc[e] = __builtin_elementwise_fma(hi2(xv[j]), hi2(w), acc[e]);
         }
+        __builtin_amdgcn_sched_barrier(0);  // one chunk's weight reads next to their FMAs (else: e-major reorder + spills)
       }
 #pragma unroll
-      for (int e = 0; e < R16_E; ++e) lg[e] = row16_sum(acc[e]) + ((bg && e < E) ? bg[e] : 0.f);
+      for (int e = 0; e < R16_E; ++e) lg[e] = row16_sum(acc[e][0] + acc[e][1]) + lds_bias[e];
     } else {
       double acc[R16_E];
 #pragma unroll
       for (int e = 0; e < R16_E; ++e) acc[e] = 0.0;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int c = u + 16 * j;
-        if (c < nchunk) {
 #pragma unroll
-          for (int e = 0; e < R16_E; ++e) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(lds_w + e * d + c * 4);
+        for (int e = 0; e < R16_E; ++e) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(lds_w + ub + (e * d + 64 * j));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[e] = fma((double)xv[j][i], (double)w[i], acc[e]);
-          }
+          for (int i = 0; i < 4; ++i) acc[e] = fma((double)xv[j][i], (double)w[i], acc[e]);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int e = 0; e < R16_E; ++e) lg[e] = (float)(row16_sum(acc[e]) + ((bg && e < E) ? (double)bg[e] : 0.0));
+      for (int e = 0; e < R16_E; ++e) lg[e] = (float)(row16_sum(acc[e]) + (double)lds_bias[e]);
     }
     if (logits_out && live && u == 0) {
 #pragma unroll
@@ -186,26 +198,33 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 3 : 2)) void router16_ker
       for (int e = 0; e < R16_E; ++e)
         if (e < E) lg[e] += noise[t * (int64_t)E + e];
     }
-    // top-kc in registers: ties -> lowest id, descending value
+    // top-kc in registers: ties -> lowest id, descending value.  Working copy with absent / already chosen
+    // experts at -inf; strict > keeps the lowest id among equals.
     const int kc = (MODE == 0 && k < E) ? k + 1 : k;
     int chosen[R16_MAX_K + 1];
     float cval[R16_MAX_K + 1];
-    unsigned taken = 0;
+    float lw[R16_E];
+#pragma unroll
+    for (int e = 0; e < R16_E; ++e) lw[e] = (e < E) ? lg[e] : -INFINITY;
 #pragma unroll
     for (int r = 0; r <= R16_MAX_K; ++r) {
       chosen[r] = 0;
       cval[r] = 0.f;
       if (r < kc) {
-        float bv = -INFINITY;
-        int bi = -1;
+        float bv = lw[0];
+        int bi = 0;
 #pragma unroll
-        for (int e = 0; e < R16_E; ++e) {
-          const bool ok = (e < E) && !((taken >> e) & 1u);
-          if (ok && (bi < 0 || lg[e] > bv)) { bv = lg[e]; bi = e; }
+        for (int e = 1; e < R16_E; ++e) {
+          const bool gt = lw[e] > bv;
+          bv = gt ? lw[e] : bv;
+          bi = gt ? e : bi;
         }
         chosen[r] = bi;
         cval[r] = bv;
-        taken |= 1u << bi;
+        if (r + 1 < kc) {
+#pragma unroll
+          for (int e = 0; e < R16_E; ++e) lw[e] = (e == bi) ? -INFINITY : lw[e];
+        }
       }
     }
     if constexpr (MODE == 0) {
@@ -351,7 +370,7 @@ template <typename XT, int NJ, bool LN, typename NT>
 int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, const float* noise, int64_t T, int d,
              int E, int k, int gate_kind, int force_f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score,
              float* logits_out, float* probs, hipStream_t s) {
-  const size_t smem = ((size_t)R16_E * d + R16_E + (LN ? 2 * (size_t)d : 0)) * 4;
+  const size_t smem = ((size_t)R16_E * d + 2 * R16_E + (LN ? 2 * (size_t)d : 0)) * 4;
   const int64_t tok_per_block = (R16_THREADS / 64) * 4;
   int64_t need = (T + tok_per_block - 1) / tok_per_block;
   // <= 768 workgroups (3 resident per CU, the LDS weight image is loaded once per workgroup), every workgroup
