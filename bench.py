@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--experts", type=int, default=8, help="global number of experts")
     ap.add_argument("--compute-dtype", default=os.environ.get("SLIMMOE_COMPUTE_DTYPE", "f16"), choices=["f16", "bf16", "f32"])
     ap.add_argument("--ep-chunks", type=int, default=1)
+    ap.add_argument("--ep-micro-batches", type=int, default=2,
+                    help="expert parallel only: micro-batches of the local batch interleaved through the model so that "
+                         "count read-backs and all-to-alls of one run under the other's compute (1 = off)")
     ap.add_argument("--cpu-batch", type=int, default=16, help="images in the CPU-oracle sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -78,6 +81,7 @@ def build_model(args, world, rank, device):
             blk.mlp.force_ep = bool(getattr(args, "force_ep", False))
             # the head is zero-initialised in the reference (vision_transformer.py:859-861); give it signal
         torch.nn.init.trunc_normal_(model.head.weight, std=0.02, a=-2, b=2, generator=g)
+    model.ep_micro_batches = args.ep_micro_batches
     sd_cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -232,7 +236,7 @@ def main():
             "config": {"workload": f"ViT-B/16 Switch-MoE E={args.experts} top-1, 224^2, batch {args.batch}/GPU, "
                                    f"full eval forward (12 blocks: attention + MoE MLP), fp16 autocast",
                        "global_batch": args.batch * world, "tokens_per_image": 197,
-                       "parallelism": ("single" if not args.force_ep else "single (EP code path forced)") if world == 1 else f"ep{world} (experts/{world} per rank, all-to-all, {args.ep_chunks} chunks)"},
+                       "parallelism": ("single" if not args.force_ep else f"single (EP code path forced, {args.ep_micro_batches} interleaved micro-batches)") if world == 1 else f"ep{world} (experts/{world} per rank, all-to-all, {args.ep_micro_batches} interleaved micro-batches)"},
             "roofline": roofline,
             "kernels": kernels,
         }

@@ -28,21 +28,71 @@ import torch
 import torch.distributed as dist
 
 
-def exchange_counts(counts_per_chunk: List[torch.Tensor], world_size: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+class _PinnedPool:
+    """Reusable pinned host buffers for the count read-back (hipHostMalloc per layer would cost more than the copy)."""
+
+    def __init__(self):
+        self.free = {}
+
+    def take(self, shape, dtype) -> torch.Tensor:
+        key = (tuple(shape), dtype)
+        lst = self.free.setdefault(key, [])
+        return lst.pop() if lst else torch.empty(shape, dtype=dtype, pin_memory=True)
+
+    def give(self, t: torch.Tensor):
+        self.free.setdefault((tuple(t.shape), t.dtype), []).append(t)
+
+
+_pinned = _PinnedPool()
+
+
+class PendingCounts:
+    """Count matrices on their way to the host.  ``finish()`` is the layer's only host sync; between
+    ``exchange_counts_start`` and ``finish`` the caller may enqueue unrelated GPU work (another micro-batch) so
+    that the GPU stays busy while the host waits."""
+
+    def __init__(self, host: torch.Tensor, event, pooled: bool, dev: torch.Tensor):
+        self.host, self.event, self.pooled, self.dev = host, event, pooled, dev
+
+    def group_offsets(self, c: int) -> torch.Tensor:
+        """int32 [W*E_local + 1] row offsets of chunk c's received groups ([w][e] order), built on the device
+        from the received counts (no host -> device copy on the critical path)."""
+        n = self.dev[1][:, c, :].reshape(-1)
+        return torch.cat([n.new_zeros(1), n.cumsum(0)]).to(torch.int32)
+
+    def finish(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self.event is not None:
+            self.event.synchronize()
+        h = self.host.to(torch.int64)
+        if self.pooled:
+            _pinned.give(self.host)
+        return h[0].permute(1, 0, 2).contiguous(), h[1].permute(1, 0, 2).contiguous()
+
+
+def exchange_counts_start(counts_per_chunk: List[torch.Tensor], world_size: int, group=None) -> PendingCounts:
     """counts_per_chunk[c]: int32 [W*E_local] rows this rank routes to each GLOBAL expert from chunk c.
-    Returns host int64 tensors (lec, gec), both [C, W, E_local]:
-      lec[c, w, e] = rows of chunk c this rank sends to rank w's local expert e
-      gec[c, w, e] = rows of chunk c rank w sends to this rank's local expert e.
-    One small all-to-all + one device->host copy for all chunks."""
-    C = len(counts_per_chunk)
+    One small all-to-all + one asynchronous device->host copy for all chunks; see ``exchange_counts``."""
     W = world_size
     E_local = counts_per_chunk[0].numel() // W
     lec = torch.stack([c.reshape(W, E_local) for c in counts_per_chunk], 0)          # [C, W, E]
     send = lec.permute(1, 0, 2).contiguous()                                          # [W, C, E]: row w goes to rank w
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
-    host = torch.stack([send, recv], 0).to("cpu", torch.int64)                        # the single sync point
-    return host[0].permute(1, 0, 2).contiguous(), host[1].permute(1, 0, 2).contiguous()
+    both = torch.stack([send, recv], 0)
+    if not both.is_cuda:
+        return PendingCounts(both, None, False, both)
+    host = _pinned.take(both.shape, both.dtype)
+    host.copy_(both, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return PendingCounts(host, ev, True, both)
+
+
+def exchange_counts(counts_per_chunk: List[torch.Tensor], world_size: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Returns host int64 tensors (lec, gec), both [C, W, E_local]:
+      lec[c, w, e] = rows of chunk c this rank sends to rank w's local expert e
+      gec[c, w, e] = rows of chunk c rank w sends to this rank's local expert e."""
+    return exchange_counts_start(counts_per_chunk, world_size, group).finish()
 
 
 def segment_table(gec_c: torch.Tensor) -> Tuple[List[int], List[int]]:
@@ -53,6 +103,18 @@ def segment_table(gec_c: torch.Tensor) -> Tuple[List[int], List[int]]:
     for n in gec_c.reshape(-1).tolist():
         offs.append(offs[-1] + int(n))
     return offs, [e for _ in range(W) for e in range(E_local)]
+
+
+_gexp_cache = {}
+
+
+def _group_expert_ids(W: int, E_local: int, device) -> torch.Tensor:
+    """Local expert id of every received row group ([w][e] order) -- constant per (W, E_local), kept on the device."""
+    key = (W, E_local, str(device))
+    t = _gexp_cache.get(key)
+    if t is None:
+        t = _gexp_cache[key] = torch.arange(E_local, dtype=torch.int32, device=device).repeat(W)
+    return t
 
 
 def all_to_all_rows(rows: torch.Tensor, send_rows: List[int], recv_rows: List[int], group=None, async_op: bool = False):
@@ -70,9 +132,29 @@ def chunk_bounds(T: int, chunks: int) -> List[Tuple[int, int]]:
     return [((T * c) // chunks, (T * (c + 1)) // chunks) for c in range(chunks)]
 
 
+def drain(gen):
+    """Run a ``*_steps`` generator to completion, ignoring its yield points; returns its return value."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as stop:
+        return stop.value
+
+
 def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.Tensor] = None,
                norm: Optional[torch.nn.Module] = None) -> torch.Tensor:
-    """Expert-parallel FMoETransformerMLP forward for this rank's tokens x [T, d] -> [T, d].
+    """Expert-parallel FMoETransformerMLP forward for this rank's tokens x [T, d] -> [T, d] (see ep_forward_steps)."""
+    return drain(ep_forward_steps(mod, x, cd, residual, norm))
+
+
+def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.Tensor] = None,
+                     norm: Optional[torch.nn.Module] = None):
+    """Generator form of the expert-parallel forward: ``yield``s wherever this micro-batch has to wait for something
+    that is not GPU compute -- (1) the count matrices reaching the host, (2) the dispatch all-to-all, (3) the return
+    all-to-all -- so that a caller interleaving several micro-batches (vit.VisionTransformer) keeps the compute
+    stream fed with the other micro-batch's attention / GEMMs meanwhile.  Every rank yields at the same points in
+    the same order whatever the routing, so the collectives stay matched.  Returns the output via StopIteration.
+
     With ``norm`` (a LayerNorm whose shape the fused kernel covers) the operator computes ``moe(norm(x))``: LayerNorm
     and router run as one pass over x and the send buffers are gathered from the normalised 16-bit image."""
     from . import ops
@@ -109,18 +191,22 @@ def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.T
         pruned = plans[0][4] if plans[0][4] is not None else idx
         g.set_loss(switch_aux_loss(pruned, probs, g.tot_expert))
 
-    lec, gec = exchange_counts([p[0] for p in plans], W, group)          # host [C, W, E_local]
-
+    pending = exchange_counts_start([p[0] for p in plans], W, group)
+    # the send buffers do not depend on the counts: enqueue their scatter before the host goes to wait
+    sends = [ops.scatter_rows(src[t0:t1], plans[c][2], k, cd) for c, (t0, t1) in enumerate(bounds)]
     out = torch.empty((T, d), dtype=x.dtype, device=x.device)
-    # stage A: scatter + dispatch all-to-all (async; chunk c+1 travels under chunk c's GEMMs)
+    yield                                                                # (1) counts in flight to the host
+    lec, gec = pending.finish()                                          # host [C, W, E_local]; the only host sync
+
+    # stage A: dispatch all-to-all (async; chunk c+1 travels under chunk c's GEMMs)
     inflight = []
     for c, (t0, t1) in enumerate(bounds):
-        counts, offsets, pos, inv_pos, _ = plans[c]
-        send = ops.scatter_rows(src[t0:t1], pos, k, cd)
+        send = sends[c]
         send_rows = lec[c].sum(1).tolist()
         recv_rows = gec[c].sum(1).tolist()
         recv, work = all_to_all_rows(send, send_rows, recv_rows, group, async_op=True)
         inflight.append((send, recv, work, send_rows, recv_rows))
+    yield                                                                # (2) dispatch all-to-all in flight
     # stage B: expert FFN on the received rows + return all-to-all (async)
     returning = []
     for c in range(len(bounds)):
@@ -128,14 +214,14 @@ def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.T
         work.wait()
         n_recv = recv.shape[0]
         if n_recv > 0:
-            offs, gexp = segment_table(gec[c])
-            offs_dev = torch.tensor(offs, dtype=torch.int32, device=x.device)
-            gexp_dev = torch.tensor(gexp, dtype=torch.int32, device=x.device)
+            offs_dev = pending.group_offsets(c)
+            gexp_dev = _group_expert_ids(W, E_local, x.device)
             y = mod._experts_fwd(recv, offs_dev, cd, out_dtype=cd, group_expert=gexp_dev)
         else:
             y = recv
         back, work2 = all_to_all_rows(y, recv_rows, send_rows, group, async_op=True)
         returning.append((y, back, work2))
+    yield                                                                # (3) return all-to-all in flight
     # stage C: gather + combine in sender order
     for c, (t0, t1) in enumerate(bounds):
         y, back, work2 = returning[c]

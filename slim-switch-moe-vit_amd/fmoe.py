@@ -203,6 +203,16 @@ class FMoETransformerMLP(nn.Module):
         block glue fused: LayerNorm + router in one pass over x (smoe_ln_router_topk), the token scatter folded into
         GEMM-1's operand DMA (a_gather) and the combine + residual add folded into GEMM-2's store.  Falls back to
         the unfused composition whenever a precondition does not hold; results agree to rounding."""
+        from .ep import drain
+        return drain(self.forward_norm_add_steps(x, norm))
+
+    def ep_active(self) -> bool:
+        return self.world_size > 1 or bool(getattr(self, "force_ep", False))
+
+    def forward_norm_add_steps(self, x: torch.Tensor, norm: nn.Module):
+        """Generator form of ``forward_norm_add``: under expert parallelism it yields at the points where this
+        micro-batch waits for the host or for an all-to-all (ep.ep_forward_steps) so that the caller can interleave
+        another micro-batch; otherwise it never yields.  The result is the generator's return value."""
         cd = self.compute_dtype or default_compute_dtype()
         g = self.gate
         ok = (x.is_cuda and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine
@@ -214,12 +224,13 @@ class FMoETransformerMLP(nn.Module):
               and ops.ln_router_supported(self.d_model, g.tot_expert, g.top_k))
         if not ok:
             return self.forward_add(norm(x), x)
-        if self.world_size > 1 or getattr(self, "force_ep", False):
-            from .ep import ep_forward
+        if self.ep_active():
+            from .ep import ep_forward_steps
             x2 = x.reshape(-1, self.d_model)
             if not x2.is_contiguous():
                 x2 = x2.contiguous()
-            return ep_forward(self, x2, cd, residual=x2, norm=norm).reshape(x.shape)
+            out = yield from ep_forward_steps(self, x2, cd, residual=x2, norm=norm)
+            return out.reshape(x.shape)
         shape = x.shape
         d, k = self.d_model, self.top_k
         x2 = x.reshape(-1, d)

@@ -193,15 +193,22 @@ class Block(nn.Module):
         return n(x)
 
     def forward(self, x):
+        from .ep import drain
+        return drain(self.forward_steps(x))
+
+    def forward_steps(self, x):
+        """The block as a generator (result = return value): it yields only inside an expert-parallel MoE ``mlp``, at
+        the points where this micro-batch waits for the host or an all-to-all (ep.ep_forward_steps)."""
         if isinstance(self.drop_path, nn.Identity) and x.is_contiguous() and isinstance(self.attn, Attention):
             a, added = self.attn(self._norm1(x), residual=x)
             x = a if added else x + a
         else:
             x = x + self.drop_path(self.attn(self._norm1(x)))
         if isinstance(self.drop_path, nn.Identity):
-            fused2 = getattr(self.mlp, "forward_norm_add", None)
-            if fused2 is not None:
-                return fused2(x, self.norm2)  # x + mlp(norm2(x)): LN + router, scatter, combine + add all fused
+            steps = getattr(self.mlp, "forward_norm_add_steps", None)
+            if steps is not None:
+                # x + mlp(norm2(x)): LN + router, scatter, combine + add all fused
+                return (yield from steps(x, self.norm2))
             fused = getattr(self.mlp, "forward_add", None)
             if fused is not None:
                 return fused(self.norm2(x), x)  # x + mlp(norm2(x)), add fused into the MoE combine store
@@ -256,12 +263,62 @@ class VisionTransformer(nn.Module):
         return {"pos_embed", "cls_token", "dist_token"}
 
     def forward_features(self, x):
+        n = self._ep_pipeline_depth(x)
+        if n > 1:
+            return self._forward_features_pipelined(x, n)
         x = self.patch_embed(x)
         x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
         x = self.pos_drop(x + self.pos_embed)
         x = self.blocks(x)
         x = self.norm(x)
         return self.pre_logits(x[:, 0])
+
+    # -- expert-parallel inference: software pipeline over micro-batches ------------------------------
+    ep_micro_batches = 2
+
+    def _ep_pipeline_depth(self, x) -> int:
+        """Micro-batches to interleave.  > 1 only for inference with expert-parallel MoE blocks whose gates never
+        drop (capacity is defined over the whole local batch, so a dropping gate must see it whole)."""
+        n = int(self.ep_micro_batches)
+        if n <= 1 or torch.is_grad_enabled() or self.training or not x.is_cuda or x.shape[0] < n:
+            return 1
+        ep = False
+        for blk in self.blocks:
+            m = getattr(blk, "mlp", None)
+            if not hasattr(blk, "forward_steps") or "forward" in blk.__dict__:  # e.g. resmoe.forward_residule_moe
+                return 1
+            if hasattr(m, "ep_active") and m.ep_active():
+                if m.gate.capacity(1 << 20) >= 0:
+                    return 1
+                ep = True
+        return n if ep else 1
+
+    def _features_steps(self, x):
+        x = self.patch_embed(x)
+        x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
+        x = self.pos_drop(x + self.pos_embed)
+        for blk in self.blocks:
+            x = yield from blk.forward_steps(x)
+        x = self.norm(x)
+        return self.pre_logits(x[:, 0])
+
+    def _forward_features_pipelined(self, x, n: int):
+        """Round-robin over n micro-batches of the local batch; each runs until its next wait point (count read-back,
+        dispatch / return all-to-all), so the compute stream always holds the other micro-batch's kernels while one
+        waits, and RCCL's stream moves one micro-batch's rows under the other's GEMMs.  The schedule depends only
+        on n and the depth, never on the routing: every rank issues its collectives in the same order.  Images are
+        independent in eval mode, so the result equals the un-pipelined forward row for row."""
+        from collections import deque
+        gens = deque((i, self._features_steps(xb)) for i, xb in enumerate(x.chunk(n, dim=0)))
+        outs = [None] * len(gens)
+        while gens:
+            i, g = gens.popleft()
+            try:
+                next(g)
+                gens.append((i, g))
+            except StopIteration as stop:
+                outs[i] = stop.value
+        return torch.cat(outs, dim=0)
 
     def forward(self, x):
         return self.head(self.forward_features(x))

