@@ -270,8 +270,14 @@ class VisionTransformer(nn.Module):
         x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
         x = self.pos_drop(x + self.pos_embed)
         x = self.blocks(x)
-        x = self.norm(x)
-        return self.pre_logits(x[:, 0])
+        return self.pre_logits(self._final_norm_cls(x))
+
+    def _final_norm_cls(self, x):
+        """``self.norm(x)[:, 0]`` (models/vision_transformer.py:826-830).  LayerNorm is per token, so normalising the
+        class token alone gives the identical row and skips a pass over the other 196 tokens of every image."""
+        if isinstance(self.norm, nn.LayerNorm):
+            return self.norm(x[:, 0])
+        return self.norm(x)[:, 0]
 
     # -- expert-parallel inference: software pipeline over micro-batches ------------------------------
     ep_micro_batches = 2
@@ -299,8 +305,7 @@ class VisionTransformer(nn.Module):
         x = self.pos_drop(x + self.pos_embed)
         for blk in self.blocks:
             x = yield from blk.forward_steps(x)
-        x = self.norm(x)
-        return self.pre_logits(x[:, 0])
+        return self.pre_logits(self._final_norm_cls(x))
 
     def _forward_features_pipelined(self, x, n: int):
         """Round-robin over n micro-batches of the local batch; each runs until its next wait point (count read-back,

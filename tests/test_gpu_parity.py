@@ -190,6 +190,30 @@ def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu, varian
     assert torch.all(got[M:] == 7.0), "rows past the last expert must stay untouched"
 
 
+@pytest.mark.parametrize("variant", [0, 3, 5, 6])
+def test_grouped_gemm_gelu_epilogue_over_the_whole_input_range(variant):
+    """The fused GELU (a fitted sigmoid form without a range clamp in the MFMA kernels, erf form in variant 0) must
+    follow the exact-erf GELU from the saturated negative side to the saturated positive side: pre-activations
+    from -6e4 to 6e4 are produced exactly (one non-zero product per output), f32 output."""
+    vals = torch.tensor([0.0, 1e-3, 0.5, 1.0, 2.5, 4.0, 5.5, 7.9, 8.0, 8.1, 9.0, 12.0, 20.0, 64.0, 300.0, 4096.0,
+                         60000.0], dtype=torch.float64)
+    vals = torch.cat([vals, -vals])
+    M, K, N = 320, 64, 64
+    A = torch.zeros(M, K, dtype=torch.float16)
+    for m in range(M):
+        A[m, m % K] = vals[m % len(vals)].half()
+    W = torch.eye(N, K, dtype=torch.float16)[None]   # out[m, n] = A[m, n]
+    offsets = torch.tensor([0, M], dtype=torch.int32)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.grouped_gemm(A.to(DEV), W.to(DEV), None, offsets.to(DEV), ops.EPI_GELU, out=out, variant=variant)
+    pre = A.double()
+    ref = torch.nn.functional.gelu(pre)
+    got = out.cpu().double()
+    assert torch.isfinite(got).all()
+    assert ((got - ref).abs() <= 1e-5 + 1e-5 * ref.abs()).all(), float((got - ref).abs().max())
+    assert (got[pre <= -9.0] == 0).all() and (got[pre >= 9.0] == pre[pre >= 9.0]).all()
+
+
 @pytest.mark.parametrize("variant,cd", [(0, torch.float32), (0, torch.float16), (1, torch.float16), (3, torch.float16),
                                         (3, torch.bfloat16), (4, torch.float16), (4, torch.bfloat16), (5, torch.float16),
                                         (5, torch.bfloat16), (6, torch.float16)])

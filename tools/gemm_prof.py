@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-variant grouped-GEMM driver for rocprofv3 runs and calibration.
-usage: gemm_prof.py <variant> <shape: fc1|fc2|fc2h|sq8k|sq4k> [iters]"""
+usage: gemm_prof.py <variant> <shape: fc1|fc1n|qkv|fc2|fc2h|sq8k|sq4k> [iters] [images (default 256)]"""
 import os
 import sys
 import time
@@ -23,7 +23,7 @@ def main():
         E, M, K, N = 1, n, n, n
         counts = [M]
     else:
-        E, M = 8, 256 * 197
+        E, M = 8, (int(sys.argv[4]) if len(sys.argv) > 4 else 256) * 197
         K, N = (768, 3072) if shape in ("fc1", "fc1n") else ((768, 2304) if shape == "qkv" else (3072, 768))
         if shape == "qkv":
             E = 1
