@@ -217,6 +217,18 @@ def main():
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                     "flops_per_launch": a["flops"] / a["launches"]}
+        # the same launches grouped the way rocprofv3 --stats names them (profiles/r01_bench_kernel_stats.csv): GEMM-1
+        # is the f16-out instantiation; GEMM-2 shares the f32-out instantiation with the attention projection
+        f1, f2, pj = agg.get("grouped_gemm_fc1"), agg.get("grouped_gemm_fc2"), agg.get("attn_proj_gemm")
+        sym = {}
+        if f1:
+            sym["grouped_gemm_pp256<f16,f16> = GEMM-1"] = {"launches_per_step": f1["launches"] / args.steps,
+                                                         "avg_launch_ms": round(f1["ms"] / f1["launches"], 4)}
+        if f2:
+            n2, m2 = f2["launches"] + (pj["launches"] if pj else 0), f2["ms"] + (pj["ms"] if pj else 0.0)
+            sym["grouped_gemm_pp256<f16,f32> = GEMM-2" + (" + attention proj" if pj else "")] = {
+                "launches_per_step": n2 / args.steps, "avg_launch_ms": round(m2 / n2, 4)}
+        roofline["by_rocprof_symbol"] = sym
 
     if rank == 0:
         total_images = args.batch * world * args.steps

@@ -12,6 +12,7 @@
 // LDS as whole 16-B-per-lane row segments (optionally scattered through row_map = fused combine).
 #include "smoe_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -1036,7 +1037,14 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
           return launch_pp256<AB, OT, 0, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
         return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
       }
+#ifdef SMOE_DIAG
+      case 5: {
+        const char* gm = getenv("SMOE_GROUP_M");
+        return launch_pp256<AB, OT, 0, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, gm ? atoi(gm) : 4, s, a_gather, a_div);
+      }
+#else
       case 5: return launch_pp256<AB, OT, 0, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+#endif
       case 6: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
 #ifdef SMOE_DIAG
       case 41: return launch_pp256<AB, OT, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
