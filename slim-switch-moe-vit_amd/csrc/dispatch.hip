@@ -2,11 +2,15 @@
 // Replaces fmoe_cuda.expert_count / assign_pos / limit_by_capacity / prune_gate_by_capacity and the
 // index_select / index_copy_ / bmm of MOEScatter / MOEGather (N1-N3, N6-N9).
 //
-// Plan = three small launches over n = T*k flat entries, chunked CH entries per workgroup:
+// Plan over n = T*k flat entries, chunked CH entries per workgroup:
 //   plan_count : per-chunk LDS histogram                    -> blockcnt[nblk][E]
 //   plan_scan  : per expert, exclusive scan over chunks      -> rawbase[nblk][E], counts, offsets
 //   plan_assign: per chunk, stable rank of each entry among same-expert entries with lower flat
 //                index (wave ballot + LDS running counters) -> pos / inv_pos / idx_pruned
+//   plan_tail  : pos[kept .. n) = -1
+// When the chunk histogram table is small (nblk * E <= PLAN_FUSED_MAX, E <= 64: every ViT shape) the scan and the
+// tail are folded into the assign launch -- every workgroup re-derives its own chunk's base ranks, the totals and
+// the offsets from the whole table in LDS (a few KB) -- so the plan is two launches instead of four.
 // Upstream orders slots by atomicSub race; here slot order is ascending flat index (deterministic),
 // and with a capacity an entry is kept iff its raw rank in its expert is < capacity.
 #include "smoe_common.h"
@@ -18,10 +22,11 @@ constexpr int PLAN_THREADS = 256;
 constexpr int PLAN_WAVES = PLAN_THREADS / 64;
 constexpr int PLAN_ITERS = 4;                                   // 64-entry steps per wave
 constexpr int PLAN_CH = PLAN_THREADS * PLAN_ITERS;              // entries per workgroup
+constexpr int PLAN_FUSED_MAX = 8192;                            // table entries the fused assign re-reads per workgroup
+constexpr int PLAN_FUSED_E = 64;
 
 __global__ __launch_bounds__(PLAN_THREADS) void plan_count_kernel(const int64_t* __restrict__ idx, int64_t n, int E,
-                                                                  int32_t* __restrict__ blockcnt,
-                                                                  int32_t* __restrict__ err_flag) {
+                                                                  int32_t* __restrict__ blockcnt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int32_t* hist = reinterpret_cast<int32_t*>(smem);
   for (int e = threadIdx.x; e < E; e += PLAN_THREADS) hist[e] = 0;
@@ -32,8 +37,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_count_kernel(const int64_t*
     const int64_t i = base + it * PLAN_THREADS + threadIdx.x;
     if (i < n) {
       const int64_t e = idx[i];
-      if (e >= 0 && e < E) atomicAdd(&hist[(int)e], 1);
-      else if (e >= E || e < -1) atomicOr(err_flag, 1);
+      if (e >= 0 && e < E) atomicAdd(&hist[(int)e], 1);  // ids outside [0, E) count as dropped (-1)
     }
   }
   __syncthreads();
@@ -68,18 +72,59 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int32_t* __restri
   }
 }
 
+// FUSED: rawbase_or_cnt is blockcnt[nblk][E]; the scan (base ranks of this chunk, totals, capacity clamp, offsets)
+// happens here in LDS, workgroup 0 publishes counts / offsets, and every workgroup clears its share of the pos tail.
+template <bool FUSED>
 __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
-    const int64_t* __restrict__ idx, int64_t n, int E, int64_t capacity, const int32_t* __restrict__ rawbase,
-    const int32_t* __restrict__ offsets, int64_t* __restrict__ pos, int64_t* __restrict__ inv_pos,
-    int64_t* __restrict__ idx_pruned) {
+    const int64_t* __restrict__ idx, int64_t n, int E, int64_t capacity, const int32_t* __restrict__ rawbase_or_cnt,
+    const int32_t* __restrict__ offsets_in, int64_t* __restrict__ pos, int64_t* __restrict__ inv_pos,
+    int64_t* __restrict__ idx_pruned, int nblk, int32_t* __restrict__ counts_out, int32_t* __restrict__ offsets_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // run[w][e]: raw rank of the next entry of expert e seen by wave w (wave w owns a contiguous quarter of the chunk)
   int32_t* run = reinterpret_cast<int32_t*>(smem);  // [PLAN_WAVES][E]
+  int32_t* sbase = run + PLAN_WAVES * E;            // FUSED: [E] base rank of this chunk, [E] totals, [E+1] offsets
+  int32_t* stot = sbase + E;
+  int32_t* soff = stot + E;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t chunk_base = (int64_t)blockIdx.x * PLAN_CH;
   const int64_t wave_base = chunk_base + (int64_t)wave * (64 * PLAN_ITERS);
 
   for (int i = tid; i < PLAN_WAVES * E; i += PLAN_THREADS) run[i] = 0;
+  if constexpr (FUSED) {
+    for (int i = tid; i < 2 * E; i += PLAN_THREADS) sbase[i] = 0;
+    __syncthreads();
+    const int me = (int)blockIdx.x;
+    for (int j = tid; j < nblk * E; j += PLAN_THREADS) {
+      const int32_t c = rawbase_or_cnt[j];
+      if (c) {
+        const int b = j / E, e = j - b * E;
+        atomicAdd(&stot[e], c);
+        if (b < me) atomicAdd(&sbase[e], c);
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int32_t acc = 0;
+      for (int e = 0; e < E; ++e) {
+        int32_t c = stot[e];
+        if (capacity >= 0 && (int64_t)c > capacity) c = (int32_t)capacity;
+        stot[e] = c;
+        soff[e] = acc;
+        acc += c;
+      }
+      soff[E] = acc;
+    }
+    __syncthreads();
+    if (me == 0) {
+      for (int e = tid; e < E; e += PLAN_THREADS) counts_out[e] = stot[e];
+      for (int e = tid; e <= E; e += PLAN_THREADS) offsets_out[e] = soff[e];
+    }
+    // tail: slots [kept, n) hold no entry
+    const int64_t kept = soff[E];
+    for (int64_t i = chunk_base + tid; i < chunk_base + PLAN_CH && i < n; i += PLAN_THREADS)
+      if (i >= kept) pos[i] = -1;
+  }
+  const int32_t* offsets = FUSED ? soff : offsets_in;
   __syncthreads();
   // pass 1: per-wave histogram of its quarter
   int64_t myidx[PLAN_ITERS];
@@ -95,7 +140,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
   __syncthreads();
   // turn per-wave counts into per-wave starting raw ranks: rawbase[b][e] + sum_{w'<w} cnt[w'][e]
   for (int e = tid; e < E; e += PLAN_THREADS) {
-    int32_t acc = rawbase[(int64_t)blockIdx.x * E + e];
+    int32_t acc = FUSED ? sbase[e] : rawbase_or_cnt[(int64_t)blockIdx.x * E + e];
 #pragma unroll
     for (int w = 0; w < PLAN_WAVES; ++w) {
       const int32_t c = run[w * E + e];
@@ -319,7 +364,7 @@ inline int64_t plan_nblk(int64_t n) { return n > 0 ? (n + PLAN_CH - 1) / PLAN_CH
 
 }  // namespace
 
-// workspace layout: [err_flag pad to 16 B][blockcnt nblk*E i32][rawbase nblk*E i32]
+// workspace layout: [16 B reserved][blockcnt nblk*E i32][rawbase nblk*E i32]
 extern "C" size_t smoe_dispatch_plan_workspace_bytes(int64_t n, int E) {
   if (n < 0 || E <= 0) return 0;
   const size_t per = (((size_t)plan_nblk(n) * (size_t)E * 4) + 15) & ~(size_t)15;
@@ -339,18 +384,21 @@ extern "C" int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t 
   hipStream_t s = (hipStream_t)stream;
   const int64_t nblk = plan_nblk(n);
   const size_t per = (((size_t)nblk * (size_t)E * 4) + 15) & ~(size_t)15;
-  int32_t* err_flag = reinterpret_cast<int32_t*>(workspace);
   int32_t* blockcnt = reinterpret_cast<int32_t*>((char*)workspace + 16);
   int32_t* rawbase = reinterpret_cast<int32_t*>((char*)workspace + 16 + per);
-  hipError_t me = hipMemsetAsync(workspace, 0, 16, s);
-  SMOE_REQUIRE(me == hipSuccess, "smoe_dispatch_plan: memset failed: %s", hipGetErrorString(me));
-  hipLaunchKernelGGL(plan_count_kernel, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)E * 4, s, idx, n, E, blockcnt, err_flag);
+  hipLaunchKernelGGL(plan_count_kernel, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)E * 4, s, idx, n, E, blockcnt);
   SMOE_CHECK_LAUNCH("smoe_dispatch_plan/count");
+  if (n > 0 && E <= PLAN_FUSED_E && nblk * E <= PLAN_FUSED_MAX) {
+    hipLaunchKernelGGL(plan_assign_kernel<true>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)(PLAN_WAVES * E + 3 * E + 1) * 4, s,
+                       idx, n, E, capacity, blockcnt, nullptr, pos, inv_pos, idx_pruned, (int)nblk, counts, offsets);
+    SMOE_CHECK_LAUNCH("smoe_dispatch_plan/assign_fused");
+    return 0;
+  }
   const int scan_threads = E < 64 ? 64 : (E > 1024 ? 1024 : ((E + 63) / 64) * 64);
   hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(scan_threads), (size_t)E * 4, s, blockcnt, (int)nblk, E, capacity, rawbase, counts, offsets);
   SMOE_CHECK_LAUNCH("smoe_dispatch_plan/scan");
   if (n > 0) {
-    hipLaunchKernelGGL(plan_assign_kernel, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)PLAN_WAVES * E * 4, s, idx, n, E, capacity, rawbase, offsets, pos, inv_pos, idx_pruned);
+    hipLaunchKernelGGL(plan_assign_kernel<false>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)PLAN_WAVES * E * 4, s, idx, n, E, capacity, rawbase, offsets, pos, inv_pos, idx_pruned, (int)nblk, nullptr, nullptr);
     SMOE_CHECK_LAUNCH("smoe_dispatch_plan/assign");
     int tb = (int)((n + 255) / 256);
     if (tb > 1024) tb = 1024;

@@ -58,7 +58,9 @@ class PendingCounts:
         """int32 [W*E_local + 1] row offsets of chunk c's received groups ([w][e] order), built on the device
         from the received counts (no host -> device copy on the critical path)."""
         n = self.dev[1][:, c, :].reshape(-1)
-        return torch.cat([n.new_zeros(1), n.cumsum(0)]).to(torch.int32)
+        offs = torch.zeros(n.numel() + 1, dtype=torch.int32, device=n.device)
+        torch.cumsum(n, 0, dtype=torch.int32, out=offs[1:])
+        return offs
 
     def finish(self) -> Tuple[torch.Tensor, torch.Tensor]:
         if self.event is not None:
@@ -72,13 +74,13 @@ class PendingCounts:
 def exchange_counts_start(counts_per_chunk: List[torch.Tensor], world_size: int, group=None) -> PendingCounts:
     """counts_per_chunk[c]: int32 [W*E_local] rows this rank routes to each GLOBAL expert from chunk c.
     One small all-to-all + one asynchronous device->host copy for all chunks; see ``exchange_counts``."""
-    W = world_size
-    E_local = counts_per_chunk[0].numel() // W
-    lec = torch.stack([c.reshape(W, E_local) for c in counts_per_chunk], 0)          # [C, W, E]
-    send = lec.permute(1, 0, 2).contiguous()                                          # [W, C, E]: row w goes to rank w
-    recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
-    both = torch.stack([send, recv], 0)
+    W, C = world_size, len(counts_per_chunk)
+    c0 = counts_per_chunk[0]
+    E_local = c0.numel() // W
+    both = torch.empty((2, W, C, E_local), dtype=c0.dtype, device=c0.device)         # [0] = sent, [1] = received
+    for c, cnt in enumerate(counts_per_chunk):                                        # row w of [0] goes to rank w
+        both[0, :, c, :].copy_(cnt.reshape(W, E_local))
+    dist.all_to_all_single(both[1], both[0], group=group)
     if not both.is_cuda:
         return PendingCounts(both, None, False, both)
     host = _pinned.take(both.shape, both.dtype)

@@ -38,9 +38,15 @@ def _stream(t: torch.Tensor):
 _PROFILE = None  # list of (name, meta, start_event, end_event) while enabled
 
 
-def profile_begin():
-    global _PROFILE
+_PROFILE_ONLY = None  # optional set of launch names to time (None = all)
+
+
+def profile_begin(only=None):
+    """Start recording per-launch HIP events.  ``only``: restrict to these launch names (each timed launch costs the
+    host two event records -- with the expert-parallel pipeline the host has no slack for timing every launch)."""
+    global _PROFILE, _PROFILE_ONLY
     _PROFILE = []
+    _PROFILE_ONLY = set(only) if only is not None else None
 
 
 def profile_end():
@@ -52,7 +58,7 @@ def profile_end():
 
 class _timed:
     def __init__(self, name, meta, ref):
-        self.on = _PROFILE is not None
+        self.on = _PROFILE is not None and (_PROFILE_ONLY is None or name in _PROFILE_ONLY)
         if self.on:
             self.name, self.meta, self.ref = name, meta, ref
 

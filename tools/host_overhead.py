@@ -52,7 +52,7 @@ def main():
                 model(x)
             pr.disable()
             torch.cuda.synchronize()
-            pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+            pstats.Stats(pr).sort_stats("tottime").print_stats(60)
     if a.force_ep:
         import torch.distributed as dist
         dist.destroy_process_group()
