@@ -61,6 +61,32 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
   const int q = lane >> 4, u = lane & 15;
   if (MODE == 1 && redo_list && *redo_count == 0) return;  // nothing to redo (the common case): exit before any setup
 
+  int64_t n_items = T;
+  if (MODE == 1 && redo_list) n_items = *redo_count;
+  const int64_t slot_gid = ((int64_t)blockIdx.x * (R16_THREADS / 64) + wave) * 4 + q;
+  const int64_t slot_stride = (int64_t)gridDim.x * (R16_THREADS / 64) * 4;
+  // The row of the NEXT item is fetched as soon as the current one's registers are free -- the first one before
+  // the weight staging below, so the HBM latency of the first rows runs under the prologue.  Dead slots of the
+  // last group re-read the last item (no predication on the loads; only stores are guarded).
+  int64_t it0 = slot_gid - q;  // all four slots of a wave iterate together (DPP needs the whole row active)
+  f32x4 xv[NJ];
+  int64_t t_next = 0;
+  bool live_next = false;
+  auto fetch = [&](int64_t i0) {
+    const int64_t it = i0 + q;
+    live_next = it < n_items;
+    const int64_t itc = live_next ? it : n_items - 1;
+    t_next = (MODE == 1 && redo_list) ? (int64_t)redo_list[itc] : itc;
+    const XT* src = x + t_next * (int64_t)(64 * NJ) + u * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float tmp[4];
+      load4(src + 64 * j, tmp);
+      xv[j] = f32x4{tmp[0], tmp[1], tmp[2], tmp[3]};
+    }
+  };
+  if (it0 < n_items) fetch(it0);
+
   for (int i = tid * 4; i < R16_E * d; i += R16_THREADS * 4) {
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (i / d < E) v = *reinterpret_cast<const f32x4*>(wg + i);
@@ -86,31 +112,15 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
 #pragma unroll
   for (int e = 0; e < R16_E; ++e) wmax2 = fmaxf(wmax2, lds_wn2[e]);
 
-  constexpr int nchunk = 16 * NJ;  // float4 chunks per row (d = 64 NJ)
-  int64_t n_items = T;
-  if (MODE == 1 && redo_list) n_items = *redo_count;
-  const int64_t slot_gid = ((int64_t)blockIdx.x * (R16_THREADS / 64) + wave) * 4 + q;
-  const int64_t slot_stride = (int64_t)gridDim.x * (R16_THREADS / 64) * 4;
-  // all four slots of a wave iterate together (DPP needs the whole row active): loop on the wave's first slot
-  for (int64_t it0 = slot_gid - q; it0 < n_items; it0 += slot_stride) {
-    const int64_t it = it0 + q;
-    const bool live = it < n_items;
-    // dead slots of the last group re-read the last item (no predication on the loads; only stores are guarded)
-    const int64_t itc = live ? it : n_items - 1;
-    const int64_t t = (MODE == 1 && redo_list) ? (int64_t)redo_list[itc] : itc;
+  while (it0 < n_items) {
+    const int64_t t = t_next;
+    const bool live = live_next;
     const int64_t rowoff = t * (int64_t)d + u * 4;  // this lane's first chunk; chunk j sits 64 j elements further
     // LDS offset of this lane's first chunk through a per-iteration opaque zero: otherwise the loop-invariant
     // LDS reads (gamma, beta, all weights) are hoisted out of the token loop and spilled
     int lz = 0;
     asm volatile("" : "+v"(lz));
     const int ub = u * 4 + lz;
-    f32x4 xv[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      float tmp[4];
-      load4(x + rowoff + 64 * j, tmp);
-      xv[j] = f32x4{tmp[0], tmp[1], tmp[2], tmp[3]};
-    }
     if constexpr (LN) {
       constexpr float inv_d = 1.0f / (float)(64 * NJ);
       f32x2 s1 = f32x2{0.f, 0.f};
@@ -188,6 +198,16 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
 #pragma unroll
       for (int e = 0; e < R16_E; ++e) lg[e] = (float)(row16_sum(acc[e]) + (double)lds_bias[e]);
     }
+    float xs = 0.f;  // |x|^2 for the error bound (MODE 0); last use of the row registers
+    if constexpr (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xs = fmaf(xv[j][i], xv[j][i], xs);
+      xs = row16_sum(xs);
+    }
+    it0 += slot_stride;
+    if (it0 < n_items) fetch(it0);  // next row on its way while this one is ranked and stored
     if (logits_out && live && u == 0) {
 #pragma unroll
       for (int e = 0; e < R16_E; ++e)
@@ -228,12 +248,6 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
       }
     }
     if constexpr (MODE == 0) {
-      float xs = 0.f;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xs = fmaf(xv[j][i], xv[j][i], xs);
-      xs = row16_sum(xs);
       float amax = 0.f;
 #pragma unroll
       for (int r = 0; r <= R16_MAX_K; ++r)
