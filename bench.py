@@ -182,6 +182,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- expert parallel: the raw exchange beside the step (a2a GB/s per link vs the 153 GB/s link) ---
+    ep_info = None
+    if world > 1:
+        rows = (args.batch * 197 // world) * world          # equal splits: the average layer's volume
+        sbuf = torch.randn(rows, 768, device=device).half()
+        rbuf = torch.empty_like(sbuf)
+        for _ in range(3):
+            dist.all_to_all_single(rbuf, sbuf)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        e0.record()
+        for _ in range(10):
+            dist.all_to_all_single(rbuf, sbuf)
+        e1.record()
+        torch.cuda.synchronize(device)
+        a2a_ms = e0.elapsed_time(e1) / 10
+        t = torch.tensor([a2a_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        a2a_ms = float(t.item())
+        per_peer = rows // world * 768 * 2
+        ep_info = {"a2a_payload_mb_per_rank": round(rows * 768 * 2 / 1e6, 1), "a2a_ms": round(a2a_ms, 4),
+                   "a2a_gb_s_per_link": round(per_peer / (a2a_ms * 1e-3) / 1e9, 1), "link_peak_gb_s_bidir": 153,
+                   "a2a_per_step": 24, "a2a_ms_per_step_if_exposed": round(24 * a2a_ms, 3),
+                   "micro_batches": args.ep_micro_batches}
+
     # ---- per-kernel accounting from the HIP events recorded inside the timed region --------------------
     agg = {}
     for name, meta, ms in prof:
@@ -258,6 +283,8 @@ def main():
         moe_ms = sum(a["ms"] for n, a in agg.items() if n in hot) / args.steps
         out["hot_path"] = {"moe_kernels_ms_per_step": round(moe_ms, 3),
                            "share_of_step": round(moe_ms / (elapsed / args.steps * 1e3), 3)}
+        if ep_info is not None:
+            out["expert_parallel"] = ep_info
         if world == 1 and sd_cpu is not None:
             ips, cpu_logits, info = cpu_baseline(sd_cpu, images_cpu[: args.cpu_batch], args.cpu_seconds)
             out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": torch.get_num_threads(),
