@@ -548,3 +548,90 @@ def test_expert_parallel_path_on_one_gpu():
         assert torch.all(got[torch.from_numpy(o.plan.idx_pruned < 0)] == 0)
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------- expert-parallel layouts on one GPU
+@pytest.mark.parametrize("variant,cd,tol", [(0, torch.float32, 2e-5), (4, torch.float16, 1e-3), (5, torch.float16, 1e-3),
+                                            (6, torch.bfloat16, 8e-3)])
+def test_grouped_gemm_group_expert_map_many_groups_per_expert(variant, cd, tol):
+    """The expert-parallel receive layout: W * E_local row groups ordered [source rank][local expert], several
+    groups per weight, some empty -- the group -> expert map must pick the right weight for every group."""
+    W_ranks, E_local, K, N = 4, 2, 128, 192
+    counts = [300, 5, 0, 130, 77, 0, 256, 321]           # [w][e]
+    gexp = torch.arange(E_local, dtype=torch.int32).repeat(W_ranks)
+    offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    M = int(offsets[-1])
+    g = _gen(71)
+    A = torch.randn(M, K, generator=g).to(cd)
+    Wt = (torch.randn(E_local, N, K, generator=g) * 0.05).to(cd)
+    bias = torch.randn(E_local, N, generator=g) * 0.1
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.grouped_gemm(A.to(DEV), Wt.to(DEV), bias.to(DEV), torch.from_numpy(offsets).to(DEV), ops.EPI_GELU, out=out,
+                     variant=variant, group_expert=gexp.to(DEV))
+    ref = torch.zeros(M, N, dtype=torch.float64)
+    for gi in range(len(counts)):
+        lo, hi, e = int(offsets[gi]), int(offsets[gi + 1]), int(gexp[gi])
+        if hi > lo:
+            ref[lo:hi] = torch.nn.functional.gelu(A[lo:hi].double() @ Wt[e].double().t() + bias[e].double())
+    assert (out.cpu().double() - ref).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("W_ranks,E_local,k", [(2, 4, 1), (4, 2, 1), (8, 1, 1), (4, 2, 2)])
+def test_expert_parallel_data_path_simulated_ranks(W_ranks, E_local, k):
+    """Every rank's side of ep.ep_forward_steps with W > 1, replayed on one GPU: the ranks' token shards are routed
+    with the HIP router / plan, the all-to-all is done by hand (slices of the send buffers, [source rank][local
+    expert] receive order), each simulated rank runs the HIP expert FFN on its receive buffer through the
+    group -> expert map and device-side group offsets exactly as ep.py builds them, rows travel back and are combined
+    with the HIP gather -- the result must equal the oracle's single-rank forward of every shard."""
+    from slim_switch_moe_vit_amd import ep
+    d, h, E = 192, 768, W_ranks * E_local
+    cd, tol = torch.float16, 2e-3
+    T_r = [700, 333, 1, 512, 64, 900, 257, 128][:W_ranks]
+    xs, wg, bg, w1, b1, w2, b2 = [], None, None, None, None, None, None
+    _, wg, bg, w1, b1, w2, b2 = _mk(1, d, h, E, seed=500 + W_ranks + k)
+    xs = [torch.randn(t, d, generator=_gen(600 + r)) for r, t in enumerate(T_r)]
+    mods = []
+    for r in range(W_ranks):   # rank r holds the gate for all E experts and the weights of its E_local experts
+        m = sm.FMoETransformerMLP(E_local, d, h, torch.nn.GELU(), top_k=k, world_size=W_ranks, compute_dtype=cd)
+        sl = slice(r * E_local, (r + 1) * E_local)
+        mods.append(_load_module(m, wg, bg, w1[sl], b1[sl], w2[sl], b2[sl]))
+    # sender side
+    plans, sends, scores, lec = [], [], [], []
+    for r in range(W_ranks):
+        x = xs[r].to(DEV)
+        idx, score, _, _ = ops.router_topk(x, wg.to(DEV), bg.to(DEV), k, ops.GATE_NAIVE)
+        counts, offsets, pos, inv_pos, _ = ops.dispatch_plan(idx, E, -1)
+        plans.append((counts, offsets, pos, inv_pos))
+        scores.append(score)
+        sends.append(ops.scatter_rows(x, pos, k, cd))
+        lec.append(counts.cpu().long().reshape(W_ranks, E_local))
+    # the exchange, by hand
+    outs = []
+    backs = [[None] * W_ranks for _ in range(W_ranks)]   # backs[src][dst]
+    for dst in range(W_ranks):
+        pieces, gec = [], torch.zeros(W_ranks, E_local, dtype=torch.int32)
+        for src in range(W_ranks):
+            off = plans[src][1].cpu().long()
+            lo, hi = int(off[dst * E_local]), int(off[(dst + 1) * E_local])
+            pieces.append(sends[src][lo:hi])
+            gec[src] = lec[src][dst].int()
+        recv = torch.cat(pieces, 0)
+        both = torch.zeros(2, W_ranks, 1, E_local, dtype=torch.int32, device=DEV)
+        both[1, :, 0, :] = gec.to(DEV)
+        offs_dev = ep.PendingCounts(None, None, False, both).group_offsets(0)
+        assert int(offs_dev[-1]) == recv.shape[0]
+        assert offs_dev.cpu().tolist() == ep.segment_table(gec.long())[0]
+        gexp = ep._group_expert_ids(W_ranks, E_local, torch.device(DEV))
+        assert gexp.cpu().tolist() == ep.segment_table(gec.long())[1]
+        y = mods[dst]._experts_fwd(recv, offs_dev, cd, out_dtype=cd, group_expert=gexp) if recv.shape[0] else recv
+        at = 0
+        for src in range(W_ranks):
+            n = int(gec[src].sum())
+            backs[src][dst] = y[at:at + n]
+            at += n
+    for r in range(W_ranks):
+        back = torch.cat(backs[r], 0)
+        T = xs[r].shape[0]
+        got = ops.gather_combine(back, plans[r][3], scores[r], T, k, torch.float32).cpu()
+        ref = mo.moe_forward(xs[r], wg, bg, w1, b1, w2, b2, k).out
+        assert (got - ref).abs().max().item() <= tol, (r, float((got - ref).abs().max()))
