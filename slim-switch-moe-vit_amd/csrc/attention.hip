@@ -26,8 +26,11 @@ __device__ __forceinline__ int k_lds_off(int row, int chunk) { return row * 128 
 __device__ __forceinline__ int v_lds_off(int row, int dt) { return row * 128 + ((dt ^ ((row >> 1) & 3)) << 5); }
 
 // NKT = key tiles of 16 held in LDS (compile-time, >= ceil(N/16): every loop below is static, so the compiler can
-// batch the LDS reads ahead of the MFMAs); NT = NKT rounded up to even (k-steps of 32 keys)
-template <typename HT, int NKT>
+// batch the LDS reads ahead of the MFMAs); NT = NKT rounded up to even (k-steps of 32 keys).  EXACT = (NKT ==
+// ceil(N/16)): only the last key tile can hold keys >= N, so only its 4 scores per lane carry mask code (the general
+// form costs a compare-select pair on all 4 NKT scores: 150 of the ~650 VALU issues of a query tile, and this
+// kernel is VALU-issue bound -- 54 MFMAs against ~600 VALU per tile).
+template <typename HT, int NKT, bool EXACT>
 __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
                                                                   int H, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,47 +104,48 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __re
       const int kg = gi * 4;
       if (gi + 1 < NKG) read_k((gi + 1) & 1, kg + 4);
       __builtin_amdgcn_sched_barrier(0);
+      // first halves of the 4 tiles, then the second halves: the two MFMAs of one accumulator are 3 issues apart
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (kg + i < nkt) {
-          if constexpr (std::is_same<HT, f16>::value) {
-            sacc[kg + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[gi & 1][i][0]), __builtin_bit_cast(f16x8, qf0), sacc[kg + i], 0, 0, 0);
-            sacc[kg + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[gi & 1][i][1]), __builtin_bit_cast(f16x8, qf1), sacc[kg + i], 0, 0, 0);
-          } else {
-            sacc[kg + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[gi & 1][i][0]), __builtin_bit_cast(bf16x8_t, qf0), sacc[kg + i], 0, 0, 0);
-            sacc[kg + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[gi & 1][i][1]), __builtin_bit_cast(bf16x8_t, qf1), sacc[kg + i], 0, 0, 0);
+      for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (kg + i < nkt) {
+            if constexpr (std::is_same<HT, f16>::value)
+              sacc[kg + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[gi & 1][i][hf]), __builtin_bit_cast(f16x8, hf ? qf1 : qf0), sacc[kg + i], 0, 0, 0);
+            else
+              sacc[kg + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[gi & 1][i][hf]), __builtin_bit_cast(bf16x8_t, hf ? qf1 : qf0), sacc[kg + i], 0, 0, 0);
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // mask only the tiles that can hold keys >= N (wave-uniform test per static tile index)
+    // keys >= N: -inf (their probability is exactly 0).  The odd padding tile NKT (when NT > NKT) has no scores at
+    // all: it is left out of max / exp and packed as zeros below.
+    if constexpr (EXACT) {
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) {
-      if (kt * 16 + 16 > N) {
+      for (int r = 0; r < 4; ++r)
+        if ((NKT - 1) * 16 + g * 4 + r >= N) sacc[NKT - 1][r] = -INFINITY;
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (kt * 16 + g * 4 + r >= N) sacc[kt][r] = -INFINITY;
-      }
     }
-    float m = -INFINITY;
+    float mm[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // four independent v_max3 chains, two per tile
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt) m = fmaxf(fmaxf(m, fmaxf(sacc[kt][0], sacc[kt][1])), fmaxf(sacc[kt][2], sacc[kt][3]));
+    for (int kt = 0; kt < NKT; ++kt) {
+      mm[(2 * kt) & 3] = fmaxf(fmaxf(mm[(2 * kt) & 3], sacc[kt][0]), sacc[kt][1]);
+      mm[(2 * kt + 1) & 3] = fmaxf(fmaxf(mm[(2 * kt + 1) & 3], sacc[kt][2]), sacc[kt][3]);
+    }
+    float m = fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3]));
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     const float nmc = -m * scale_log2e;  // exp2(s*c - m*c): scale folded into one FMA per score
-    float l = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+    for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], scale_log2e, nmc));
-        sacc[kt][r] = p;
-        l += p;
-      }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv_l = 1.0f / l;
+      for (int r = 0; r < 4; ++r) sacc[kt][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], scale_log2e, nmc));
 
     // ---- O^T = V^T P^T: P packed to 16 bit first (frees the f32 scores), then per k-step 8 transposed reads issued
     //      together ahead of their 4 MFMAs --------------------------------------------------------------------------
@@ -151,18 +155,24 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __re
       if constexpr (std::is_same<HT, f16>::value) {
         f16x8 t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { t[r] = (f16)sacc[2 * ks][r]; t[4 + r] = (f16)sacc[2 * ks + 1][r]; }
+        for (int r = 0; r < 4; ++r) { t[r] = (f16)sacc[2 * ks][r]; t[4 + r] = (2 * ks + 1 < NKT) ? (f16)sacc[2 * ks + 1][r] : (f16)0.f; }
         pf[ks] = __builtin_bit_cast(u32x4, t);
       } else {
         s16x8 t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { t[r] = (short)f32_to_bf16(sacc[2 * ks][r]); t[4 + r] = (short)f32_to_bf16(sacc[2 * ks + 1][r]); }
+        for (int r = 0; r < 4; ++r) { t[r] = (short)f32_to_bf16(sacc[2 * ks][r]); t[4 + r] = (2 * ks + 1 < NKT) ? (short)f32_to_bf16(sacc[2 * ks + 1][r]) : (short)0; }
         pf[ks] = __builtin_bit_cast(u32x4, t);
       }
     }
     f32x4 oacc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // softmax denominator on the matrix pipe: an all-ones "V^T" fragment sums the (16-bit rounded) probabilities of
+    // every query over the keys -- 7 MFMAs instead of 56 v_add + 2 cross-lane adds, and the normaliser is the sum
+    // of exactly the values that multiply V
+    f32x4 lacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones = std::is_same<HT, f16>::value ? u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u}
+                                                    : u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
     const int tq = qi >> 2, tp = qi & 3;  // transposed-read address roles inside the 16-lane group
     s16x4 v0[2][4], v1[2][4];  // double-buffered transposed V fragments
     auto read_v = [&](int buf, int ks) {
@@ -194,8 +204,13 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __re
         else
           oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf[ks]), oacc[dt], 0, 0, 0);
       }
+      if constexpr (std::is_same<HT, f16>::value)
+        lacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, pf[ks]), lacc, 0, 0, 0);
+      else
+        lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, pf[ks]), lacc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    const float inv_l = 1.0f / lacc[0];
     // ---- store: lane (g, qi) holds head-dim elements 16 dt + 4 g + r of query q0 + qi ----------------------------
     if (q0 + qi < N) {
       HT* op = out + ((int64_t)b * N + q0 + qi) * (H * ATT_D) + h * ATT_D + g * 4;
@@ -217,10 +232,10 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __re
   }
 }
 
-template <typename HT, int NKT>
+template <typename HT, int NKT, bool EXACT>
 int launch_attn(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s) {
   const size_t smem = 2 * (size_t)NKT * 16 * 128;
-  auto kern = attn_fwd_kernel<HT, NKT>;
+  auto kern = attn_fwd_kernel<HT, NKT, EXACT>;
   static bool attr_done = false;
   if (!attr_done && smem > 48 * 1024) {
     hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -239,10 +254,14 @@ int launch_attn(const void* qkv, void* out, int B, int N, int H, float scale, hi
 template <typename HT>
 int attn_dispatch(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s) {
   const int nkt = (N + 15) / 16;
-  if (nkt <= 4) return launch_attn<HT, 4>(qkv, out, B, N, H, scale, s);
-  if (nkt <= 8) return launch_attn<HT, 8>(qkv, out, B, N, H, scale, s);
-  if (nkt <= 13) return launch_attn<HT, 13>(qkv, out, B, N, H, scale, s);   // N = 197 (ViT @224, +cls): 13 tiles
-  if (nkt <= 16) return launch_attn<HT, 16>(qkv, out, B, N, H, scale, s);
+  if (nkt == 13) return launch_attn<HT, 13, true>(qkv, out, B, N, H, scale, s);   // N = 197 / 198 (ViT @224 + cls)
+  if (nkt == 4) return launch_attn<HT, 4, true>(qkv, out, B, N, H, scale, s);
+  if (nkt == 8) return launch_attn<HT, 8, true>(qkv, out, B, N, H, scale, s);
+  if (nkt == 16) return launch_attn<HT, 16, true>(qkv, out, B, N, H, scale, s);
+  if (nkt < 4) return launch_attn<HT, 4, false>(qkv, out, B, N, H, scale, s);
+  if (nkt < 8) return launch_attn<HT, 8, false>(qkv, out, B, N, H, scale, s);
+  if (nkt < 13) return launch_attn<HT, 13, false>(qkv, out, B, N, H, scale, s);
+  if (nkt < 16) return launch_attn<HT, 16, false>(qkv, out, B, N, H, scale, s);
   smoe_set_error("smoe_attention_fwd: N=%d unsupported (N <= 256)", N);
   return 1;
 }
