@@ -25,6 +25,8 @@ def main():
     else:
         E, M = 8, (int(sys.argv[4]) if len(sys.argv) > 4 else 256) * 197
         K, N = (768, 3072) if shape in ("fc1", "fc1n") else ((768, 2304) if shape == "qkv" else (3072, 768))
+        if shape.startswith("k"):  # k<K>n<N>: plain f16-out GEMM of that depth / width (per-tile constant cost probes)
+            K, N = (int(v) for v in shape[1:].split("n"))
         if shape == "qkv":
             E = 1
         base = M // E
