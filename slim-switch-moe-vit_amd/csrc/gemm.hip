@@ -706,6 +706,65 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
                                        (__attribute__((address_space(3))) void*)(sw + ((s0 + s) * NW + wave) * 1024), 16, 0, 0);
   };
 
+  // ---- DEEP layout (ABL & 16): LDS regions = the four fragment halves a K-tile is read in (A-half h = rows
+  //      wr*TBM/2 + h*16*AFR .. of both wave groups, B-half h = W rows wc*64 + h*32 .. of all four wave columns), so
+  //      every region is read in ONE interval (B-half 0 in two) and can be re-staged for tile t+2 four intervals
+  //      later: each half-tile DMA gets >= 6 intervals to land instead of 3, two half-tiles stay in flight across
+  //      the tile boundary (cdna_hip_programming.md "256^2 8-phase template": counted vmcnt, never 0 in the loop).
+  constexpr bool DEEP = (ABL & 16) != 0;
+  constexpr int A_HALF_PIECES = TBM / 16;                      // 8-row DMA pieces per A-half (16 / 20)
+  constexpr int A_HS = (A_HALF_PIECES + NW - 1) / NW;          // pieces per wave per A-half, rounded up (2 / 3)
+  const AB* a_hsrc[2][A_HS];
+  const AB* w_hsrc[2][2];
+  if constexpr (DEEP) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int s2 = 0; s2 < A_HS; ++s2) {
+        int pi = wave + NW * s2;
+        if (pi >= A_HALF_PIECES) pi = A_HALF_PIECES - 1;       // never issued (guarded below); keep the pointer valid
+        const int r = pi * 8 + l_row;                          // row inside the half
+        const int trow = (r / (16 * AFR)) * (TBM / 2) + h * (16 * AFR) + r % (16 * AFR);
+        int gr = m0 + trow;
+        if (gr >= m_end) gr = m_end - 1;
+        const int64_t arow = (MODE == 0 && a_gather) ? a_gather[gr] / a_div : (int64_t)gr;
+        a_hsrc[h][s2] = A + arow * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int r = (wave + NW * s2) * 8 + l_row;            // row inside the half (0..127)
+        int gw = n0 + (r / 32) * 64 + h * 32 + r % 32;
+        if (gw >= N) gw = N - 1;
+        w_hsrc[h][s2] = W + ((int64_t)(MODE == 0 ? e : 0) * N + gw) * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
+      }
+    }
+  }
+  auto dma_ah = [&](int kt, int buf, int h) {
+    char* sa = smem + buf * STAGE + h * (TBM / 2) * BK_BYTES;
+#pragma unroll
+    for (int s2 = 0; s2 < A_HS; ++s2) {
+      if (A_HALF_PIECES % NW == 0 || s2 + 1 < A_HS || wave < A_HALF_PIECES % NW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_hsrc[h][s2] + kt * 64),
+                                         (__attribute__((address_space(3))) void*)(sa + (wave + NW * s2) * 1024), 16, 0, 0);
+    }
+  };
+  auto dma_wh = [&](int kt, int buf, int h) {
+    char* sw = smem + buf * STAGE + (TBM + h * 128) * BK_BYTES;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_hsrc[h][s2] + kt * 64),
+                                       (__attribute__((address_space(3))) void*)(sw + (wave + NW * s2) * 1024), 16, 0, 0);
+  };
+  // counted wait that leaves this wave's two newest half-tiles (one A-half, one B-half) in flight
+  auto wait_keep2 = [&]() {
+    if constexpr (A_HALF_PIECES % NW == 0) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      if (wave < A_HALF_PIECES % NW) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+  };
+
   f32x4 acc[2 * AFR][4];
 #pragma unroll
   for (int i = 0; i < 2 * AFR; ++i)
@@ -727,7 +786,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   }
   auto read_a = [&](int buf, int half) {
     if (ABL & 2) { asm volatile("" : "+v"(ar[0][0]), "+v"(ar[1][1])); return; }
-    const char* sa = smem + buf * STAGE + (wr * (TBM / 2) + half * (16 * AFR)) * BK_BYTES;
+    const char* sa = smem + buf * STAGE + (DEEP ? half * (TBM / 2) + wr * (16 * AFR) : wr * (TBM / 2) + half * (16 * AFR)) * BK_BYTES;
 #pragma unroll
     for (int i = 0; i < AFR; ++i)
 #pragma unroll
@@ -735,7 +794,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   };
   auto read_b = [&](int buf, int half) {
     if (ABL & 2) { asm volatile("" : "+v"(br[0][0]), "+v"(br[1][1])); return; }
-    const char* sw = smem + buf * STAGE + (TBM + wc * 64 + half * 32) * BK_BYTES;
+    const char* sw = smem + buf * STAGE + (TBM + (DEEP ? half * 128 + wc * 32 : wc * 64 + half * 32)) * BK_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -758,6 +817,59 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   } while (0)
 
   if (nk > 0) {  // block-uniform (an expert without rows has an empty k-range in wgrad mode)
+  if constexpr (DEEP) {
+    // ---- prologue: tile 0 -> buffer 0, the first two halves of tile 1 -> buffer 1 (they may stay in flight) ----
+    dma_ah(0, 0, 0); dma_wh(0, 0, 0); dma_ah(0, 0, 1); dma_wh(0, 0, 1);
+    if (nk > 1) {
+      dma_ah(1, 1, 0); dma_wh(1, 1, 1);
+      wait_keep2();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PP_BARRIER();
+    if (wr == 1) PP_BARRIER();  // stagger: group 1 starts one interval late
+    // Invariant at the head of tile t: tile t is in LDS; A-half 0 and B-half 1 of tile t+1 are in flight.
+    //   R1(t): A-half 1 of t+1 (that region of the other buffer was last read in R3(t-1))
+    //   R2(t): B-half 0 of t+1 (last read R4(t-1))      R3(t): A-half 0 of t+2 (this buffer, last read R1(t))
+    //   R4(t): B-half 1 of t+2 (last read R2(t))
+    // Every re-stage is >= 4 intervals after the region's last ds_read (3 would do: the reader's lgkmcnt(0) at the
+    // head of its next interval plus one barrier for the staggered group); every half-tile has >= 6 intervals to
+    // land; the wait that closes tile t keeps the two newest (both for tile t+2) in flight.
+    for (int t = 0; t < nk; ++t) {
+      const int cur = t & 1, nxt = cur ^ 1;
+      const bool n1 = (t + 1 < nk), n2 = (t + 2 < nk);
+      read_b(cur, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(cur, 0);
+      if (n1) dma_ah(t + 1, nxt, 1);
+      PP_BARRIER();
+      PP_MFMA(0, 0);
+      PP_BARRIER();
+      read_b(cur, 1);
+      if (n1) dma_wh(t + 1, nxt, 0);
+      PP_BARRIER();
+      PP_MFMA(0, 1);
+      PP_BARRIER();
+      read_a(cur, 1);
+      if (n2) dma_ah(t + 2, cur, 0);
+      PP_BARRIER();
+      PP_MFMA(1, 1);
+      PP_BARRIER();
+      read_b(cur, 0);
+      if (n2) dma_wh(t + 2, cur, 1);
+      if (wr == 1) {  // group 1: its program interval 6 is global interval 8t+7, the last one of tile t
+        if (n2) wait_keep2();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      PP_BARRIER();
+      PP_MFMA(1, 0);
+      if (wr == 0) {  // group 0: program interval 7 = global 8t+7
+        if (n2) wait_keep2();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      PP_BARRIER();
+    }
+  } else {
   // ---- prologue: tiles 0 and 1 -> buffers 0 and 1 ------------------------------------------------------
   dma_a(0, 0, 0); dma_a(0, 0, 2); dma_w(0, 0, 0); dma_w(0, 0, 2);
   if (nk > 1) {
@@ -860,6 +972,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     PP_BARRIER();
   }
   }
+  }  // !DEEP
   if (wr == 0) PP_BARRIER();  // equalise barrier counts; after it every wave is done with LDS
   }
 #undef PP_MFMA
@@ -1033,8 +1146,14 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
         const int64_t t256 = ((m_rows_max + 255) / 256 + E / 2) * ntn, t320 = ((m_rows_max + 319) / 320 + E / 2) * ntn;
         const int cus = num_cus();
         const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c320 = (double)((t320 + cus - 1) / cus) * 1.25;
-        if (c320 <= c256)  // ties go to the taller tile (more FLOP per LDS-fill byte)
+        // deep = half-organised LDS with two half-tiles in flight across the tile boundary (variants 7 / 8): +3-4 % on
+        // long K loops (GEMM-2, 8192^3), -3 % at K = 768 where the uneven per-wave DMA split of the 320-row tile shows
+        const bool deep = K >= 2048;
+        if (c320 <= c256) {  // ties go to the taller tile (more FLOP per LDS-fill byte)
+          if (deep) return launch_pp256<AB, OT, 16, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
           return launch_pp256<AB, OT, 0, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+        }
+        if (deep) return launch_pp256<AB, OT, 16, 4>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
         return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
       }
 #ifdef SMOE_DIAG
@@ -1046,6 +1165,8 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
       case 5: return launch_pp256<AB, OT, 0, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
 #endif
       case 6: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+      case 7: return launch_pp256<AB, OT, 16, 4>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+      case 8: return launch_pp256<AB, OT, 16, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
 #ifdef SMOE_DIAG
       case 41: return launch_pp256<AB, OT, 1>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
       case 42: return launch_pp256<AB, OT, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s);
@@ -1097,8 +1218,8 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   if (m_rows_max == 0) return 0;
   SMOE_REQUIRE(A && W && out, "smoe_grouped_gemm: null pointer");
   if (K % 64 != 0 || smoe_dtype_size(ab_dtype) != 2) variant = 0;
-  SMOE_REQUIRE(!a_gather || ((variant == 4 || variant == 5 || variant == 6) && a_div >= 1),
-               "smoe_grouped_gemm: a_gather needs variant 4-6 (16-bit operands, K %% 64 == 0)");
+  SMOE_REQUIRE(!a_gather || (variant >= 4 && variant <= 8 && a_div >= 1),
+               "smoe_grouped_gemm: a_gather needs variant 4-8 (16-bit operands, K %% 64 == 0)");
   hipStream_t s = (hipStream_t)stream;
   switch (ab_dtype) {
     case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div);

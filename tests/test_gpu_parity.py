@@ -169,7 +169,7 @@ def _gemm_ref(A, W, bias, offsets, gelu):
                                         ([700, 650, 600, 800, 655, 690, 710, 640], 768, 3072)])
 @pytest.mark.parametrize("cd,tol", [(torch.float32, 2e-5), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("gelu", [False, True])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu, variant):
     if variant and (cd == torch.float32 or K % 64):
         pytest.skip("glds variants take 16-bit operands and K % 64 == 0")
@@ -190,7 +190,7 @@ def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu, varian
     assert torch.all(got[M:] == 7.0), "rows past the last expert must stay untouched"
 
 
-@pytest.mark.parametrize("variant", [0, 3, 5, 6])
+@pytest.mark.parametrize("variant", [0, 3, 5, 6, 7, 8])
 def test_grouped_gemm_gelu_epilogue_over_the_whole_input_range(variant):
     """The fused GELU (a fitted sigmoid form without a range clamp in the MFMA kernels, erf form in variant 0) must
     follow the exact-erf GELU from the saturated negative side to the saturated positive side: pre-activations
@@ -216,7 +216,8 @@ def test_grouped_gemm_gelu_epilogue_over_the_whole_input_range(variant):
 
 @pytest.mark.parametrize("variant,cd", [(0, torch.float32), (0, torch.float16), (1, torch.float16), (3, torch.float16),
                                         (3, torch.bfloat16), (4, torch.float16), (4, torch.bfloat16), (5, torch.float16),
-                                        (5, torch.bfloat16), (6, torch.float16)])
+                                        (5, torch.bfloat16), (6, torch.float16), (7, torch.float16), (8, torch.float16),
+                                        (8, torch.bfloat16)])
 def test_grouped_gemm_fused_combine_row_map(variant, cd):
     E, K, N, T = 4, 128, 64, 1000
     g = _gen(3)

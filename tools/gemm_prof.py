@@ -33,8 +33,15 @@ def main():
         counts = [base] * E
         counts[-1] += M - base * E
     offsets = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=dev)
-    A = torch.randn(M, K, device=dev).half()
-    W = (torch.randn(E, N, K, device=dev) * 0.02).half()
+    data = os.environ.get("SMOE_DATA", "randn")  # clocks depend on the operand bits: compare like with like
+    if data == "zeros":
+        A, W = torch.zeros(M, K, device=dev).half(), torch.zeros(E, N, K, device=dev).half()
+    elif data == "uniform":
+        A = (torch.rand(M, K, device=dev) * 2 - 1).half()
+        W = (torch.rand(E, N, K, device=dev) * 2 - 1).half()
+    else:
+        A = torch.randn(M, K, device=dev).half()
+        W = (torch.randn(E, N, K, device=dev) * 0.02).half()
     b = torch.randn(E, N, device=dev) * 0.02
     epi = ops.EPI_GELU if shape == "fc1" else ops.EPI_NONE
     odt = torch.float32 if shape == "fc2" else torch.float16
