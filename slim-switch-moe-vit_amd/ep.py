@@ -28,6 +28,28 @@ import torch
 import torch.distributed as dist
 
 
+class _DoneWork:
+    """Stand-in for a collective's work handle when the exchange already completed synchronously."""
+
+    def wait(self):
+        return True
+
+
+def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None, async_op: bool = False):
+    """``dist.all_to_all_single`` on the group's own transport.  RCCL ("nccl") moves device buffers directly; a gloo
+    group cannot take CUDA tensors through all-to-all, so there the buffers are staged through the host -- slow, but
+    it lets the complete multi-rank data path (routing, exchange layouts, group->expert GEMMs, the micro-batch
+    pipeline) run as several processes on ONE GPU in tests/test_gpu_model.py."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        h_in = inp.cpu()
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, h_in, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(h_out)
+        return _DoneWork() if async_op else None
+    return dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
+                                  async_op=async_op)
+
+
 class _PinnedPool:
     """Reusable pinned host buffers for the count read-back (hipHostMalloc per layer would cost more than the copy)."""
 
@@ -80,7 +102,7 @@ def exchange_counts_start(counts_per_chunk: List[torch.Tensor], world_size: int,
     both = torch.empty((2, W, C, E_local), dtype=c0.dtype, device=c0.device)         # [0] = sent, [1] = received
     for c, cnt in enumerate(counts_per_chunk):                                        # row w of [0] goes to rank w
         both[0, :, c, :].copy_(cnt.reshape(W, E_local))
-    dist.all_to_all_single(both[1], both[0], group=group)
+    _a2a(both[1], both[0], group=group)
     if not both.is_cuda:
         return PendingCounts(both, None, False, both)
     host = _pinned.take(both.shape, both.dtype)
@@ -124,8 +146,7 @@ def all_to_all_rows(rows: torch.Tensor, send_rows: List[int], recv_rows: List[in
     (received [sum(recv_rows), d], work handle or None)."""
     n_send, n_recv = int(sum(send_rows)), int(sum(recv_rows))
     out = torch.empty((n_recv, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-    work = dist.all_to_all_single(out, rows[:n_send], output_split_sizes=[int(v) for v in recv_rows],
-                                  input_split_sizes=[int(v) for v in send_rows], group=group, async_op=async_op)
+    work = _a2a(out, rows[:n_send], [int(v) for v in recv_rows], [int(v) for v in send_rows], group, async_op)
     return out, work
 
 

@@ -137,3 +137,64 @@ def test_expert_parallel_micro_batch_pipeline_equals_plain_forward():
             assert model._ep_pipeline_depth(images) == 1
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, q):
+    """One expert-parallel rank; both ranks share cuda:0 and talk over gloo (ep._a2a stages through the host)."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        E, E_local = 4, 4 // world
+        torch.manual_seed(0)
+        full = _init(sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=50), 11).eval()
+        torch.manual_seed(0)
+        part = sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=50, world_size=world).eval()
+        sd = full.state_dict()
+        sl = slice(rank * E_local, (rank + 1) * E_local)
+        for k in list(sd):
+            if ".experts." in k:   # [E, ...] expert tensors: this rank keeps its slice
+                sd[k] = sd[k][sl].clone()
+        part.load_state_dict(sd)
+        full, part = full.to(DEV), part.to(DEV)
+        images = torch.randn(6, 3, 224, 224, generator=torch.Generator().manual_seed(100 + rank)).to(DEV)
+        res = {}
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            ref = full(images).float()
+            for n in (1, 2, 3):
+                part.ep_micro_batches = n
+                assert part._ep_pipeline_depth(images) == n
+                res[n] = float((part(images).float() - ref).abs().max())
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_expert_parallel_ranks_on_one_gpu_match_single_rank_model():
+    """The whole W = 2 inference path (router over all experts, count exchange, all-to-all-v in both directions with
+    the [source rank][local expert] receive layout, group -> expert GEMMs, combine, and the micro-batch pipeline that
+    interleaves collectives of several micro-batches) as two processes on one GPU; each rank's logits for ITS images
+    must match the single-rank model holding all four experts."""
+    import socket
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for p in procs:
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    got = dict(q.get(timeout=10) for _ in range(2))
+    assert sorted(got) == [0, 1]
+    for rank, res in got.items():
+        for n, err in res.items():
+            assert err <= 3e-2, (rank, n, err)
