@@ -176,3 +176,83 @@ def test_block_level_training_step_runs():
         loss0 = loss0 or float(loss)
     assert float(loss) < loss0
     assert m.blocks[0].mlp.experts.htoh4.weight.grad is not None
+
+
+def _two_rank_train_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks on cuda:0; ep._a2a stages through the host
+    try:
+        d, h, E = 128, 256, 4
+        E_local = E // world
+        T = [700, 433]
+        _, wg, bg, w1, b1, w2, b2, _ = _params(1, d, h, E, seed=21)
+        xs = [torch.randn(T[r], d, generator=_gen(30 + r)) for r in range(world)]
+        gs = [torch.randn(T[r], d, generator=_gen(40 + r)) for r in range(world)]
+
+        def load(mod, sl):
+            with torch.no_grad():
+                mod.gate.gate.weight.copy_(wg); mod.gate.gate.bias.copy_(bg)
+                mod.experts.htoh4.weight.copy_(w1[sl]); mod.experts.htoh4.bias.copy_(b1[sl])
+                mod.experts.h4toh.weight.copy_(w2[sl]); mod.experts.h4toh.bias.copy_(b2[sl])
+            return mod.to(DEV).train()
+
+        # reference: one rank holding all experts, both shards (expert gradients add up over the shards)
+        full = load(sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=2), slice(0, E))
+        ref_dx, ref_out, ref_gate = {}, {}, {}
+        for r in range(world):
+            full.gate.gate.weight.grad = None
+            full.gate.gate.bias.grad = None
+            xg = xs[r].to(DEV).requires_grad_(True)
+            out = full(xg)
+            (out * gs[r].to(DEV)).sum().backward()
+            ref_dx[r], ref_out[r] = xg.grad, out.detach()
+            ref_gate[r] = (full.gate.gate.weight.grad.clone(), full.gate.gate.bias.grad.clone())
+        # this rank of the expert-parallel pair
+        sl = slice(rank * E_local, (rank + 1) * E_local)
+        part = load(sm.FMoETransformerMLP(E_local, d, h, torch.nn.GELU(), top_k=2, world_size=world), sl)
+        xg = xs[rank].to(DEV).requires_grad_(True)
+        out = part(xg)
+        (out * gs[rank].to(DEV)).sum().backward()
+        errs = {
+            "out": _rel(out.detach().cpu(), ref_out[rank].cpu()),
+            "dx": _rel(xg.grad.cpu(), ref_dx[rank].cpu()),
+            "dWg": _rel(part.gate.gate.weight.grad.cpu(), ref_gate[rank][0].cpu()),
+            "dW1": _rel(part.experts.htoh4.weight.grad.cpu(), full.experts.htoh4.weight.grad[sl].cpu()),
+            "db1": _rel(part.experts.htoh4.bias.grad.cpu(), full.experts.htoh4.bias.grad[sl].cpu()),
+            "dW2": _rel(part.experts.h4toh.weight.grad.cpu(), full.experts.h4toh.weight.grad[sl].cpu()),
+            "db2": _rel(part.experts.h4toh.bias.grad.cpu(), full.experts.h4toh.bias.grad[sl].cpu()),
+        }
+        q.put((rank, errs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_expert_parallel_ranks_training_step_on_one_gpu():
+    """fwd + bwd of the MoE operator across TWO expert-parallel ranks (two processes on one GPU, gloo transport):
+    outputs, dx and the router gradient of every rank match the single-rank operator on that rank's tokens, and each
+    rank's expert weight / bias gradients are the single-rank gradients (summed over both ranks' tokens) of the
+    experts it owns."""
+    import socket
+    import torch.multiprocessing as mp
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for p in procs:
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    got = dict(q.get(timeout=10) for _ in range(2))
+    assert sorted(got) == [0, 1]
+    for rank, errs in got.items():
+        for name, err in errs.items():
+            assert err < 2e-3, (rank, name, err)
