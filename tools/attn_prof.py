@@ -3,7 +3,9 @@
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from slim_switch_moe_vit_amd import ops
+from slim_switch_moe_vit_amd import ops, _lib
+if os.environ.get("SMOE_LIB"):
+    _lib.LIB_PATH = os.environ["SMOE_LIB"]
 B, N, H, D = 256, 197, 12, 64
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 qkv = torch.randn(B, N, 3, H, D, device="cuda:0").half()
