@@ -262,13 +262,35 @@ class VisionTransformer(nn.Module):
     def no_weight_decay(self):
         return {"pos_embed", "cls_token", "dist_token"}
 
+    def _embed(self, x):
+        """``pos_drop(cat(cls_token, patch_embed(x)) + pos_embed)`` (models/vision_transformer.py:818-824).  Under
+        fp16-autocast inference the same arithmetic in three launches fewer: patch gather and the fp16 cast autocast
+        puts in front of the projection in one copy, cached fp16 weights, and the class-token concat folded into the
+        position-embedding add (fp16 tokens + f32 embedding -> f32 stream, as the mixed-dtype cat / add promote)."""
+        pe = self.patch_embed
+        if (type(pe) is PatchEmbed and _autocast_half_inference(x) and x.dtype == torch.float32 and not self.training
+                and tuple(x.shape[-2:]) == pe.img_size):
+            hc = self.__dict__.setdefault("_half", _HalfCache())
+            B, C = x.shape[0], x.shape[1]
+            (ph, pw), (gh, gw) = pe.patch_size, pe.grid_size
+            p16 = torch.empty((B, gh, gw, C, ph, pw), dtype=torch.float16, device=x.device)
+            p16.copy_(x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5))
+            w = hc.get(pe.proj.weight).reshape(pe.proj.weight.shape[0], -1)
+            tok = F.linear(p16.reshape(B, gh * gw, C * ph * pw), w,
+                           hc.get(pe.proj.bias) if pe.proj.bias is not None else None)
+            out = torch.empty((B, gh * gw + 1, tok.shape[-1]), dtype=torch.float32, device=x.device)
+            torch.add(tok, self.pos_embed[:, 1:], out=out[:, 1:])
+            out[:, 0] = self.cls_token[0, 0] + self.pos_embed[0, 0]
+            return out
+        x = pe(x)
+        x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
+        return self.pos_drop(x + self.pos_embed)
+
     def forward_features(self, x):
         n = self._ep_pipeline_depth(x)
         if n > 1:
             return self._forward_features_pipelined(x, n)
-        x = self.patch_embed(x)
-        x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
-        x = self.pos_drop(x + self.pos_embed)
+        x = self._embed(x)
         x = self.blocks(x)
         return self.pre_logits(self._final_norm_cls(x))
 
@@ -300,9 +322,7 @@ class VisionTransformer(nn.Module):
         return n if ep else 1
 
     def _features_steps(self, x):
-        x = self.patch_embed(x)
-        x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
-        x = self.pos_drop(x + self.pos_embed)
+        x = self._embed(x)
         for blk in self.blocks:
             x = yield from blk.forward_steps(x)
         return self.pre_logits(self._final_norm_cls(x))
@@ -326,7 +346,12 @@ class VisionTransformer(nn.Module):
         return torch.cat(outs, dim=0)
 
     def forward(self, x):
-        return self.head(self.forward_features(x))
+        f = self.forward_features(x)
+        if isinstance(self.head, nn.Linear) and _autocast_half_inference(f):
+            hc = self.__dict__.setdefault("_half", _HalfCache())  # what autocast computes, minus the per-call weight casts
+            return F.linear(f.to(torch.float16), hc.get(self.head.weight),
+                            hc.get(self.head.bias) if self.head.bias is not None else None)
+        return self.head(f)
 
 
 def _deit(embed_dim, default_depth, num_heads, pretrained=False, **kwargs):
