@@ -251,17 +251,16 @@ def main():
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                     "flops_per_launch": a["flops"] / a["launches"]}
-        # the same launches grouped the way rocprofv3 --stats names them (profiles/r01_bench_kernel_stats.csv): GEMM-1
-        # is the f16-out instantiation; GEMM-2 shares the f32-out instantiation with the attention projection
-        f1, f2, pj = agg.get("grouped_gemm_fc1"), agg.get("grouped_gemm_fc2"), agg.get("attn_proj_gemm")
+        # the same launches under the names rocprofv3 --stats gives them (profiles/r01_bench_kernel_stats.csv):
+        # grouped_gemm_pp256<operand, out, ABL, MODE, AFR>; ABL 16 = the deep schedule variant 4 picks for K >= 2048
         sym = {}
-        if f1:
-            sym["grouped_gemm_pp256<f16,f16> = GEMM-1"] = {"launches_per_step": f1["launches"] / args.steps,
-                                                         "avg_launch_ms": round(f1["ms"] / f1["launches"], 4)}
-        if f2:
-            n2, m2 = f2["launches"] + (pj["launches"] if pj else 0), f2["ms"] + (pj["ms"] if pj else 0.0)
-            sym["grouped_gemm_pp256<f16,f32> = GEMM-2" + (" + attention proj" if pj else "")] = {
-                "launches_per_step": n2 / args.steps, "avg_launch_ms": round(m2 / n2, 4)}
+        for label, key in (("grouped_gemm_pp256<f16,f16,0,0,5> = GEMM-1 (K 768, GELU)", "grouped_gemm_fc1"),
+                           ("grouped_gemm_pp256<f16,f32,16,0,5> = GEMM-2 (K 3072, combine + residual)", "grouped_gemm_fc2"),
+                           ("grouped_gemm_pp256<f16,f32,0,0,5> = attention projection (K 768, + residual)", "attn_proj_gemm")):
+            a2 = agg.get(key)
+            if a2:
+                sym[label] = {"launches_per_step": a2["launches"] / args.steps,
+                              "avg_launch_ms": round(a2["ms"] / a2["launches"], 4)}
         if world == 1 and not args.force_ep:  # (under expert parallelism both GEMMs are the f16-out instantiation)
             roofline["by_rocprof_symbol"] = sym
 
