@@ -137,7 +137,9 @@ int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int
  * smoe_pad_offsets:     offsets_pad[e] = sum_{e'<e} round_up(count[e'], 64)
  * smoe_transpose_pad:   src [n_rows, C] expert-sorted -> dst [C, Lp] K-major, per-expert ranges at offsets_pad, zero pad
  * smoe_grouped_wgrad:   out[e] (f32 [R1,R2]) = PT[:, range e] @ QT[:, range e]^T   (PT [R1,Lp], QT [R2,Lp], 16-bit)
- * smoe_group_colsum:    out[e, c] = sum over expert e's rows of src[:, c]  (bias gradients)                       */
+ * smoe_group_colsum:    out[e, c] = sum over expert e's rows of src[:, c]  (bias gradients); C % 4 == 0; two passes
+ *                       (512-row chunk partials in `workspace`, then a per-expert sum in chunk order: deterministic);
+ *                       n_rows_max >= offsets[E] sizes the launch                                                   */
 int smoe_gelu(const void* src, void* dst, int dtype, int64_t n, void* stream);
 int smoe_rowdot(const void* dout, int dout_dtype, const void* y, int y_dtype, const int64_t* inv_pos,
                 int64_t n, int k, int d, float* dscore, void* stream);
@@ -146,7 +148,9 @@ int smoe_transpose_pad(const void* src, int dtype, const int32_t* offsets, const
                        int64_t n_rows, int C, int Lp, void* dst, void* stream);
 int smoe_grouped_wgrad(const void* PT, const void* QT, int ab_dtype, const int32_t* offsets_pad, int E, int R1,
                        int R2, int Lp, float* out, void* stream);
-int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int C, float* out, void* stream);
+size_t smoe_group_colsum_workspace_bytes(int64_t n_rows_max, int E, int C);
+int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int64_t n_rows_max, int C, float* out,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- small helpers ------------------------------------------------------------------------------------
  * elementwise cast between dtypes (weight shadow copies; not on the per-step path)                  */

@@ -105,24 +105,89 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict_
   }
 }
 
+// Bias gradients, two deterministic passes.  Pass 1: one workgroup per (512-row chunk of one expert, 256-column slab);
+// wave w sums the chunk's rows w, w+4, ... (a row of the slab is 256 contiguous elements = one 8-byte load per lane),
+// the four waves meet in LDS and the workgroup stores one f32 partial row.  The grid is an upper bound (the row
+// counts live on the device); chunks are numbered expert by expert, so pass 2 adds each expert's partial rows in
+// chunk order.  (The previous one-thread-per-column walk over all of an expert's rows ran 96 workgroups at
+// 735 us for 310 MB; this streams it at HBM speed.)
+constexpr int CS_ROWS = 512;
+constexpr int CS_COLS = 256;
+
+__device__ __forceinline__ bool colsum_find_chunk(const int32_t* __restrict__ offsets, int E, int chunk, int& e_out,
+                                                  int& r0, int& r1) {
+  int base = 0;
+  for (int e = 0; e < E; ++e) {
+    const int lo = offsets[e], hi = offsets[e + 1];
+    const int nc = (hi - lo + CS_ROWS - 1) / CS_ROWS;
+    if (chunk < base + nc) {
+      e_out = e;
+      r0 = lo + (chunk - base) * CS_ROWS;
+      r1 = r0 + CS_ROWS < hi ? r0 + CS_ROWS : hi;
+      return true;
+    }
+    base += nc;
+  }
+  return false;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void group_colsum_kernel(const T* __restrict__ src, const int32_t* __restrict__ offsets,
-                                                           int C, float* __restrict__ out) {
-  // block (cb, e): 256 columns of expert e, 4 row phases... thread = column, loop over the expert's rows
+__global__ __launch_bounds__(256) void group_colsum_partial_kernel(const T* __restrict__ src,
+                                                                   const int32_t* __restrict__ offsets, int E, int C,
+                                                                   float* __restrict__ partial) {
+  __shared__ float red[4][CS_COLS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * CS_COLS + lane * 4;
+  int e, r0, r1;
+  const bool have = colsum_find_chunk(offsets, E, (int)blockIdx.y, e, r0, r1);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (have && c < C) {  // C % 4 == 0 (checked on the host)
+    auto ld = [&](int row, float (&v)[4]) {
+      const T* p = src + (int64_t)row * C + c;
+      if constexpr (std::is_same<T, float>::value) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+      } else {
+        load4(p, v);
+      }
+    };
+    int r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {  // four rows in flight per lane
+      float v0[4], v1[4], v2[4], v3[4];
+      ld(r, v0); ld(r + 4, v1); ld(r + 8, v2); ld(r + 12, v3);
+      a0 += (v0[0] + v1[0]) + (v2[0] + v3[0]);
+      a1 += (v0[1] + v1[1]) + (v2[1] + v3[1]);
+      a2 += (v0[2] + v1[2]) + (v2[2] + v3[2]);
+      a3 += (v0[3] + v1[3]) + (v2[3] + v3[3]);
+    }
+    for (; r < r1; r += 4) {
+      float v0[4];
+      ld(r, v0);
+      a0 += v0[0]; a1 += v0[1]; a2 += v0[2]; a3 += v0[3];
+    }
+  }
+  red[wave][lane * 4 + 0] = a0;
+  red[wave][lane * 4 + 1] = a1;
+  red[wave][lane * 4 + 2] = a2;
+  red[wave][lane * 4 + 3] = a3;
+  __syncthreads();
+  const int cc = blockIdx.x * CS_COLS + threadIdx.x;
+  if (cc < C)
+    partial[(int64_t)blockIdx.y * C + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void group_colsum_final_kernel(const float* __restrict__ partial,
+                                                                 const int32_t* __restrict__ offsets, int C,
+                                                                 float* __restrict__ out) {
   const int e = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const int lo = offsets[e], hi = offsets[e + 1];
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-  int r = lo;
-  auto ld = [&](int row) -> float {
-    if constexpr (std::is_same<T, float>::value) return src[(int64_t)row * C + c];
-    else if constexpr (std::is_same<T, f16>::value) return (float)src[(int64_t)row * C + c];
-    else return bf16_to_f32(src[(int64_t)row * C + c]);
-  };
-  for (; r + 4 <= hi; r += 4) { acc0 += ld(r); acc1 += ld(r + 1); acc2 += ld(r + 2); acc3 += ld(r + 3); }
-  for (; r < hi; ++r) acc0 += ld(r);
-  out[(int64_t)e * C + c] = (acc0 + acc1) + (acc2 + acc3);
+  int base = 0;
+  for (int q = 0; q < e; ++q) base += (offsets[q + 1] - offsets[q] + CS_ROWS - 1) / CS_ROWS;
+  const int nc = (offsets[e + 1] - offsets[e] + CS_ROWS - 1) / CS_ROWS;
+  float acc = 0.f;
+  for (int k = 0; k < nc; ++k) acc += partial[(int64_t)(base + k) * C + c];
+  out[(int64_t)e * C + c] = acc;
 }
 
 template <typename F> int by_dtype(int code, F&& f) {
@@ -197,15 +262,30 @@ extern "C" int smoe_transpose_pad(const void* src, int dtype, const int32_t* off
   return 0;
 }
 
-extern "C" int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int C, float* out,
-                                 void* stream) {
-  SMOE_REQUIRE(src && offsets && out && E >= 1 && C > 0, "smoe_group_colsum: bad arguments");
+static inline int64_t colsum_chunks(int64_t n_rows_max, int E) { return (n_rows_max + CS_ROWS - 1) / CS_ROWS + E; }
+
+extern "C" size_t smoe_group_colsum_workspace_bytes(int64_t n_rows_max, int E, int C) {
+  if (n_rows_max < 0 || E < 1 || C < 1) return 0;
+  return (size_t)colsum_chunks(n_rows_max, E) * (size_t)C * 4;
+}
+
+extern "C" int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int64_t n_rows_max, int C,
+                                 float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  SMOE_REQUIRE(offsets && out && E >= 1 && C > 0 && C % 4 == 0 && n_rows_max >= 0, "smoe_group_colsum: bad arguments");
+  SMOE_REQUIRE(n_rows_max == 0 || src, "smoe_group_colsum: null pointer");
+  SMOE_REQUIRE(workspace && workspace_bytes >= smoe_group_colsum_workspace_bytes(n_rows_max, E, C),
+               "smoe_group_colsum: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((C + 255) / 256, E);
+  const int64_t chunks = colsum_chunks(n_rows_max, E);
+  SMOE_REQUIRE(chunks <= 65535, "smoe_group_colsum: too many rows (%lld)", (long long)n_rows_max);
+  float* partial = reinterpret_cast<float*>(workspace);
+  dim3 grid1((C + CS_COLS - 1) / CS_COLS, (unsigned)chunks), grid2((C + 255) / 256, E);
   return by_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    hipLaunchKernelGGL((group_colsum_kernel<T>), grid, dim3(256), 0, s, (const T*)src, offsets, C, out);
-    SMOE_CHECK_LAUNCH("smoe_group_colsum");
+    hipLaunchKernelGGL((group_colsum_partial_kernel<T>), grid1, dim3(256), 0, s, (const T*)src, offsets, E, C, partial);
+    SMOE_CHECK_LAUNCH("smoe_group_colsum/partial");
+    hipLaunchKernelGGL(group_colsum_final_kernel, grid2, dim3(256), 0, s, partial, offsets, C, out);
+    SMOE_CHECK_LAUNCH("smoe_group_colsum/final");
     return 0;
   });
 }

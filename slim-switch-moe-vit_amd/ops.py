@@ -398,10 +398,15 @@ def grouped_wgrad(PT: torch.Tensor, QT: torch.Tensor, offsets_pad: torch.Tensor)
 
 
 def group_colsum(src: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    """out[e, c] = sum of the rows of group e (bias gradients); deterministic two-pass reduction."""
     _chk(src, "src", ndim=2)
     E = offsets.numel() - 1
-    out = torch.empty((E, src.shape[1]), dtype=torch.float32, device=src.device)
-    rc = _lib.load().smoe_group_colsum(_ptr(src), dtype_code(src.dtype), _ptr(offsets), E, src.shape[1], _ptr(out),
-                                       _stream(src))
+    n, C = src.shape
+    lib = _lib.load()
+    out = torch.empty((E, C), dtype=torch.float32, device=src.device)
+    ws_bytes = lib.smoe_group_colsum_workspace_bytes(n, E, C)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=src.device)
+    rc = lib.smoe_group_colsum(_ptr(src), dtype_code(src.dtype), _ptr(offsets), E, n, C, _ptr(out), _ptr(ws), ws_bytes,
+                               _stream(src))
     _lib.check(rc, "smoe_group_colsum")
     return out

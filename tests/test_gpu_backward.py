@@ -128,6 +128,23 @@ def test_cfg5_switch_capacity_aux_backward():
     assert _rel(xg.grad.cpu()[dropped], leaves[0].grad[dropped]) < 5e-3
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 2e-2), (torch.float32, 1e-5)])
+def test_group_colsum_many_chunks_and_empty_groups(dtype, tol):
+    """Bias-gradient reduction over groups spanning several 512-row chunks, chunk-boundary sizes and empty groups;
+    deterministic (two runs bit-identical)."""
+    counts = [1500, 0, 512, 513, 1, 0, 1023, 7]
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device=DEV)
+    n, C = sum(counts), 776
+    src = (torch.randn(n + 5, C, generator=_gen(3)) * 0.5).to(dtype).to(DEV)   # rows past offsets[E] are ignored
+    got = ops.group_colsum(src, offsets)
+    again = ops.group_colsum(src, offsets)
+    assert torch.equal(got, again)
+    o = offsets.tolist()
+    for e in range(len(counts)):
+        ref = src[o[e]:o[e + 1]].double().sum(0).cpu()
+        assert (got[e].cpu().double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
 def test_expert_parallel_training_path_on_one_gpu():
     """fwd + bwd through the expert-parallel code path (count exchange, all-to-all-v each way and their adjoints,
     grouped GEMMs / wgrad with the group -> expert map) on a world of one rank == the single-rank training path."""
