@@ -148,6 +148,12 @@ int smoe_transpose_pad(const void* src, int dtype, const int32_t* offsets, const
                        int64_t n_rows, int C, int Lp, void* dst, void* stream);
 int smoe_grouped_wgrad(const void* PT, const void* QT, int ab_dtype, const int32_t* offsets_pad, int E, int R1,
                        int R2, int Lp, float* out, void* stream);
+/* smoe_gate_wgrad: router weight gradient dWg [E, C] f32 = dl^T x, dl [n_rows, E] f32 (d loss / d logits), x [n_rows, C]
+ * f32 / f16 / bf16; E <= 16, C % 4 == 0; HBM-bound two-pass weighted column sum (what torch's matmul backward of the gate
+ * nn.Linear computes, models/resmoe_flop_hook.py:7-8 names that layer). */
+size_t smoe_gate_wgrad_workspace_bytes(int64_t n_rows, int E, int C);
+int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int64_t n_rows, int E, int C, float* out, void* workspace,
+                    size_t workspace_bytes, void* stream);
 size_t smoe_group_colsum_workspace_bytes(int64_t n_rows_max, int E, int C);
 int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int64_t n_rows_max, int C, float* out,
                       void* workspace, size_t workspace_bytes, void* stream);

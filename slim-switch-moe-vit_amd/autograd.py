@@ -157,6 +157,32 @@ class _GroupFFN(torch.autograd.Function):
         return drows, dW1, db1, dW2, db2, None, None, None, None
 
 
+class _GateLogits(torch.autograd.Function):
+    """logits = x Wg^T + bg.  Forward value: the logits the HIP router already computed (f32 accumulate, f64 for the
+    tokens it had to re-evaluate) -- no second projection; backward: dx = dl Wg (a thin library GEMM), dWg = dl^T x as a
+    streaming reduction (smoe_gate_wgrad; the library's skinny-output GEMM needs 4x the HBM time), dbg = column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, logits):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return logits.view_as(logits)
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, w = ctx.saved_tensors
+        dl = dl.float().contiguous()
+        dx = (dl @ w.float()).to(x.dtype) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if x.is_cuda and dl.shape[1] <= 16 and x.shape[1] % 4 == 0 and x.dtype in (torch.float32, torch.float16, torch.bfloat16):
+                dw = ops.gate_wgrad(dl, x.contiguous()).to(w.dtype)
+            else:
+                dw = (dl.t() @ x.float()).to(w.dtype)
+        db = dl.sum(0) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
 def _route_train(mod, x):
     """HIP routing + the differentiable gate score; returns (idx, score, plan tensors)."""
     from .fmoe import SwitchGate
@@ -168,13 +194,14 @@ def _route_train(mod, x):
     noise = g.make_noise(T, x.device) if is_switch else None
     gw = g.gate.weight.detach().float().contiguous()
     gb = g.gate.bias.detach().float() if g.gate.bias is not None else None
+    need_grad = is_switch or k > 1
     with torch.no_grad():
-        idx, score_c, _, _ = ops.router_topk(x.detach(), gw, gb, k, g.kind, noise)
+        idx, score_c, logits_r, _ = ops.router_topk(x.detach(), gw, gb, k, g.kind, noise, want_logits=need_grad)
         cap = g.capacity(T)
         counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, g.tot_expert, cap)
     mod.last_plan = (idx, score_c, counts, offsets, pos, inv_pos)
-    if is_switch or k > 1:  # tiny [T,E] work -- the routing itself stays the HIP router's
-        logits = F.linear(x.float(), g.gate.weight.float(), g.gate.bias.float() if g.gate.bias is not None else None)
+    if need_grad:  # tiny [T,E] work -- the routing itself stays the HIP router's
+        logits = _GateLogits.apply(x, g.gate.weight, g.gate.bias, logits_r)
         if is_switch:
             if noise is not None:
                 logits = logits + noise

@@ -190,6 +190,64 @@ __global__ __launch_bounds__(256) void group_colsum_final_kernel(const float* __
   out[(int64_t)e * C + c] = acc;
 }
 
+// Router weight gradient dWg[e, c] = sum_t dl[t, e] * x[t, c]: a [E x T] x [T x d] product whose output is tiny (E <= 16
+// rows) and whose K dimension is the token count -- an HBM-bound weighted column sum, not a GEMM (a library GEMM picks a
+// 32x16 tile and needs 180 us for 155 MB).  Same two deterministic passes as the bias gradients: 512-row chunk x
+// 256-column slab partials, then a sum over chunks.
+constexpr int GW_MAX_E = 16;
+
+template <typename T, int EB>
+__global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const float* __restrict__ dl, const T* __restrict__ x,
+                                                                 int64_t n_rows, int E, int C, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);  // [4 waves][EB][CS_COLS]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * CS_COLS + lane * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+  const int64_t r1 = r0 + CS_ROWS < n_rows ? r0 + CS_ROWS : n_rows;
+  float acc[EB][4];
+#pragma unroll
+  for (int e = 0; e < EB; ++e) acc[e][0] = acc[e][1] = acc[e][2] = acc[e][3] = 0.f;
+  if (c < C) {
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+      float v[4];
+      load4(x + r * C + c, v);
+      const float* g = dl + r * E;
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        const float w = e < E ? g[e] : 0.f;
+        acc[e][0] = fmaf(w, v[0], acc[e][0]);
+        acc[e][1] = fmaf(w, v[1], acc[e][1]);
+        acc[e][2] = fmaf(w, v[2], acc[e][2]);
+        acc[e][3] = fmaf(w, v[3], acc[e][3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EB; ++e)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[(wave * EB + e) * CS_COLS + lane * 4 + i] = acc[e][i];
+  __syncthreads();
+  const int cc = blockIdx.x * CS_COLS + threadIdx.x;
+  if (cc < C) {
+    for (int e = 0; e < E; ++e) {
+      const float s01 = red[(0 * EB + e) * CS_COLS + threadIdx.x] + red[(1 * EB + e) * CS_COLS + threadIdx.x];
+      const float s23 = red[(2 * EB + e) * CS_COLS + threadIdx.x] + red[(3 * EB + e) * CS_COLS + threadIdx.x];
+      partial[((int64_t)blockIdx.y * E + e) * C + cc] = s01 + s23;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_wgrad_final_kernel(const float* __restrict__ partial, int n_chunks, int E, int C,
+                                                               float* __restrict__ out) {
+  const int e = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int k = 0; k < n_chunks; ++k) acc += partial[((int64_t)k * E + e) * C + c];
+  out[(int64_t)e * C + c] = acc;
+}
+
 template <typename F> int by_dtype(int code, F&& f) {
   switch (code) {
     case SMOE_F32: return f((float*)nullptr);
@@ -286,6 +344,48 @@ extern "C" int smoe_group_colsum(const void* src, int dtype, const int32_t* offs
     SMOE_CHECK_LAUNCH("smoe_group_colsum/partial");
     hipLaunchKernelGGL(group_colsum_final_kernel, grid2, dim3(256), 0, s, partial, offsets, C, out);
     SMOE_CHECK_LAUNCH("smoe_group_colsum/final");
+    return 0;
+  });
+}
+
+extern "C" size_t smoe_gate_wgrad_workspace_bytes(int64_t n_rows, int E, int C) {
+  if (n_rows < 0 || E < 1 || C < 1) return 0;
+  return (size_t)((n_rows + CS_ROWS - 1) / CS_ROWS) * (size_t)E * (size_t)C * 4;
+}
+
+// dWg [E, C] (f32) = dl^T x for dl [n_rows, E] f32 and x [n_rows, C] (f32 / f16 / bf16); E <= 16, C % 4 == 0.
+extern "C" int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int64_t n_rows, int E, int C, float* out,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  SMOE_REQUIRE(out && E >= 1 && E <= GW_MAX_E && C > 0 && C % 4 == 0 && n_rows >= 0, "smoe_gate_wgrad: bad arguments (E <= %d, C %% 4 == 0)", GW_MAX_E);
+  hipStream_t s = (hipStream_t)stream;
+  if (n_rows == 0) {
+    hipError_t me = hipMemsetAsync(out, 0, (size_t)E * C * 4, s);
+    SMOE_REQUIRE(me == hipSuccess, "smoe_gate_wgrad: memset failed");
+    return 0;
+  }
+  SMOE_REQUIRE(dl && x, "smoe_gate_wgrad: null pointer");
+  SMOE_REQUIRE(workspace && workspace_bytes >= smoe_gate_wgrad_workspace_bytes(n_rows, E, C), "smoe_gate_wgrad: workspace too small");
+  const int64_t chunks = (n_rows + CS_ROWS - 1) / CS_ROWS;
+  SMOE_REQUIRE(chunks <= 65535, "smoe_gate_wgrad: too many rows (%lld)", (long long)n_rows);
+  float* partial = reinterpret_cast<float*>(workspace);
+  dim3 grid1((C + CS_COLS - 1) / CS_COLS, (unsigned)chunks), grid2((C + 255) / 256, E);
+  return by_dtype(x_dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    if (E <= 8) {
+      hipLaunchKernelGGL((gate_wgrad_partial_kernel<T, 8>), grid1, dim3(256), (size_t)4 * 8 * CS_COLS * 4, s, dl, (const T*)x, n_rows, E, C, partial);
+    } else {
+      auto kern = gate_wgrad_partial_kernel<T, 16>;
+      static bool attr_done = false;
+      if (!attr_done) {
+        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * CS_COLS * 4);
+        SMOE_REQUIRE(ae == hipSuccess, "smoe_gate_wgrad: hipFuncSetAttribute failed");
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(kern, grid1, dim3(256), (size_t)4 * 16 * CS_COLS * 4, s, dl, (const T*)x, n_rows, E, C, partial);
+    }
+    SMOE_CHECK_LAUNCH("smoe_gate_wgrad/partial");
+    hipLaunchKernelGGL(gate_wgrad_final_kernel, grid2, dim3(256), 0, s, partial, (int)chunks, E, C, out);
+    SMOE_CHECK_LAUNCH("smoe_gate_wgrad/final");
     return 0;
   });
 }

@@ -397,6 +397,23 @@ def grouped_wgrad(PT: torch.Tensor, QT: torch.Tensor, offsets_pad: torch.Tensor)
     return out
 
 
+def gate_wgrad(dl: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dWg [E, d] f32 = dl^T x for dl [T, E] f32, x [T, d]: the router weight gradient as a streaming reduction."""
+    _chk(dl, "dl", torch.float32, 2, align=4)
+    _chk(x, "x", ndim=2)
+    T, E = dl.shape
+    C = x.shape[1]
+    if x.shape[0] != T:
+        raise RuntimeError("gate_wgrad: row counts differ")
+    lib = _lib.load()
+    out = torch.empty((E, C), dtype=torch.float32, device=x.device)
+    ws_bytes = lib.smoe_gate_wgrad_workspace_bytes(T, E, C)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    rc = lib.smoe_gate_wgrad(_ptr(dl), _ptr(x), dtype_code(x.dtype), T, E, C, _ptr(out), _ptr(ws), ws_bytes, _stream(x))
+    _lib.check(rc, "smoe_gate_wgrad")
+    return out
+
+
 def group_colsum(src: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     """out[e, c] = sum of the rows of group e (bias gradients); deterministic two-pass reduction."""
     _chk(src, "src", ndim=2)

@@ -273,3 +273,15 @@ def test_two_expert_parallel_ranks_training_step_on_one_gpu():
     for rank, errs in got.items():
         for name, err in errs.items():
             assert err < 2e-3, (rank, name, err)
+
+
+@pytest.mark.parametrize("T,E,d,dtype", [(1, 4, 64, torch.float32), (5000, 8, 768, torch.float32), (1537, 16, 192, torch.float16),
+                                          (700, 3, 1024, torch.bfloat16)])
+def test_gate_wgrad_matches_matmul(T, E, d, dtype):
+    g = _gen(T + E)
+    dl = torch.randn(T, E, generator=g)
+    x = torch.randn(T, d, generator=g).to(dtype)
+    got = ops.gate_wgrad(dl.to(DEV), x.to(DEV)).cpu().double()
+    ref = dl.double().t() @ x.double()
+    assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()) * (T ** 0.5)
+    assert torch.equal(ops.gate_wgrad(dl.to(DEV), x.to(DEV)).cpu().double(), got)   # deterministic
