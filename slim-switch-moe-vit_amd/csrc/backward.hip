@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void group_colsum_final_kernel(const float* __
 // 32x16 tile and needs 180 us for 155 MB).  Same two deterministic passes as the bias gradients: 512-row chunk x
 // 256-column slab partials, then a sum over chunks.
 constexpr int GW_MAX_E = 16;
+constexpr int GW_ROWS = 256;  // rows per chunk: ~600 workgroups at T = 50k, all resident
 
 template <typename T, int EB>
 __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const float* __restrict__ dl, const T* __restrict__ x,
@@ -203,15 +204,13 @@ __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const float* __
   float* red = reinterpret_cast<float*>(smem_raw);  // [4 waves][EB][CS_COLS]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * CS_COLS + lane * 4;
-  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
-  const int64_t r1 = r0 + CS_ROWS < n_rows ? r0 + CS_ROWS : n_rows;
+  const int64_t r0 = (int64_t)blockIdx.y * GW_ROWS;
+  const int64_t r1 = r0 + GW_ROWS < n_rows ? r0 + GW_ROWS : n_rows;
   float acc[EB][4];
 #pragma unroll
   for (int e = 0; e < EB; ++e) acc[e][0] = acc[e][1] = acc[e][2] = acc[e][3] = 0.f;
   if (c < C) {
-    for (int64_t r = r0 + wave; r < r1; r += 4) {
-      float v[4];
-      load4(x + r * C + c, v);
+    auto row = [&](int64_t r, const float (&v)[4]) {
       const float* g = dl + r * E;
 #pragma unroll
       for (int e = 0; e < EB; ++e) {
@@ -221,6 +220,20 @@ __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const float* __
         acc[e][2] = fmaf(w, v[2], acc[e][2]);
         acc[e][3] = fmaf(w, v[3], acc[e][3]);
       }
+    };
+    int64_t r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {  // four rows of x in flight per lane
+      float v0[4], v1[4], v2[4], v3[4];
+      load4(x + r * C + c, v0);
+      load4(x + (r + 4) * C + c, v1);
+      load4(x + (r + 8) * C + c, v2);
+      load4(x + (r + 12) * C + c, v3);
+      row(r, v0); row(r + 4, v1); row(r + 8, v2); row(r + 12, v3);
+    }
+    for (; r < r1; r += 4) {
+      float v0[4];
+      load4(x + r * C + c, v0);
+      row(r, v0);
     }
   }
 #pragma unroll
@@ -238,14 +251,24 @@ __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const float* __
   }
 }
 
+// one workgroup per (64-column slab, expert): wave w adds chunks w, w+4, ... (lane = column), the four meet in LDS
 __global__ __launch_bounds__(256) void gate_wgrad_final_kernel(const float* __restrict__ partial, int n_chunks, int E, int C,
                                                                float* __restrict__ out) {
-  const int e = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float acc = 0.f;
-  for (int k = 0; k < n_chunks; ++k) acc += partial[((int64_t)k * E + e) * C + c];
-  out[(int64_t)e * C + c] = acc;
+  __shared__ float red[4][64];
+  const int e = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    int k = wave;
+    for (; k + 4 < n_chunks; k += 8) {
+      a0 += partial[((int64_t)k * E + e) * C + c];
+      a1 += partial[((int64_t)(k + 4) * E + e) * C + c];
+    }
+    if (k < n_chunks) a0 += partial[((int64_t)k * E + e) * C + c];
+  }
+  red[wave][lane] = a0 + a1;
+  __syncthreads();
+  if (wave == 0 && c < C) out[(int64_t)e * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 template <typename F> int by_dtype(int code, F&& f) {
@@ -350,7 +373,7 @@ extern "C" int smoe_group_colsum(const void* src, int dtype, const int32_t* offs
 
 extern "C" size_t smoe_gate_wgrad_workspace_bytes(int64_t n_rows, int E, int C) {
   if (n_rows < 0 || E < 1 || C < 1) return 0;
-  return (size_t)((n_rows + CS_ROWS - 1) / CS_ROWS) * (size_t)E * (size_t)C * 4;
+  return (size_t)((n_rows + GW_ROWS - 1) / GW_ROWS) * (size_t)E * (size_t)C * 4;
 }
 
 // dWg [E, C] (f32) = dl^T x for dl [n_rows, E] f32 and x [n_rows, C] (f32 / f16 / bf16); E <= 16, C % 4 == 0.
@@ -365,10 +388,10 @@ extern "C" int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int6
   }
   SMOE_REQUIRE(dl && x, "smoe_gate_wgrad: null pointer");
   SMOE_REQUIRE(workspace && workspace_bytes >= smoe_gate_wgrad_workspace_bytes(n_rows, E, C), "smoe_gate_wgrad: workspace too small");
-  const int64_t chunks = (n_rows + CS_ROWS - 1) / CS_ROWS;
+  const int64_t chunks = (n_rows + GW_ROWS - 1) / GW_ROWS;
   SMOE_REQUIRE(chunks <= 65535, "smoe_gate_wgrad: too many rows (%lld)", (long long)n_rows);
   float* partial = reinterpret_cast<float*>(workspace);
-  dim3 grid1((C + CS_COLS - 1) / CS_COLS, (unsigned)chunks), grid2((C + 255) / 256, E);
+  dim3 grid1((C + CS_COLS - 1) / CS_COLS, (unsigned)chunks), grid2((C + 63) / 64, E);
   return by_dtype(x_dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
     if (E <= 8) {
