@@ -38,9 +38,10 @@ def parse():
     ap.add_argument("--experts", type=int, default=8, help="global number of experts")
     ap.add_argument("--compute-dtype", default=os.environ.get("SLIMMOE_COMPUTE_DTYPE", "f16"), choices=["f16", "bf16", "f32"])
     ap.add_argument("--ep-chunks", type=int, default=1)
-    ap.add_argument("--ep-micro-batches", type=int, default=2,
+    ap.add_argument("--ep-micro-batches", type=int, default=0,
                     help="expert parallel only: micro-batches of the local batch interleaved through the model so that "
-                         "count read-backs and all-to-alls of one run under the other's compute (1 = off)")
+                         "count read-backs and all-to-alls of one run under the other's compute (1 = off; 0 = time "
+                         "1, 2 and 3 during warm-up and keep the fastest -- the right depth depends on the link rate)")
     ap.add_argument("--cpu-batch", type=int, default=16, help="images in the CPU-oracle sample")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,7 +82,7 @@ def build_model(args, world, rank, device):
             blk.mlp.force_ep = bool(getattr(args, "force_ep", False))
             # the head is zero-initialised in the reference (vision_transformer.py:859-861); give it signal
         torch.nn.init.trunc_normal_(model.head.weight, std=0.02, a=-2, b=2, generator=g)
-    model.ep_micro_batches = args.ep_micro_batches
+    model.ep_micro_batches = max(1, args.ep_micro_batches)
     sd_cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -171,6 +172,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    ep_tuning = None
+    if (world > 1 or args.force_ep) and args.ep_micro_batches == 0:
+        # pipeline depth: fewer micro-batches = bigger, more efficient kernels; more = more transfer hidden.  Which
+        # wins depends on the xGMI rate at this world size, so measure (every rank takes the same, all-reduced, decision)
+        ep_tuning = {}
+        for n in (1, 2, 3):
+            model.ep_micro_batches = n
+            for _ in range(2):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step()
+            fence()
+            t = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ep_tuning[n] = round(float(t.item()) * 1e3, 3)
+        args.ep_micro_batches = min(ep_tuning, key=ep_tuning.get)
+        model.ep_micro_batches = args.ep_micro_batches
     for _ in range(args.warmup):
         step()
     fence()
@@ -212,7 +233,10 @@ def main():
         ep_info = {"a2a_payload_mb_per_rank": round(rows * 768 * 2 / 1e6, 1), "a2a_ms": round(a2a_ms, 4),
                    "a2a_gb_s_per_link": round(per_peer / (a2a_ms * 1e-3) / 1e9, 1), "link_peak_gb_s_bidir": 153,
                    "a2a_per_step": 24, "a2a_ms_per_step_if_exposed": round(24 * a2a_ms, 3),
-                   "micro_batches": args.ep_micro_batches}
+                   "micro_batches": args.ep_micro_batches, "micro_batch_tuning_ms_per_step": ep_tuning}
+
+    if ep_info is None and ep_tuning is not None:
+        ep_info = {"micro_batches": args.ep_micro_batches, "micro_batch_tuning_ms_per_step": ep_tuning}
 
     # ---- per-kernel accounting from the HIP events recorded inside the timed region --------------------
     agg = {}
