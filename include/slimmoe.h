@@ -117,14 +117,19 @@ int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, cons
  * multiplied by row_scale[row_map[r]] if row_scale != NULL  (MOEGather + bmm for k = 1).
  * Optional fused residual (residual != NULL, same dtype / shape as out): the stored value is
  * residual[orow, :] + value -- the `x + mlp(norm2(x))` add of models/vision_transformer.py:321.
- * Optional fused scatter (a_gather != NULL; variant 4 only): row r of the GEMM reads A[a_gather[r] / a_div, :]
+ * Optional fused scatter (a_gather != NULL; variants 4-8): row r of the GEMM reads A[a_gather[r] / a_div, :]
  * instead of A[r, :] -- MOEScatter's index_select(x, pos // k) folded into the operand DMA (A = the token matrix).
  * SMOE_EPI_GELU_GRAD (backward of the activation, fused into the dgrad GEMM): `residual` then holds the saved
  * pre-activations H and the stored value is value * gelu'(H[r, :]).
  * Optional group -> expert map (group_expert != NULL, i32 [G]): `offsets` then delimits G row groups and
  * group g uses W[group_expert[g]] / bias[group_expert[g]] (expert-parallel receive layout: one group per
  * (source rank, local expert)); n_experts = leading dimension of W / bias.
- * Requires K*sizeof(ab) % 128 == 0 and N % 8 == 0.                                                  */
+ * Requires K*sizeof(ab) % 128 == 0 and N % 8 == 0.
+ * variant: 4 = production choice (8-wave ping-pong kernel, LDS-DMA staging; picks the 256- or 320-row tile by the
+ * number of workgroup rounds and, for K >= 2048, the deep prefetch schedule); 5 / 6 force the 320- / 256-row tile,
+ * 7 / 8 the deep schedule on the 256- / 320-row tile; 1-3 earlier LDS-DMA structures and 0 the register-staged
+ * kernel (the only one for f32 operands or K % 64 != 0; chosen automatically then) are kept as A/B references.
+ * All variants compute the same function.                                                              */
 int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int32_t* offsets,
                       const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
                       int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,
