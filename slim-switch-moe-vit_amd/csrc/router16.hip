@@ -1,4 +1,5 @@
-// Router, 16-lanes-per-token layout (E <= 8, d in {192, 384, 768, 1024}): the fast path of smoe_router_topk.
+// Router, 16-lanes-per-token layout (E <= 8 at d in {192, 384, 768, 1024}; E <= 16 at d in {768, 1024}): the fast
+// path of smoe_router_topk.  EB = experts held per lane (8 or 16 accumulator pairs).
 //
 // Four tokens per wave: lane = 16 q + u handles the float4 chunks u, u+16, u+32, ... of token slot q (every load
 // instruction covers 4 x 256 contiguous bytes).  Per-token reductions are 4 DPP-modified adds inside a 16-lane
@@ -14,7 +15,6 @@ namespace {
 
 constexpr int R16_THREADS = 256;
 constexpr int R16_MAX_K = 4;
-constexpr int R16_E = 8;
 
 template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
   const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
@@ -43,18 +43,18 @@ __device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v
 // normalised in registers (two-pass mean / variance over the 16-lane row, f32), written once as the 16-bit
 // operand image the expert GEMM gathers from (xn16) and optionally as f32 (xn32), and routed on its f32 value.
 // The f64 redo pass recomputes the same normalisation with the same lane layout, hence bit-identical inputs.
-template <typename XT, int NJ, int MODE, bool LN, typename NT>
-__global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_kernel(
+template <typename XT, int NJ, int MODE, bool LN, typename NT, int EB>
+__global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? 4 : 2) : 2)) void router16_kernel(
     const XT* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
     NT* __restrict__ xn16, float* __restrict__ xn32, const float* __restrict__ wg, const float* __restrict__ bg,
     const float* __restrict__ noise, int64_t T, int d, int E, int k, int gate_kind,
     int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_list, int64_t* __restrict__ idx_out,
     float* __restrict__ score_out, float* __restrict__ logits_out, float* __restrict__ probs_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* lds_w = reinterpret_cast<float*>(smem);            // [R16_E][d], rows >= E zero
-  float* lds_wn2 = lds_w + R16_E * d;                        // [R16_E]
-  float* lds_bias = lds_wn2 + R16_E;                         // [R16_E] gate bias, zero where absent (branch-free add)
-  float* lds_g = lds_bias + R16_E;                           // [d] LayerNorm weight, then [d] bias (LN only)
+  float* lds_w = reinterpret_cast<float*>(smem);            // [EB][d], rows >= E zero
+  float* lds_wn2 = lds_w + EB * d;                        // [EB]
+  float* lds_bias = lds_wn2 + EB;                         // [EB] gate bias, zero where absent (branch-free add)
+  float* lds_g = lds_bias + EB;                           // [d] LayerNorm weight, then [d] bias (LN only)
   float* lds_be = lds_g + d;
   d = 64 * NJ;  // the launcher only dispatches exact multiples: makes every chunk bound below compile-time
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,12 +87,12 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
   };
   if (it0 < n_items) fetch(it0);
 
-  for (int i = tid * 4; i < R16_E * d; i += R16_THREADS * 4) {
+  for (int i = tid * 4; i < EB * d; i += R16_THREADS * 4) {
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
     if (i / d < E) v = *reinterpret_cast<const f32x4*>(wg + i);
     *reinterpret_cast<f32x4*>(lds_w + i) = v;
   }
-  if (tid < R16_E) lds_bias[tid] = (bg && tid < E) ? bg[tid] : 0.f;
+  if (tid < EB) lds_bias[tid] = (bg && tid < E) ? bg[tid] : 0.f;
   if (LN) {
     for (int i = tid; i < d; i += R16_THREADS) {
       lds_g[i] = ln_g ? ln_g[i] : 1.f;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
     }
   }
   __syncthreads();
-  for (int e = wave; MODE == 0 && e < R16_E; e += R16_THREADS / 64) {  // squared row norms, one wave per expert row
+  for (int e = wave; MODE == 0 && e < EB; e += R16_THREADS / 64) {  // squared row norms, one wave per expert row
     float s = 0.f;
     for (int c = lane; c < d; c += 64) s = fmaf(lds_w[e * d + c], lds_w[e * d + c], s);
 #pragma unroll
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
   __syncthreads();
   float wmax2 = 0.f;
 #pragma unroll
-  for (int e = 0; e < R16_E; ++e) wmax2 = fmaxf(wmax2, lds_wn2[e]);
+  for (int e = 0; e < EB; ++e) wmax2 = fmaxf(wmax2, lds_wn2[e]);
 
   while (it0 < n_items) {
     const int64_t t = t_next;
@@ -163,16 +163,16 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
         }
       }
     }
-    float lg[R16_E];
+    float lg[EB];
     if constexpr (MODE == 0) {
       // two partial sums per expert (even / odd element pairs): packed f32 FMAs, half the issue slots
-      f32x2 acc[R16_E];
+      f32x2 acc[EB];
 #pragma unroll
-      for (int e = 0; e < R16_E; ++e) acc[e] = f32x2{0.f, 0.f};
+      for (int e = 0; e < EB; ++e) acc[e] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-        for (int e = 0; e < R16_E; ++e) {
+        for (int e = 0; e < EB; ++e) {
           const f32x4 w = *reinterpret_cast<const f32x4*>(lds_w + ub + (e * d + 64 * j));
           acc[e] = __builtin_elementwise_fma(lo2(xv[j]), lo2(w), acc[e]);
           acc[e] = __builtin_elementwise_fma(hi2(xv[j]), hi2(w), acc[e]);
@@ -180,15 +180,15 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
         __builtin_amdgcn_sched_barrier(0);  // one chunk's weight reads next to their FMAs (else: e-major reorder + spills)
       }
 #pragma unroll
-      for (int e = 0; e < R16_E; ++e) lg[e] = row16_sum(acc[e][0] + acc[e][1]) + lds_bias[e];
+      for (int e = 0; e < EB; ++e) lg[e] = row16_sum(acc[e][0] + acc[e][1]) + lds_bias[e];
     } else {
-      double acc[R16_E];
+      double acc[EB];
 #pragma unroll
-      for (int e = 0; e < R16_E; ++e) acc[e] = 0.0;
+      for (int e = 0; e < EB; ++e) acc[e] = 0.0;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-        for (int e = 0; e < R16_E; ++e) {
+        for (int e = 0; e < EB; ++e) {
           const f32x4 w = *reinterpret_cast<const f32x4*>(lds_w + ub + (e * d + 64 * j));
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[e] = fma((double)xv[j][i], (double)w[i], acc[e]);
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int e = 0; e < R16_E; ++e) lg[e] = (float)(row16_sum(acc[e]) + (double)lds_bias[e]);
+      for (int e = 0; e < EB; ++e) lg[e] = (float)(row16_sum(acc[e]) + (double)lds_bias[e]);
     }
     float xs = 0.f;  // |x|^2 for the error bound (MODE 0); last use of the row registers
     if constexpr (MODE == 0) {
@@ -210,12 +210,12 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
     if (it0 < n_items) fetch(it0);  // next row on its way while this one is ranked and stored
     if (logits_out && live && u == 0) {
 #pragma unroll
-      for (int e = 0; e < R16_E; ++e)
+      for (int e = 0; e < EB; ++e)
         if (e < E) logits_out[t * (int64_t)E + e] = lg[e];
     }
     if (gate_kind == SMOE_GATE_SWITCH && noise && live) {
 #pragma unroll
-      for (int e = 0; e < R16_E; ++e)
+      for (int e = 0; e < EB; ++e)
         if (e < E) lg[e] += noise[t * (int64_t)E + e];
     }
     // top-kc in registers: ties -> lowest id, descending value.  Working copy with absent / already chosen
@@ -223,9 +223,9 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
     const int kc = (MODE == 0 && k < E) ? k + 1 : k;
     int chosen[R16_MAX_K + 1];
     float cval[R16_MAX_K + 1];
-    float lw[R16_E];
+    float lw[EB];
 #pragma unroll
-    for (int e = 0; e < R16_E; ++e) lw[e] = (e < E) ? lg[e] : -INFINITY;
+    for (int e = 0; e < EB; ++e) lw[e] = (e < E) ? lg[e] : -INFINITY;
 #pragma unroll
     for (int r = 0; r <= R16_MAX_K; ++r) {
       chosen[r] = 0;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
         float bv = lw[0];
         int bi = 0;
 #pragma unroll
-        for (int e = 1; e < R16_E; ++e) {
+        for (int e = 1; e < EB; ++e) {
           const bool gt = lw[e] > bv;
           bv = gt ? lw[e] : bv;
           bi = gt ? e : bi;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
         cval[r] = bv;
         if (r + 1 < kc) {
 #pragma unroll
-          for (int e = 0; e < R16_E; ++e) lw[e] = (e == bi) ? -INFINITY : lw[e];
+          for (int e = 0; e < EB; ++e) lw[e] = (e == bi) ? -INFINITY : lw[e];
         }
       }
     }
@@ -277,16 +277,16 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? 4 : 2)) void router16_ker
           }
       } else {
         const float mx = cval[0];
-        float pe[R16_E];
+        float pe[EB];
         float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < R16_E; ++e) {
+        for (int e = 0; e < EB; ++e) {
           pe[e] = (e < E) ? expf(lg[e] - mx) : 0.f;
           s += pe[e];
         }
         if (probs_out) {
 #pragma unroll
-          for (int e = 0; e < R16_E; ++e)
+          for (int e = 0; e < EB; ++e)
             if (e < E) probs_out[t * (int64_t)E + e] = pe[e] / s;
         }
         idx_out[t] = chosen[0];
@@ -380,19 +380,34 @@ struct LnArgs {
   const float* g; const float* b; float eps; void* xn16; int xn16_dtype; float* xn32; bool on;
 };
 
-template <typename XT, int NJ, bool LN, typename NT>
+template <typename XT, int NJ, bool LN, typename NT, int EB>
 int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, const float* noise, int64_t T, int d,
              int E, int k, int gate_kind, int force_f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score,
              float* logits_out, float* probs, hipStream_t s) {
-  const size_t smem = ((size_t)R16_E * d + 2 * R16_E + (LN ? 2 * (size_t)d : 0)) * 4;
+  const size_t smem = ((size_t)EB * d + 2 * EB + (LN ? 2 * (size_t)d : 0)) * 4;
   const int64_t tok_per_block = (R16_THREADS / 64) * 4;
   int64_t need = (T + tok_per_block - 1) / tok_per_block;
-  // <= 768 workgroups (3 resident per CU, the LDS weight image is loaded once per workgroup), every workgroup
-  // the same number of 16-token groups
-  const int64_t iters = (need + 767) / 768;
+  // <= 768 workgroups (3 resident per CU; 512 = 2 per CU for the 16-expert image: the LDS weight image is loaded once
+  // per workgroup), every workgroup the same number of 16-token groups
+  constexpr int64_t max_wg = EB <= 8 ? 768 : 512;
+  const int64_t iters = (need + max_wg - 1) / max_wg;
   const int grid = (int)(need < 1 ? 1 : (need + iters - 1) / (iters < 1 ? 1 : iters));
+  if (smem > 64 * 1024) {  // 16 experts x d 1024 (+ LayerNorm vectors): above the default dynamic-LDS limit
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(router16_kernel<XT, NJ, 0, LN, NT, EB>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(router16_kernel<XT, NJ, 1, LN, NT, EB>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (a0 != hipSuccess || a1 != hipSuccess) {
+        smoe_set_error("smoe_router_topk: hipFuncSetAttribute failed");
+        return 1;
+      }
+      attr_done = true;
+    }
+  }
 #define R16_LAUNCH(MODE, GRID, RC, RL)                                                                               \
-  hipLaunchKernelGGL((router16_kernel<XT, NJ, MODE, LN, NT>), dim3(GRID), dim3(R16_THREADS), smem, s, (const XT*)x,  \
+  hipLaunchKernelGGL((router16_kernel<XT, NJ, MODE, LN, NT, EB>), dim3(GRID), dim3(R16_THREADS), smem, s, (const XT*)x,  \
                      ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, noise, T, d, E, k, gate_kind, RC, RL, idx,   \
                      score, logits_out, probs)
   if (force_f64 && !LN) {
@@ -424,11 +439,18 @@ template <typename XT, bool LN, typename NT>
 int dispatch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, const float* noise, int64_t T, int d,
                int E, int k, int gate_kind, int f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score, float* lo,
                float* pr, hipStream_t s) {
+  if (E > 8) {  // 16 experts per lane: instantiated for the ViT-B / ViT-L widths only (compile time)
+    switch (d) {
+      case 768: return launch16<XT, 12, LN, NT, 16>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+      case 1024: return launch16<XT, 16, LN, NT, 16>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+    }
+    return -1;
+  }
   switch (d) {
-    case 192: return launch16<XT, 3, LN, NT>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
-    case 384: return launch16<XT, 6, LN, NT>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
-    case 768: return launch16<XT, 12, LN, NT>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
-    case 1024: return launch16<XT, 16, LN, NT>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+    case 192: return launch16<XT, 3, LN, NT, 8>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+    case 384: return launch16<XT, 6, LN, NT, 8>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+    case 768: return launch16<XT, 12, LN, NT, 8>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+    case 1024: return launch16<XT, 16, LN, NT, 8>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
   }
   return -1;
 }
@@ -446,7 +468,9 @@ int dispatch16_ln(const void* x, const LnArgs& ln, const float* wg, const float*
 }  // namespace
 
 static bool shape_ok16(int d, int E, int k) {
-  return E <= R16_E && k <= R16_MAX_K && (d == 192 || d == 384 || d == 768 || d == 1024);
+  if (k > R16_MAX_K) return false;
+  if (E <= 8) return d == 192 || d == 384 || d == 768 || d == 1024;
+  return E <= 16 && (d == 768 || d == 1024);
 }
 
 // returns -1 when the shape is not covered by this fast path (caller falls back to router.hip)
