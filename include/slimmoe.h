@@ -56,7 +56,7 @@ int smoe_router_topk(const void* x, int x_dtype, const float* wg, const float* b
 /* LayerNorm + router fused (block glue, models/vision_transformer.py:321 `mlp(norm2(x))`): xn = LN(x)*gamma+beta
  * is written as a 16-bit image (xn16: f16/bf16, may be NULL) and / or f32 (xn32, may be NULL) and routed exactly
  * as smoe_router_topk routes xn.  Shapes covered: smoe_ln_router_supported(d, E, k) (k <= 4; E <= 8 with
- * d in {192, 384, 768, 1024}, E <= 16 with d in {768, 1024}); workspace as smoe_router_workspace_bytes(T). */
+ * d in {192, 384, 768, 1024}, E <= 32 with d in {768, 1024}); workspace as smoe_router_workspace_bytes(T). */
 int smoe_ln_router_supported(int d, int E, int k);
 int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_gamma, const float* ln_beta, float ln_eps,
                         void* xn16, int xn16_dtype, float* xn32, const float* wg, const float* bg, const float* noise,

@@ -1,5 +1,5 @@
-// Router, 16-lanes-per-token layout (E <= 8 at d in {192, 384, 768, 1024}; E <= 16 at d in {768, 1024}): the fast
-// path of smoe_router_topk.  EB = experts held per lane (8 or 16 accumulator pairs).
+// Router, 16-lanes-per-token layout (E <= 8 at d in {192, 384, 768, 1024}; E <= 32 at d in {768, 1024}): the fast
+// path of smoe_router_topk.  EB = experts held per lane (8, 16 or 32 accumulator pairs).
 //
 // Four tokens per wave: lane = 16 q + u handles the float4 chunks u, u+16, u+32, ... of token slot q (every load
 // instruction covers 4 x 256 contiguous bytes).  Per-token reductions are 4 DPP-modified adds inside a 16-lane
@@ -44,7 +44,7 @@ __device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v
 // operand image the expert GEMM gathers from (xn16) and optionally as f32 (xn32), and routed on its f32 value.
 // The f64 redo pass recomputes the same normalisation with the same lane layout, hence bit-identical inputs.
 template <typename XT, int NJ, int MODE, bool LN, typename NT, int EB>
-__global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? 4 : 2) : 2)) void router16_kernel(
+__global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? 4 : (EB <= 16 ? 2 : 1)) : (EB <= 16 ? 2 : 1))) void router16_kernel(
     const XT* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
     NT* __restrict__ xn16, float* __restrict__ xn32, const float* __restrict__ wg, const float* __restrict__ bg,
     const float* __restrict__ noise, int64_t T, int d, int E, int k, int gate_kind,
@@ -389,7 +389,7 @@ int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, 
   int64_t need = (T + tok_per_block - 1) / tok_per_block;
   // <= 768 workgroups (3 resident per CU; 512 = 2 per CU for the 16-expert image: the LDS weight image is loaded once
   // per workgroup), every workgroup the same number of 16-token groups
-  constexpr int64_t max_wg = EB <= 8 ? 768 : 512;
+  constexpr int64_t max_wg = EB <= 8 ? 768 : (EB <= 16 ? 512 : 256);
   const int64_t iters = (need + max_wg - 1) / max_wg;
   const int grid = (int)(need < 1 ? 1 : (need + iters - 1) / (iters < 1 ? 1 : iters));
   if (smem > 64 * 1024) {  // 16 experts x d 1024 (+ LayerNorm vectors): above the default dynamic-LDS limit
@@ -439,6 +439,13 @@ template <typename XT, bool LN, typename NT>
 int dispatch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, const float* noise, int64_t T, int d,
                int E, int k, int gate_kind, int f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score, float* lo,
                float* pr, hipStream_t s) {
+  if (E > 16) {  // 32 experts per lane (one workgroup per CU: the f32 weight image is 96-128 KB); ViT-B / ViT-L widths
+    switch (d) {
+      case 768: return launch16<XT, 12, LN, NT, 32>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+      case 1024: return launch16<XT, 16, LN, NT, 32>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+    }
+    return -1;
+  }
   if (E > 8) {  // 16 experts per lane: instantiated for the ViT-B / ViT-L widths only (compile time)
     switch (d) {
       case 768: return launch16<XT, 12, LN, NT, 16>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
@@ -470,7 +477,7 @@ int dispatch16_ln(const void* x, const LnArgs& ln, const float* wg, const float*
 static bool shape_ok16(int d, int E, int k) {
   if (k > R16_MAX_K) return false;
   if (E <= 8) return d == 192 || d == 384 || d == 768 || d == 1024;
-  return E <= 16 && (d == 768 || d == 1024);
+  return E <= 32 && (d == 768 || d == 1024);
 }
 
 // returns -1 when the shape is not covered by this fast path (caller falls back to router.hip)

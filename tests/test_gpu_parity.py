@@ -40,7 +40,7 @@ def _mk(T, d, h, E, seed, wstd=0.02, skew=False):
 # ------------------------------------------------------------------------------------------ router
 @pytest.mark.parametrize("T,d,E,k", [(1, 192, 4, 1), (777, 192, 4, 2), (5000, 768, 8, 1), (3000, 768, 8, 2),
                                      (2000, 1024, 32, 1), (513, 64, 3, 3), (1000, 384, 70, 2), (4001, 768, 16, 1),
-                                     (1500, 1024, 12, 3)])
+                                     (1500, 1024, 12, 3), (2500, 768, 32, 2)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("force_f64", [False, True])
 def test_router_naive_matches_oracle(T, d, E, k, dtype, force_f64):
@@ -300,7 +300,7 @@ def test_forward_add_equals_residual_plus_forward(k, gate, cap):
 
 @pytest.mark.parametrize("d,h,E,k,gate", [(192, 768, 4, 1, "naive"), (768, 3072, 8, 1, "naive"), (384, 768, 8, 2, "naive"),
                                           (1024, 1024, 5, 1, "switch"), (768, 768, 16, 1, "naive"), (1024, 512, 13, 2, "naive"),
-                                          (768, 768, 16, 1, "switch")])
+                                          (768, 768, 16, 1, "switch"), (1024, 1024, 32, 1, "naive"), (768, 768, 27, 2, "naive")])
 def test_fused_layernorm_router_and_block_half(d, h, E, k, gate):
     """smoe_ln_router_topk + a_gather GEMM-1 + fused combine/residual == x + mlp(LayerNorm(x)):
     (a) the fused LayerNorm matches F.layer_norm, (b) routing equals the oracle's on the very same normalised rows,
