@@ -55,7 +55,7 @@ def build_model(args, world, rank, device):
     """ViT-B/16 shell + MoE MLP in every block; random init of that architecture (no checkpoints offline).
     Router / expert tensors are drawn for all E experts from one seed, then sliced per rank, so the
     N-GPU model is the same function as the 1-GPU model."""
-    import slim_switch_moe_vit_amd as sm
+    import slim_switch_moe_vit_amd  # noqa: F401  (registers the package alias for the hyphenated directory)
     from slim_switch_moe_vit_amd.vit import _deit
     from slim_switch_moe_vit_amd.resmoe import patch_blocks_with_moe
 

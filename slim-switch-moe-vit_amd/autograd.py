@@ -17,10 +17,9 @@ ordinary differentiable torch ops on logits recomputed from x, with the ROUTING 
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
 import torch
-import torch.nn.functional as F
 
 from . import ops
 

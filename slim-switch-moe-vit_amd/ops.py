@@ -6,7 +6,7 @@ Shapes / dtypes / contiguity are validated here, before the C call (SURVEY.md 8b
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

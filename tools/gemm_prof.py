@@ -3,7 +3,6 @@
 usage: gemm_prof.py <variant> <shape: fc1|fc1n|qkv|fc2|fc2h|sq8k|sq4k> [iters] [images (default 256)]"""
 import os
 import sys
-import time
 
 import torch
 

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Fused LayerNorm + router driver for timing / rocprofv3 (ViT-B shape: T = 256 x 197, d 768, E 8, k 1).
 usage: lnrouter_prof.py [iters] [images]; SMOE_LIB=<path> selects an alternative build of the library."""
-import ctypes, os, sys, torch
+import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import slim_switch_moe_vit_amd as sm
+import slim_switch_moe_vit_amd  # noqa: F401
 from slim_switch_moe_vit_amd import ops, _lib
 if os.environ.get("SMOE_LIB"):
     _lib.LIB_PATH = os.environ["SMOE_LIB"]
