@@ -153,6 +153,12 @@ int smoe_transpose_pad(const void* src, int dtype, const int32_t* offsets, const
                        int64_t n_rows, int C, int Lp, void* dst, void* stream);
 int smoe_grouped_wgrad(const void* PT, const void* QT, int ab_dtype, const int32_t* offsets_pad, int E, int R1,
                        int R2, int Lp, float* out, void* stream);
+/* smoe_grouped_wgrad_rows: the same weight gradients as smoe_grouped_wgrad, straight from the token-major operands
+ * (P [n_rows,R1], Q [n_rows,R2], f16 / bf16, expert-sorted rows; offsets i32 [E+1] = plain row ranges, any lengths):
+ * out[e] (f32 [R1,R2]) = sum_{r in expert e} P[r,:]^T Q[r,:].  No transposed copies: the MFMA fragments are read
+ * from LDS with transposing reads.  R1, R2 multiples of 8; zero16 = 16 zero bytes in device memory. */
+int smoe_grouped_wgrad_rows(const void* P, const void* Q, int ab_dtype, const int32_t* offsets, int E, int R1, int R2,
+                            const void* zero16, float* out, void* stream);
 /* smoe_gate_wgrad: router weight gradient dWg [E, C] f32 = dl^T x, dl [n_rows, E] f32 (d loss / d logits), x [n_rows, C]
  * f32 / f16 / bf16; E <= 16, C % 4 == 0; HBM-bound two-pass weighted column sum (what torch's matmul backward of the gate
  * nn.Linear computes, models/resmoe_flop_hook.py:7-8 names that layer). */

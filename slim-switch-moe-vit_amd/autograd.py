@@ -138,10 +138,10 @@ class _GroupFFN(torch.autograd.Function):
         else:
             dH = ops.grouped_gemm(dY, w2t, None, offsets, ops.EPI_GELU_GRAD, cd, variant=mod.gemm_variant,
                                   group_expert=gexp, residual=Hp)
-        offp = ops.pad_offsets(offsets)
-        Lp = ops.padded_len(n, G)
-        dW2 = ops.grouped_wgrad(ops.transpose_pad(dY, offsets, offp, Lp), ops.transpose_pad(A, offsets, offp, Lp), offp)
-        dW1 = ops.grouped_wgrad(ops.transpose_pad(dH, offsets, offp, Lp), ops.transpose_pad(rows, offsets, offp, Lp), offp)
+        # dW2[e] = dY_e^T A_e, dW1[e] = dH_e^T R_e straight from the token-major tensors (transposing LDS reads;
+        # smoe_transpose_pad + smoe_grouped_wgrad is the older two-step form, kept in ops for A/B tests)
+        dW2 = ops.grouped_wgrad_rows(dY, A, offsets)
+        dW1 = ops.grouped_wgrad_rows(dH, rows, offsets)
         db2 = ops.group_colsum(dY, offsets) if ctx.has_b2 else None
         db1 = ops.group_colsum(dH, offsets) if ctx.has_b1 else None
         if G != E_local:  # rank-major groups (source rank, local expert): fold the source ranks

@@ -11,5 +11,5 @@ void smoe_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int smoe_abi_version(void) { return 9; }
+extern "C" int smoe_abi_version(void) { return 10; }
 extern "C" const char* smoe_last_error(void) { return g_err; }

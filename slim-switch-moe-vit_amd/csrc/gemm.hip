@@ -619,6 +619,13 @@ int launch_glds(const void* A, const void* W, const float* bias, const int32_t* 
 // MODE 1 = weight-gradient GEMM: C[e] = P^T[:, k-range e] (Q^T[:, k-range e])^T with both operands stored K-major
 // ([rows, Lp], per-expert column ranges padded to multiples of 64: smoe_transpose_pad); `offsets` are the
 // padded ranges, K = Lp (row stride), N = rows of Q^T, m_rows = rows of P^T, one [m_rows, N] output per expert.
+// MODE 2 = the same weight gradient straight from the TOKEN-major operands P [rows, m_rows], Q [rows, N] (no transposed
+// copies): `offsets` are the experts' plain row ranges, K is unused.  A K-tile is 64 token rows; in LDS every 64-column
+// slab of the tile is stored [token][64 columns] in exactly the bytes the K-major layout gives 64 tile rows (so the DMA
+// pieces, regions and the re-staging schedule are unchanged), and the MFMA fragments -- 8 k-values of one output
+// column per lane -- come from ds_read_b64_tr_b16 (two transposed reads per fragment, as attention.hip reads V).  Both
+// operands use the same k-slot permutation (slot j of lane group g <-> token 32 kk + 16 (j >> 2) + 4 g + (j & 3)), which
+// a contraction does not see.  Rows past an expert's range read a 16-byte zero page (`residual` carries its address).
 // AFR = A row fragments per wave per A-half: tile height TBM = 64 * AFR (256 or 320 rows).  The taller tile cuts the
 // tile count (fc2 / proj at cfg 2: 600 -> 480 tiles = 2 instead of 3 rounds on 256 CUs) and raises FLOP per LDS-fill byte.
 template <typename AB, typename OT, int ABL = 0, int MODE = 0, int AFR = 4>
@@ -662,9 +669,10 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     n0 = (rem / group_m) * TBN;
     m_end = m_rows;
     k_base = offsets[e];
-    nk = (offsets[e + 1] - k_base) / 64;
+    nk = MODE == 2 ? (offsets[e + 1] - k_base + 63) / 64 : (offsets[e + 1] - k_base) / 64;
     out += (int64_t)e * m_rows * N;
   }
+  const int k_hi = (MODE == 2) ? offsets[e + 1] : 0;  // MODE 2: first row past this expert's range
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -673,8 +681,26 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   const int l_row = lane >> 3, l_pos = lane & 7;
   const AB* a_src[ASLOTS];
   const AB* w_src[SLOTS];
+  // per K-tile advance of the source pointers (elements): 64 k-columns, or 64 token rows in MODE 2
+  const int64_t a_step = (MODE == 2) ? (int64_t)64 * m_rows : 64, w_step = (MODE == 2) ? (int64_t)64 * N : 64;
+  int t_row[ASLOTS];  // MODE 2: token row (inside the K-tile) this lane stages in slot s
+  if constexpr (MODE == 2) {
+    static_assert(MODE != 2 || AFR == 4, "token-major wgrad is written for the 256-row tile");
 #pragma unroll
-  for (int s = 0; s < ASLOTS; ++s) {
+    for (int s = 0; s < ASLOTS; ++s) {
+      const int pc = s * NW + wave;             // 1-KiB piece: slab pc / 8 (64 output columns), token rows 8 (pc % 8) ..
+      const int row = 8 * (pc & 7) + l_row;
+      const int ch = (((l_pos >> 1) ^ ((row >> 1) & 3)) << 1) | (l_pos & 1);   // 32-byte segment swizzle (source side)
+      int ca = m0 + 64 * (pc >> 3) + ch * 8, cw = n0 + 64 * (pc >> 3) + ch * 8;
+      if (ca > m_rows - 8) ca = m_rows - 8;     // columns past the matrix: any valid address (those outputs are not stored)
+      if (cw > N - 8) cw = N - 8;
+      t_row[s] = row;
+      a_src[s] = A + (int64_t)(k_base + row) * m_rows + ca;
+      w_src[s] = W + (int64_t)(k_base + row) * N + cw;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < ASLOTS && MODE != 2; ++s) {
     const int r = 8 * (s * NW + wave) + l_row;
     int gr = m0 + r;
     if (gr >= m_end) gr = m_end - 1;
@@ -683,12 +709,27 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     a_src[s] = A + arow * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
   }
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) {
+  for (int s = 0; s < SLOTS && MODE != 2; ++s) {
     const int r = 8 * (s * NW + wave) + l_row;
     int gw = n0 + r;
     if (gw >= N) gw = N - 1;
     w_src[s] = W + ((int64_t)(MODE == 0 ? e : 0) * N + gw) * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
   }
+  // MODE 2: source of A piece s of K-tile kt -- the zero page once the token row is past the expert's range
+  auto a_ptr = [&](int s, int kt) -> const AB* {
+    if constexpr (MODE == 2) {
+      return (k_base + kt * 64 + t_row[s] < k_hi) ? a_src[s] + kt * a_step : reinterpret_cast<const AB*>(residual);
+    } else {
+      return a_src[s] + kt * a_step;
+    }
+  };
+  auto w_ptr = [&](int s, int kt) -> const AB* {
+    if constexpr (MODE == 2) {  // keep the address inside the allocation; its products meet zeros from A
+      return (k_base + kt * 64 + t_row[s] < k_hi) ? w_src[s] + kt * w_step : w_src[s];
+    } else {
+      return w_src[s] + kt * w_step;
+    }
+  };
   // DMA of A pieces of K-tile kt into buffer buf: "lo" (s0 == 0) = slots 0,1 (tile rows 0-127, read by wave group 0
   // only), "hi" = slots 2.. (the rest; for the 320-row tile slot 2 straddles the two groups' rows and is re-staged
   // with the group-1 region, after BOTH groups' last reads of it have retired)
@@ -698,21 +739,21 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     if (s0 == 0) {
 #pragma unroll
       for (int s = 0; s < 2; ++s)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s] + kt * 64),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr(s, kt)),
                                          (__attribute__((address_space(3))) void*)(sa + (s * NW + wave) * 1024), 16, 0, 0);
     } else {
 #pragma unroll
       for (int s = 2; s < ASLOTS; ++s)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s] + kt * 64),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr(s, kt)),
                                          (__attribute__((address_space(3))) void*)(sa + (s * NW + wave) * 1024), 16, 0, 0);
     }
   };
   auto dma_a1 = [&](int kt, int buf, int s1) {  // one 1-KiB piece
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[s1] + kt * 64),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr(s1, kt)),
                                      (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (s1 * NW + wave) * 1024), 16, 0, 0);
   };
   auto dma_w1 = [&](int kt, int buf, int s1) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[s1] + kt * 64),
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr(s1, kt)),
                                      (__attribute__((address_space(3))) void*)(smem + buf * STAGE + TBM * BK_BYTES + (s1 * NW + wave) * 1024), 16, 0, 0);
   };
   auto dma_w = [&](int kt, int buf, int s0) {
@@ -720,7 +761,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     char* sw = smem + buf * STAGE + TBM * BK_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[s0 + s] + kt * 64),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr(s0 + s, kt)),
                                        (__attribute__((address_space(3))) void*)(sw + ((s0 + s) * NW + wave) * 1024), 16, 0, 0);
   };
 
@@ -802,7 +843,30 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) br[i][kk] = u32x4{0x2c002800u + lane, 0xac002400u, 0x28002c00u, 0x2400a800u + i};
   }
+  // MODE 2: transposed fragment reads.  Lane (g = fq, qi = fr) addresses token row 32 kk + 4 g + (qi >> 2) (+16 for the
+  // second half of the fragment), 8-byte chunk qi & 3 of the 16-column block; the hardware hands lane qi the four
+  // tokens' values of column qi.
+  auto read_tr = [&](const char* slab, int seg, int kk) -> u32x4 {
+    const int tq = fr >> 2, tp = fr & 3;
+    const int r0 = 32 * kk + 4 * fq + tq, r1 = r0 + 16;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(slab + r0 * 128 + ((seg ^ ((r0 >> 1) & 3)) << 5) + tp * 8));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(slab + r1 * 128 + ((seg ^ ((r1 >> 1) & 3)) << 5) + tp * 8));
+    s16x8 v;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) { v[q4] = lo[q4]; v[4 + q4] = hi[q4]; }
+    return __builtin_bit_cast(u32x4, v);
+  };
   auto read_a = [&](int buf, int half) {
+    if constexpr (MODE == 2) {
+      const char* slab = smem + buf * STAGE + (wr * 2 + half) * 8192;   // 64 output rows = one [64 tokens][64 columns] slab
+#pragma unroll
+      for (int i = 0; i < AFR; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) ar[i][kk] = read_tr(slab, i, kk);
+      return;
+    }
     if (ABL & 2) { asm volatile("" : "+v"(ar[0][0]), "+v"(ar[1][1])); return; }
     const char* sa = smem + buf * STAGE + (DEEP ? half * (TBM / 2) + wr * (16 * AFR) : wr * (TBM / 2) + half * (16 * AFR)) * BK_BYTES;
 #pragma unroll
@@ -811,6 +875,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
       for (int kk = 0; kk < 2; ++kk) ar[i][kk] = *reinterpret_cast<const u32x4*>(sa + swz(i * 16 + fr, kk * 4 + fq));
   };
   auto read_b = [&](int buf, int half) {
+    if constexpr (MODE == 2) {
+      const char* slab = smem + buf * STAGE + TBM * BK_BYTES + wc * 8192;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) br[i][kk] = read_tr(slab, half * 2 + i, kk);
+      return;
+    }
     if (ABL & 2) { asm volatile("" : "+v"(br[0][0]), "+v"(br[1][1])); return; }
     const char* sw = smem + buf * STAGE + (TBM + (DEEP ? half * 128 + wc * 32 : wc * 64 + half * 32)) * BK_BYTES;
 #pragma unroll
@@ -995,6 +1067,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   }
 #undef PP_MFMA
 
+  const OT* const resid_e = (MODE == 2) ? nullptr : residual;  // MODE 2 passes its zero page in `residual`
   // ---- epilogue in row passes through LDS (same as the glds variants) --------------------------------
   constexpr int TM = TBM / 2, TN = 64, MI = 2 * AFR, NI = 4;
   constexpr int OB = OutPack<OT>::bytes;
@@ -1027,7 +1100,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   const int trow = tid / TPR, tcol = tid % TPR;
 #pragma unroll
   for (int p = 0; p < NPASS; ++p) {
-    // (1) resolve this pass's output rows and start the residual loads: their latency hides under (2)
+    // (1) resolve this pass's output rows and start the resid_e loads: their latency hides under (2)
     int64_t orow[ITS];
     float oscale[ITS];
     u32x4 resv[ITS][CPT];
@@ -1045,8 +1118,8 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
       for (int j = 0; j < CPT; ++j) {
         resv[it][j] = u32x4{0u, 0u, 0u, 0u};
         const int ncol = n0 + (tcol + j * TPR) * (16 / OB);
-        if (residual && orow[it] >= 0 && ncol < N)
-          resv[it][j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) +
+        if (resid_e && orow[it] >= 0 && ncol < N)
+          resv[it][j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(resid_e) +
                                                         (orow[it] * (int64_t)N + ncol) * OB);
       }
     }
@@ -1065,7 +1138,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
       }
     }
     __syncthreads();
-    // (3) whole-row-segment stores (combine scale and residual / gelu' fused)
+    // (3) whole-row-segment stores (combine scale and resid_e / gelu' fused)
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
       if (orow[it] >= 0) {
@@ -1077,7 +1150,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
           if (ncol < N) {
             u32x4 v = *reinterpret_cast<const u32x4*>(smem + r * C_STRIDE + ch * 16);
             if (row_map && row_scale) v = scale16<OT>(v, oscale[it]);
-            if (residual) v = fuse_aux<OT>(epilogue, resv[it][j], v);
+            if (resid_e) v = fuse_aux<OT>(epilogue, resv[it][j], v);
             *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow[it] * (int64_t)N + ncol) * OB) = v;
           }
         }
@@ -1135,6 +1208,31 @@ int launch_wgrad(const void* PT, const void* QT, const int32_t* offsets_pad, int
                      (const int32_t*)nullptr, E, Lp, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, out, tn, tm, R1, (const int64_t*)nullptr, 1);
   SMOE_CHECK_LAUNCH("smoe_grouped_wgrad");
+  return 0;
+}
+
+// token-major weight gradient (MODE 2): P [n_rows, R1], Q [n_rows, R2] row-major, offsets = plain row ranges
+template <typename AB>
+int launch_wgrad_rows(const void* P, const void* Q, const int32_t* offsets, int E, int R1, int R2, const void* zero16,
+                      float* out, hipStream_t s) {
+  constexpr int TBM = 256, TBN = 256;
+  const int tm = (R1 + TBM - 1) / TBM, tn = (R2 + TBN - 1) / TBN;
+  const int grid = E * tm * tn;
+  const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
+  auto kern = grouped_gemm_pp256<AB, float, 0, 2>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (ae != hipSuccess) {
+      smoe_set_error("smoe_grouped_wgrad_rows: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
+      return (int)ae;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)P, (const AB*)Q, (const float*)nullptr, offsets,
+                     (const int32_t*)nullptr, E, 0, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
+                     (const float*)zero16, out, tn, tm, R1, (const int64_t*)nullptr, 1);
+  SMOE_CHECK_LAUNCH("smoe_grouped_wgrad_rows");
   return 0;
 }
 
@@ -1260,5 +1358,19 @@ extern "C" int smoe_grouped_wgrad(const void* PT, const void* QT, int ab_dtype, 
   if (ab_dtype == SMOE_F16) return launch_wgrad<f16>(PT, QT, offsets_pad, E, R1, R2, Lp, out, s);
   if (ab_dtype == SMOE_BF16) return launch_wgrad<bf16_bits>(PT, QT, offsets_pad, E, R1, R2, Lp, out, s);
   smoe_set_error("smoe_grouped_wgrad: operands must be f16 or bf16");
+  return 1;
+}
+
+// Weight gradients straight from the token-major operands (no transposed copies):
+//   out[e] (f32 [R1,R2]) = sum over rows r of expert e of P[r, :]^T Q[r, :]     P [n_rows,R1], Q [n_rows,R2], 16-bit
+// offsets i32 [E+1] = the experts' row ranges (any lengths, empty allowed); zero16 = 16 bytes of zeros in device memory.
+extern "C" int smoe_grouped_wgrad_rows(const void* P, const void* Q, int ab_dtype, const int32_t* offsets, int E, int R1,
+                                       int R2, const void* zero16, float* out, void* stream) {
+  SMOE_REQUIRE(P && Q && offsets && out && zero16, "smoe_grouped_wgrad_rows: null pointer");
+  SMOE_REQUIRE(E >= 1 && R1 >= 8 && R2 >= 8 && R1 % 8 == 0 && R2 % 8 == 0, "smoe_grouped_wgrad_rows: bad sizes E=%d R1=%d R2=%d", E, R1, R2);
+  hipStream_t s = (hipStream_t)stream;
+  if (ab_dtype == SMOE_F16) return launch_wgrad_rows<f16>(P, Q, offsets, E, R1, R2, zero16, out, s);
+  if (ab_dtype == SMOE_BF16) return launch_wgrad_rows<bf16_bits>(P, Q, offsets, E, R1, R2, zero16, out, s);
+  smoe_set_error("smoe_grouped_wgrad_rows: operands must be f16 or bf16");
   return 1;
 }

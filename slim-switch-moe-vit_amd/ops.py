@@ -397,6 +397,31 @@ def grouped_wgrad(PT: torch.Tensor, QT: torch.Tensor, offsets_pad: torch.Tensor)
     return out
 
 
+_zero_pages = {}
+
+
+def _zero16(device) -> torch.Tensor:
+    t = _zero_pages.get(str(device))
+    if t is None:
+        t = _zero_pages[str(device)] = torch.zeros(64, dtype=torch.uint8, device=device)
+    return t
+
+
+def grouped_wgrad_rows(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    """out[e] (f32 [R1, R2]) = P[rows of e]^T @ Q[rows of e] from the token-major operands (no transposed copies)."""
+    _chk(P, "P", ndim=2)
+    _chk(Q, "Q", ndim=2)
+    if P.dtype != Q.dtype or P.dtype not in (torch.float16, torch.bfloat16) or P.shape[0] != Q.shape[0]:
+        raise RuntimeError("grouped_wgrad_rows: P and Q must be f16 / bf16 with the same row count")
+    E = offsets.numel() - 1
+    R1, R2 = P.shape[1], Q.shape[1]
+    out = torch.empty((E, R1, R2), dtype=torch.float32, device=P.device)
+    rc = _lib.load().smoe_grouped_wgrad_rows(_ptr(P), _ptr(Q), dtype_code(P.dtype), _ptr(offsets), E, R1, R2,
+                                              _ptr(_zero16(P.device)), _ptr(out), _stream(P))
+    _lib.check(rc, "smoe_grouped_wgrad_rows")
+    return out
+
+
 def gate_wgrad(dl: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """dWg [E, d] f32 = dl^T x for dl [T, E] f32, x [T, d]: the router weight gradient as a streaming reduction."""
     _chk(dl, "dl", torch.float32, 2, align=4)

@@ -285,3 +285,28 @@ def test_gate_wgrad_matches_matmul(T, E, d, dtype):
     ref = dl.double().t() @ x.double()
     assert (got - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item()) * (T ** 0.5)
     assert torch.equal(ops.gate_wgrad(dl.to(DEV), x.to(DEV)).cpu().double(), got)   # deterministic
+
+
+@pytest.mark.parametrize("counts,R1,R2", [([64, 128], 256, 256), ([100, 0, 37, 64, 1], 72, 136), ([300, 5, 777], 768, 256),
+                                          ([1000, 900, 1100, 950], 768, 3072)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
+def test_grouped_wgrad_rows_matches_per_expert_matmul(counts, R1, R2, dtype, tol):
+    """Token-major wgrad (transposed LDS reads, no transposed operand copies): ragged and empty experts, row counts
+    that are not multiples of the 64-token K-tile (the tail reads the zero page), output tiles with row / column tails;
+    and the same numbers as the transposed-copy path."""
+    E = len(counts)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device=DEV)
+    n = sum(counts)
+    g = _gen(n + R1)
+    P = (torch.randn(n + 3, R1, generator=g) * 0.5).to(dtype).to(DEV)   # rows past offsets[E] exist and must not be read into a sum
+    Q = (torch.randn(n + 3, R2, generator=g) * 0.5).to(dtype).to(DEV)
+    got = ops.grouped_wgrad_rows(P, Q, offsets).cpu().double()
+    o = offsets.tolist()
+    for e in range(E):
+        ref = P[o[e]:o[e + 1]].double().t().cpu() @ Q[o[e]:o[e + 1]].double().cpu()
+        scale = max(1.0, ref.abs().max().item())
+        assert (got[e] - ref).abs().max().item() <= tol * scale, (e, float((got[e] - ref).abs().max()))
+    offp = ops.pad_offsets(offsets)
+    Lp = ops.padded_len(n + 3, E)
+    old = ops.grouped_wgrad(ops.transpose_pad(P, offsets, offp, Lp), ops.transpose_pad(Q, offsets, offp, Lp), offp).cpu().double()
+    assert (got - old).abs().max().item() <= 1e-3 * max(1.0, old.abs().max().item())
