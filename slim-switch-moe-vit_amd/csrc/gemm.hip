@@ -716,19 +716,27 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     w_src[s] = W + ((int64_t)(MODE == 0 ? e : 0) * N + gw) * K + k_base + ((l_pos ^ ((r >> 1) & 7)) << 3);
   }
   // MODE 2: source of A piece s of K-tile kt -- the zero page once the token row is past the expert's range
+  // (only the last K-tile of an expert can hold such rows: a wave-uniform test keeps the per-lane selects out of the
+  // steady state)
   auto a_ptr = [&](int s, int kt) -> const AB* {
+    const AB* ptr = a_src[s] + kt * a_step;
     if constexpr (MODE == 2) {
-      return (k_base + kt * 64 + t_row[s] < k_hi) ? a_src[s] + kt * a_step : reinterpret_cast<const AB*>(residual);
-    } else {
-      return a_src[s] + kt * a_step;
+      if (kt == nk - 1) {
+        const uint64_t keep = (k_base + kt * 64 + t_row[s] < k_hi) ? ~0ull : 0ull;
+        ptr = reinterpret_cast<const AB*>((reinterpret_cast<uint64_t>(ptr) & keep) | (reinterpret_cast<uint64_t>(residual) & ~keep));
+      }
     }
+    return ptr;
   };
   auto w_ptr = [&](int s, int kt) -> const AB* {
+    const AB* ptr = w_src[s] + kt * w_step;
     if constexpr (MODE == 2) {  // keep the address inside the allocation; its products meet zeros from A
-      return (k_base + kt * 64 + t_row[s] < k_hi) ? w_src[s] + kt * w_step : w_src[s];
-    } else {
-      return w_src[s] + kt * w_step;
+      if (kt == nk - 1) {
+        const uint64_t keep = (k_base + kt * 64 + t_row[s] < k_hi) ? ~0ull : 0ull;
+        ptr = reinterpret_cast<const AB*>((reinterpret_cast<uint64_t>(ptr) & keep) | (reinterpret_cast<uint64_t>(w_src[s]) & ~keep));
+      }
     }
+    return ptr;
   };
   // DMA of A pieces of K-tile kt into buffer buf: "lo" (s0 == 0) = slots 0,1 (tile rows 0-127, read by wave group 0
   // only), "hi" = slots 2.. (the rest; for the 320-row tile slot 2 straddles the two groups' rows and is re-staged
