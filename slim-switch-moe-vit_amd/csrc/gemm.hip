@@ -718,9 +718,12 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   // MODE 2: source of A piece s of K-tile kt -- the zero page once the token row is past the expert's range
   // (only the last K-tile of an expert can hold such rows: a wave-uniform test keeps the per-lane selects out of the
   // steady state)
+  // MODE 2 keeps running pointers: every slot's pieces are requested for K-tiles 0, 1, 2, ... in order (prologue: 0 and 1,
+  // then one per loop iteration), so the 64-row advance is an add instead of a 64-bit multiply per DMA
   auto a_ptr = [&](int s, int kt) -> const AB* {
-    const AB* ptr = a_src[s] + kt * a_step;
+    const AB* ptr = a_src[s] + (MODE == 2 ? 0 : kt * a_step);
     if constexpr (MODE == 2) {
+      a_src[s] += a_step;
       if (kt == nk - 1) {
         const uint64_t keep = (k_base + kt * 64 + t_row[s] < k_hi) ? ~0ull : 0ull;
         ptr = reinterpret_cast<const AB*>((reinterpret_cast<uint64_t>(ptr) & keep) | (reinterpret_cast<uint64_t>(residual) & ~keep));
@@ -728,12 +731,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     }
     return ptr;
   };
+  const AB* const w_safe = W;  // any valid address for rows past the range (their products meet zeros from A)
   auto w_ptr = [&](int s, int kt) -> const AB* {
-    const AB* ptr = w_src[s] + kt * w_step;
-    if constexpr (MODE == 2) {  // keep the address inside the allocation; its products meet zeros from A
+    const AB* ptr = w_src[s] + (MODE == 2 ? 0 : kt * w_step);
+    if constexpr (MODE == 2) {
+      w_src[s] += w_step;
       if (kt == nk - 1) {
         const uint64_t keep = (k_base + kt * 64 + t_row[s] < k_hi) ? ~0ull : 0ull;
-        ptr = reinterpret_cast<const AB*>((reinterpret_cast<uint64_t>(ptr) & keep) | (reinterpret_cast<uint64_t>(w_src[s]) & ~keep));
+        ptr = reinterpret_cast<const AB*>((reinterpret_cast<uint64_t>(ptr) & keep) | (reinterpret_cast<uint64_t>(w_safe) & ~keep));
       }
     }
     return ptr;
@@ -854,13 +859,18 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   // MODE 2: transposed fragment reads.  Lane (g = fq, qi = fr) addresses token row 32 kk + 4 g + (qi >> 2) (+16 for the
   // second half of the fragment), 8-byte chunk qi & 3 of the 16-column block; the hardware hands lane qi the four
   // tokens' values of column qi.
+  // Issued as inline asm: behind the builtin hipcc puts an `s_waitcnt vmcnt(0)` in front of every group of
+  // transposing reads (it cannot tell them from the LDS-DMA destinations in flight), which drains the operand pipeline
+  // three times per K-tile (486 us per launch instead of ~330).  The price: the compiler does not count these reads
+  // either, so the MFMA cluster that consumes them waits lgkmcnt(0) explicitly (PP_MFMA, MODE 2).
   auto read_tr = [&](const char* slab, int seg, int kk) -> u32x4 {
     const int tq = fr >> 2, tp = fr & 3;
     const int r0 = 32 * kk + 4 * fq + tq, r1 = r0 + 16;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(slab + r0 * 128 + ((seg ^ ((r0 >> 1) & 3)) << 5) + tp * 8));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(slab + r1 * 128 + ((seg ^ ((r1 >> 1) & 3)) << 5) + tp * 8));
+    const uint32_t a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(slab + r0 * 128 + ((seg ^ ((r0 >> 1) & 3)) << 5) + tp * 8);
+    const uint32_t a1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(slab + r1 * 128 + ((seg ^ ((r1 >> 1) & 3)) << 5) + tp * 8);
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
     s16x8 v;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) { v[q4] = lo[q4]; v[4 + q4] = hi[q4]; }
@@ -901,6 +911,10 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
 #define PP_MFMA(AH, BH)                                                                                              \
   do {                                                                                                               \
     if (ABL & 4) { asm volatile("" :: "v"(ar[0][0]), "v"(ar[AFR - 1][1]), "v"(br[0][0]), "v"(br[1][1])); break; }          \
+    if constexpr (MODE == 2) {  /* the inline-asm fragment reads are invisible to the compiler's lgkmcnt bookkeeping */  \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }                                                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                                   \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < AFR; ++i)                 \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \

@@ -10,6 +10,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import slim_switch_moe_vit_amd as sm  # noqa: E402
+from slim_switch_moe_vit_amd import _lib  # noqa: E402
+if os.environ.get("SMOE_LIB"):
+    _lib.LIB_PATH = os.environ["SMOE_LIB"]
 
 
 def main():
