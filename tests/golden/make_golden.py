@@ -4,8 +4,8 @@
 
 1. ``ref_mlp_tiny.npz`` / ``ref_layernorm_tiny.npz`` -- outputs of the REFERENCE's own importable code:
    /root/reference/models/layers.py (``Mlp`` 391-414 = the dense FFN every expert generalises, and the manual
-   ``LayerNorm`` 160-224), loaded standalone by file path (the rest of the reference needs timm / fmoe, which
-   are absent: SURVEY.md 8c).  These pin the per-expert FFN of the oracle and of the HIP path (E = 1 <=> Mlp).
+   ``LayerNorm`` 160-224; ``Attention`` 227-269 -> ``ref_attention_tiny.npz``), loaded standalone by file path
+   (the rest of the reference needs timm / fmoe, which are absent: SURVEY.md 8c).  These pin the per-expert FFN of the oracle and of the HIP path (E = 1 <=> Mlp).
 2. ``oracle_moe_small.npz`` -- regression vectors produced by oracle/moe_oracle.py (NOT reference outputs;
    the MoE operator itself is 'parity unpinned', see the oracle header).
 Only data is stored: inputs, parameters, expected outputs.
@@ -59,6 +59,26 @@ def main():
         yl = ln(x)
     np.savez_compressed(os.path.join(HERE, "ref_layernorm_tiny.npz"), x=x.numpy(), w=ln.weight.detach().numpy(),
                         b=ln.bias.detach().numpy(), y=yl.numpy())
+
+    # ---- 1c. reference Attention (models/layers.py:227-269; the same computation as models/vision_transformer.py:248-280)
+    #          at ViT-Ti dims (d = 192, 3 heads of 64), 2 images x 50 tokens and 1 image x 197 tokens
+    att = ref.Attention(192, num_heads=3, qkv_bias=True)
+    g_keep, g = g, torch.Generator().manual_seed(4321)   # own stream: the vectors of section 2 stay as committed
+    with torch.no_grad():
+        torch.nn.init.trunc_normal_(att.qkv.weight, std=0.1, a=-2, b=2, generator=g)   # std 0.1: a softmax that is not flat
+        torch.nn.init.trunc_normal_(att.proj.weight, std=0.05, a=-2, b=2, generator=g)
+        att.qkv.bias.copy_(torch.randn(576, generator=g) * 0.05)
+        att.proj.bias.copy_(torch.randn(192, generator=g) * 0.05)
+    att.eval()
+    xa = torch.randn(2, 50, 192, generator=g)
+    xb = torch.randn(1, 197, 192, generator=g)
+    with torch.no_grad():
+        ya, yb = att(xa), att(xb)
+    np.savez_compressed(os.path.join(HERE, "ref_attention_tiny.npz"), xa=xa.numpy(), xb=xb.numpy(), ya=ya.numpy(),
+                        yb=yb.numpy(), qkv_w=att.qkv.weight.detach().numpy(), qkv_b=att.qkv.bias.detach().numpy(),
+                        proj_w=att.proj.weight.detach().numpy(), proj_b=att.proj.bias.detach().numpy(),
+                        num_heads=np.array(3))
+    g = g_keep
 
     # ---- 2. oracle regression vectors (small dims)
     from oracle import moe_oracle as mo

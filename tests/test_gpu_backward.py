@@ -96,10 +96,15 @@ def test_naive_gate_backward_matches_autograd(k):
         assert _rel(gt.cpu(), rf.grad) < 5e-3, name
 
 
-def test_cfg5_switch_capacity_aux_backward():
-    """SwitchGate, capacity_factor 1.0 (drops on the skewed router), aux loss in the objective."""
-    T, d, h, E = 1200, 128, 256, 8
+@pytest.mark.parametrize("T,d,h,wstd", [(1200, 128, 256, 0.05), (4096, 768, 3072, 0.02)])
+def test_cfg5_switch_capacity_aux_backward(T, d, h, wstd):
+    """SwitchGate, capacity_factor 1.0 (drops on the skewed router), aux loss in the objective: out, aux, dx, dWg,
+    dbg, dW1, db1, dW2, db2 against float64 autograd through the oracle.  Second case = BASELINE cfg 5 at its own
+    operator dims (ViT-B/16: d 768, h 3072, E 8, weights drawn like _init_vit_weights)."""
+    E = 8
     x, wg, bg, w1, b1, w2, b2, gout = _params(T, d, h, E, seed=77, skew=True)
+    if wstd != 0.05:
+        w1, b1, w2, b2 = (t * (wstd / 0.05) for t in (w1, b1, w2, b2))
     mod = sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=1, gate="switch", capacity_factor=1.0).to(DEV)
     mod.gate.switch_eps = 0.0  # no jitter: oracle and device see the same logits
     with torch.no_grad():
@@ -264,10 +269,8 @@ def test_two_expert_parallel_ranks_training_step_on_one_gpu():
     procs = [ctx.Process(target=_two_rank_train_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(300)
-    for p in procs:
-        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    from _mp import join_or_kill
+    join_or_kill(procs, 300)
     got = dict(q.get(timeout=10) for _ in range(2))
     assert sorted(got) == [0, 1]
     for rank, errs in got.items():

@@ -23,6 +23,17 @@ def _gen(seed):
     return torch.Generator().manual_seed(seed)
 
 
+def _float_bar(got, ref, tol=1e-3):
+    """THE float bar of the operator tests (north_star: "fp tolerance <= 1e-3 on expert outputs"), stated once, in
+    the convention test_grouped_gemm_matches_fp64_reference uses: max |diff| <= tol * max(1, max |ref|) AND
+    relative L2 <= tol.  Returns the numbers so that a failure prints the scale it was judged at."""
+    diff = got.double() - ref.double()
+    scale = max(1.0, float(ref.abs().max()))
+    max_abs, rel_l2 = float(diff.abs().max()), float(diff.norm() / ref.double().norm().clamp(min=1e-30))
+    assert max_abs <= tol * scale and rel_l2 <= tol, dict(max_abs=max_abs, ref_abs_max=scale, rel_l2=rel_l2, tol=tol)
+    return max_abs, scale, rel_l2
+
+
 def _mk(T, d, h, E, seed, wstd=0.02, skew=False):
     g = _gen(seed)
     x = torch.randn(T, d, generator=g)
@@ -365,6 +376,35 @@ def test_attention_kernel_matches_reference_attention(B, N, H, dt, tol):
     assert (got.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+def test_attention_path_matches_reference_attention_golden(golden_dir):
+    """The REFERENCE's own ``Attention`` outputs (models/layers.py:227-269 == models/vision_transformer.py:248-280;
+    tests/golden/ref_attention_tiny.npz): (1) smoe_attention_fwd on the qkv the reference weights give, then the
+    projection; (2) the product module ``vit.Attention`` under fp16 autocast with the residual add fused into the
+    projection GEMM.  f16 operands: 2e-3 x scale."""
+    from slim_switch_moe_vit_amd.vit import Attention
+    g = np.load(os.path.join(golden_dir, "ref_attention_tiny.npz"))
+    t = lambda k: torch.from_numpy(g[k])
+    H = int(g["num_heads"])
+    att = Attention(192, num_heads=H, qkv_bias=True)
+    with torch.no_grad():
+        att.qkv.weight.copy_(t("qkv_w")); att.qkv.bias.copy_(t("qkv_b"))
+        att.proj.weight.copy_(t("proj_w")); att.proj.bias.copy_(t("proj_b"))
+    att = att.to(DEV).eval()
+    for xk, yk in (("xa", "ya"), ("xb", "yb")):
+        x, ref = t(xk), t(yk)
+        B, N, C = x.shape
+        scale = max(1.0, float(ref.abs().max()))
+        qkv = torch.nn.functional.linear(x, t("qkv_w"), t("qkv_b")).half().to(DEV)          # [B, N, 3*H*64]
+        o = ops.attention(qkv, B, N, H, 64, 64 ** -0.5).float().cpu()
+        y = torch.nn.functional.linear(o, t("proj_w"), t("proj_b"))
+        assert (y - ref).abs().max().item() <= 2e-3 * scale, (y - ref).abs().max().item()
+        res = torch.randn(B, N, C, generator=_gen(3)).to(DEV)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            out, added = att(x.to(DEV).half(), residual=res)
+        assert added, "the fused projection + residual path must be the one that runs"
+        assert ((out - res).cpu() - ref).abs().max().item() <= 2e-3 * scale
+
+
 def test_moe_module_e1_equals_reference_mlp_golden(golden_dir):
     """E = 1: the HIP path reproduces the REFERENCE's own dense Mlp (models/layers.py:391-414) outputs."""
     g = np.load(os.path.join(golden_dir, "ref_mlp_tiny.npz"))
@@ -452,9 +492,7 @@ def test_moe_module_cfg3_cfg4_dims(d, h, E, k, T):
     r = mo.moe_forward(x, wg, bg, w1, b1, w2, b2, k)
     assert torch.equal(mod.last_plan[0].cpu(), r.idx)
     assert np.array_equal(mod.last_plan[4].cpu().numpy(), r.plan.pos)
-    diff = out - r.out
-    assert (diff.norm() / r.out.norm()).item() <= 1e-3
-    assert diff.abs().max().item() <= 2.5e-3
+    _float_bar(out, r.out, 1e-3)
 
 
 # ------------------------------------------------------------------------------------------ full size (cfg 2)
@@ -485,15 +523,11 @@ def test_cfg2_full_size_properties():
         perm = torch.randperm(T, generator=_gen(1)).to(DEV)
         outp = mod(xg[perm].reshape(B, N, d)).reshape(T, d)
         assert (outp - out.reshape(T, d)[perm]).abs().max().item() == 0.0
-    # sampled oracle comparison on 2048 random tokens.  f16 MFMA operands (f32 accumulate): relative L2 error
-    # <= 1e-3 and max-abs <= 2.5e-3 at this scale (error budget in DESIGN.md: four 2^-11 roundings of O(1)
-    # data over K = 768 / 3072 give sigma ~ 2.3e-4, i.e. ~1.5e-3 at the 5.5-sigma tail of 1.5M samples)
+    # sampled oracle comparison on 2048 random tokens, f16 MFMA operands (the benchmarked mode), at the float bar:
+    # max |diff| <= 1e-3 * max(1, max |ref|) and relative L2 <= 1e-3 (error budget in DESIGN.md section 2)
     sel = torch.randperm(T, generator=_gen(2))[:2048]
     r = mo.moe_forward(x[sel], wg, bg, w1, b1, w2, b2, 1)
-    diff = out.reshape(T, d).cpu()[sel] - r.out
-    rel_l2 = (diff.norm() / r.out.norm()).item()
-    assert rel_l2 <= 1e-3, rel_l2
-    assert diff.abs().max().item() <= 2.5e-3, diff.abs().max().item()
+    _float_bar(out.reshape(T, d).cpu()[sel], r.out, 1e-3)
     # the f32-exact MFMA mode meets the strict bound on every element
     mod32 = _load_module(sm.CustomizedMoEMLP(d, h, E, 1, 0.0, compute_dtype=torch.float32), wg, bg, w1, b1, w2, b2)
     with torch.no_grad():
@@ -528,7 +562,10 @@ def test_expert_parallel_path_on_one_gpu():
                 got = mod(x.to(DEV))
                 got_add = mod.forward_add(x.to(DEV), r)
             o = mo.moe_forward(x, wg, bg, w1, b1, w2, b2, k).out
-            assert (got.cpu() - o).abs().max().item() <= tol
+            if cd == torch.float16:
+                _float_bar(got.cpu(), o, 1e-3)   # expert outputs vs the oracle: the one float bar
+            else:
+                assert (got.cpu() - o).abs().max().item() <= tol
             assert (got - ref).abs().max().item() <= tol
             assert (got_add - ref_add).abs().max().item() <= tol
             # block half with the fused LayerNorm + router in front of the expert-parallel exchange
@@ -588,7 +625,7 @@ def test_expert_parallel_data_path_simulated_ranks(W_ranks, E_local, k):
     with the HIP gather -- the result must equal the oracle's single-rank forward of every shard."""
     from slim_switch_moe_vit_amd import ep
     d, h, E = 192, 768, W_ranks * E_local
-    cd, tol = torch.float16, 2e-3
+    cd = torch.float16
     T_r = [700, 333, 1, 512, 64, 900, 257, 128][:W_ranks]
     xs, wg, bg, w1, b1, w2, b2 = [], None, None, None, None, None, None
     _, wg, bg, w1, b1, w2, b2 = _mk(1, d, h, E, seed=500 + W_ranks + k)
@@ -637,4 +674,4 @@ def test_expert_parallel_data_path_simulated_ranks(W_ranks, E_local, k):
         T = xs[r].shape[0]
         got = ops.gather_combine(back, plans[r][3], scores[r], T, k, torch.float32).cpu()
         ref = mo.moe_forward(xs[r], wg, bg, w1, b1, w2, b2, k).out
-        assert (got - ref).abs().max().item() <= tol, (r, float((got - ref).abs().max()))
+        _float_bar(got, ref, 1e-3)

@@ -46,6 +46,16 @@ def test_layernorm_matches_reference(golden_dir):
     assert torch.allclose(y, torch.from_numpy(g["y"]), rtol=0, atol=5e-6)
 
 
+def test_attention_matches_reference_attention(golden_dir):
+    """oracle.attention == the reference's own ``Attention`` module (models/layers.py:227-269, the computation of
+    models/vision_transformer.py:248-280) on the committed inputs / parameters / outputs."""
+    g = _load(golden_dir, "ref_attention_tiny.npz")
+    t = lambda k: torch.from_numpy(g[k])
+    for xk, yk in (("xa", "ya"), ("xb", "yb")):
+        y = mo.attention(t(xk), t("qkv_w"), t("qkv_b"), t("proj_w"), t("proj_b"), int(g["num_heads"]))
+        assert torch.allclose(y, t(yk), rtol=0, atol=3e-6), (y - t(yk)).abs().max()
+
+
 def test_oracle_regression_vectors(golden_dir):
     g = _load(golden_dir, "oracle_moe_small.npz")
     for name in ("naive_k2", "naive_k1", "switch_cap"):
