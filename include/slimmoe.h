@@ -9,8 +9,15 @@
  *
  * Conventions
  *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller
- *    (torch tensors), contiguous, 16-byte aligned; nothing here allocates, frees or synchronises,
- *    so every call is graph-capturable;
+ *    (torch tensors), contiguous, 16-byte aligned; nothing here allocates, frees or synchronises;
+ *  - process-global state is limited to (i) the thread-local error string and (ii) one atomic bit per
+ *    (kernel, device) recording that the kernel's dynamic-LDS limit has been raised on that device, plus the
+ *    cached CU count per device.  smoe_init() sets all of (ii) for the CURRENT device; call it once per device
+ *    before capturing launches into a hipGraph (after it no entry point touches function attributes).  Without
+ *    it the first launch of a kernel on a device sets its attribute itself (thread-safe: the update is an
+ *    atomic OR and setting the attribute twice is harmless);
+ *  - entry points may be called concurrently from several host threads and on several streams; buffers handed
+ *    to concurrent calls (workspaces, outputs) must be distinct;
  *  - all launches go to `stream` (a hipStream_t passed as void*);
  *  - return 0 on success, non-zero on error; smoe_last_error() gives the thread-local message;
  *  - dtype codes: SMOE_F32 / SMOE_F16 / SMOE_BF16.
@@ -31,6 +38,8 @@ enum { SMOE_EPI_NONE = 0, SMOE_EPI_GELU = 1, SMOE_EPI_GELU_GRAD = 2 };
 
 /* library ABI version (bumped on any signature change) */
 int smoe_abi_version(void);
+/* raise the dynamic-LDS limit of every kernel of the library on the current device (see Conventions); idempotent */
+int smoe_init(void);
 /* message for the last non-zero return on this thread */
 const char* smoe_last_error(void);
 

@@ -1,0 +1,55 @@
+"""Derived device tensors that are made once and reused (16-bit shadows of parameters, constant index tables).
+
+Such a tensor is produced by a kernel on whichever stream first asks for it; a later consumer on ANOTHER stream
+must not read it before that kernel has run.  Every entry therefore carries the event recorded behind its producer
+and the stream it was produced on; ``get`` makes any other stream wait on that event (a no-op for the single-stream
+case, which never leaves the producing stream).  Versioned entries are rebuilt when the source tensor changes
+(``_version`` / ``data_ptr``); in-place updates through ``.data`` do not bump ``_version`` -- call ``invalidate()``
+after those (the modules do it from a load_state_dict post-hook)."""
+from __future__ import annotations
+
+import weakref
+from typing import Callable, Hashable
+
+import torch
+
+_ALL = weakref.WeakSet()
+
+
+class StreamCache:
+    def __init__(self):
+        self._c = {}
+        _ALL.add(self)
+
+    def invalidate(self):
+        self._c.clear()
+
+    def get(self, key: Hashable, version, make: Callable[[], torch.Tensor]) -> torch.Tensor:
+        hit = self._c.get(key)
+        if hit is None or hit[0] != version:
+            t = make()
+            ev = sid = None
+            if t.is_cuda:
+                st = torch.cuda.current_stream(t.device)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                sid = st.cuda_stream
+            hit = (version, t, ev, sid)
+            self._c[key] = hit
+            return t
+        _, t, ev, sid = hit
+        if ev is not None:
+            st = torch.cuda.current_stream(t.device)
+            if st.cuda_stream != sid:
+                st.wait_event(ev)
+        return t
+
+
+def param_version(p: torch.Tensor):
+    return (p._version, p.data_ptr(), p.dtype)
+
+
+def invalidate_all():
+    """Drop every derived tensor (after in-place parameter updates that bypass autograd's version counter)."""
+    for c in list(_ALL):
+        c.invalidate()

@@ -11,13 +11,14 @@ import torch  # noqa: F401  (must be imported first: the library resolves libamd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
 # name -> (restype, argtypes); mirrors include/slimmoe.h one to one
 SIGNATURES = {
     "smoe_abi_version": (c_int, []),
+    "smoe_init": (c_int, []),
     "smoe_last_error": (ctypes.c_char_p, []),
     "smoe_router_workspace_bytes": (c_size_t, [c_int64]),
     "smoe_router_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
@@ -81,6 +82,20 @@ def load():
         raise SlimMoEError(f"libslimmoe_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
     _lib = lib
     return lib
+
+
+_inited_devices = set()
+
+
+def init_device(index: int):
+    """smoe_init() once per device of this process: every kernel's dynamic-LDS limit is raised up front, so that no
+    launcher touches function attributes afterwards (graph capture, several streams / threads)."""
+    if index in _inited_devices:
+        return
+    lib = load()
+    with torch.cuda.device(index):
+        check(lib.smoe_init(), "smoe_init")
+    _inited_devices.add(index)
 
 
 def check(rc: int, what: str):

@@ -236,15 +236,7 @@ template <typename HT, int NKT, bool EXACT>
 int launch_attn(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s) {
   const size_t smem = 2 * (size_t)NKT * 16 * 128;
   auto kern = attn_fwd_kernel<HT, NKT, EXACT>;
-  static bool attr_done = false;
-  if (!attr_done && smem > 48 * 1024) {
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (ae != hipSuccess) {
-      smoe_set_error("smoe_attention_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
-      return (int)ae;
-    }
-    attr_done = true;
-  }
+  SMOE_ENSURE_SMEM(attn_fwd_kernel<HT, NKT, EXACT>);
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(ATT_THREADS), smem, s, (const HT*)qkv, (HT*)out, N, H,
                      scale * 1.4426950408889634f);
   SMOE_CHECK_LAUNCH("smoe_attention_fwd");

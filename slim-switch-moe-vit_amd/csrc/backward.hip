@@ -398,12 +398,7 @@ extern "C" int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int6
       hipLaunchKernelGGL((gate_wgrad_partial_kernel<T, 8>), grid1, dim3(256), (size_t)4 * 8 * CS_COLS * 4, s, dl, (const T*)x, n_rows, E, C, partial);
     } else {
       auto kern = gate_wgrad_partial_kernel<T, 16>;
-      static bool attr_done = false;
-      if (!attr_done) {
-        hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16 * CS_COLS * 4);
-        SMOE_REQUIRE(ae == hipSuccess, "smoe_gate_wgrad: hipFuncSetAttribute failed");
-        attr_done = true;
-      }
+      SMOE_ENSURE_SMEM(gate_wgrad_partial_kernel<T, 16>);
       hipLaunchKernelGGL(kern, grid1, dim3(256), (size_t)4 * 16 * CS_COLS * 4, s, dl, (const T*)x, n_rows, E, C, partial);
     }
     SMOE_CHECK_LAUNCH("smoe_gate_wgrad/partial");

@@ -384,15 +384,7 @@ int launch_t128(const void* A, const void* W, const float* bias, const int32_t* 
   const size_t ctile = (size_t)BM * (BN * OB + C_PAD);
   if (ctile > smem) smem = ctile;
   auto kern = grouped_gemm_t128<AB, OT>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    if (ae != hipSuccess) {
-      smoe_set_error("smoe_grouped_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
-      return (int)ae;
-    }
-    attr_done = true;
-  }
+  SMOE_ENSURE_SMEM(grouped_gemm_t128<AB, OT>);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert,
                      E, K, N, epilogue, row_map, row_scale, (const OT*)residual, (OT*)out, n_tiles_n, group_m);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
@@ -576,15 +568,7 @@ int launch_glds(const void* A, const void* W, const float* bias, const int32_t* 
   const int grid = m_groups * group_m * n_tiles_n;
   const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
   auto kern = grouped_gemm_glds<AB, OT, TBM, TBN, WM, WN, MINW>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (ae != hipSuccess) {
-      smoe_set_error("smoe_grouped_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
-      return (int)ae;
-    }
-    attr_done = true;
-  }
+  SMOE_ENSURE_SMEM(grouped_gemm_glds<AB, OT, TBM, TBN, WM, WN, MINW>);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert,
                      E, K, N, epilogue, row_map, row_scale, (const OT*)residual, (OT*)out, n_tiles_n, group_m);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
@@ -731,7 +715,9 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     }
     return ptr;
   };
-  const AB* const w_safe = W;  // any valid address for rows past the range (their products meet zeros from A)
+  // rows past the range read the zero page too (MODE 2 passes it in `residual`): 0 x 0, never 0 x Inf / NaN from
+  // whatever bytes an arbitrary valid address happens to hold
+  const AB* const w_safe = (MODE == 2) ? reinterpret_cast<const AB*>(residual) : W;
   auto w_ptr = [&](int s, int kt) -> const AB* {
     const AB* ptr = w_src[s] + (MODE == 2 ? 0 : kt * w_step);
     if constexpr (MODE == 2) {
@@ -1194,15 +1180,7 @@ int launch_pp256(const void* A, const void* W, const float* bias, const int32_t*
   const int grid = m_groups * group_m * n_tiles_n;
   const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
   auto kern = grouped_gemm_pp256<AB, OT, ABL, 0, AFR>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (ae != hipSuccess) {
-      smoe_set_error("smoe_grouped_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
-      return (int)ae;
-    }
-    attr_done = true;
-  }
+  SMOE_ENSURE_SMEM(grouped_gemm_pp256<AB, OT, ABL, 0, AFR>);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)A, (const AB*)W, bias, offsets, group_expert, E, K, N,
                      epilogue, row_map, row_scale, (const OT*)residual, (OT*)out, n_tiles_n, group_m, 0, a_gather, a_div);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm");
@@ -1217,15 +1195,7 @@ int launch_wgrad(const void* PT, const void* QT, const int32_t* offsets_pad, int
   const int grid = E * tm * tn;
   const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
   auto kern = grouped_gemm_pp256<AB, float, 0, 1>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (ae != hipSuccess) {
-      smoe_set_error("smoe_grouped_wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
-      return (int)ae;
-    }
-    attr_done = true;
-  }
+  SMOE_ENSURE_SMEM(grouped_gemm_pp256<AB, float, 0, 1>);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)PT, (const AB*)QT, (const float*)nullptr, offsets_pad,
                      (const int32_t*)nullptr, E, Lp, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, out, tn, tm, R1, (const int64_t*)nullptr, 1);
@@ -1242,30 +1212,12 @@ int launch_wgrad_rows(const void* P, const void* Q, const int32_t* offsets, int 
   const int grid = E * tm * tn;
   const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
   auto kern = grouped_gemm_pp256<AB, float, 0, 2>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (ae != hipSuccess) {
-      smoe_set_error("smoe_grouped_wgrad_rows: hipFuncSetAttribute failed: %s", hipGetErrorString(ae));
-      return (int)ae;
-    }
-    attr_done = true;
-  }
+  SMOE_ENSURE_SMEM(grouped_gemm_pp256<AB, float, 0, 2>);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)P, (const AB*)Q, (const float*)nullptr, offsets,
                      (const int32_t*)nullptr, E, 0, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
                      (const float*)zero16, out, tn, tm, R1, (const int64_t*)nullptr, 1);
   SMOE_CHECK_LAUNCH("smoe_grouped_wgrad_rows");
   return 0;
-}
-
-inline int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-    else n = 256;
-  }
-  return n;
 }
 
 template <typename AB, typename OT>
@@ -1282,7 +1234,7 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
         const int ntn = (N + 255) / 256;
         // expected tile counts (each group's last tile is half full on average); the kernel balances the real ones
         const int64_t t256 = ((m_rows_max + 255) / 256 + E / 2) * ntn, t320 = ((m_rows_max + 319) / 320 + E / 2) * ntn;
-        const int cus = num_cus();
+        const int cus = smoe_num_cus();
         const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c320 = (double)((t320 + cus - 1) / cus) * 1.25;
         // deep = half-organised LDS with two half-tiles in flight across the tile boundary (variants 7 / 8): +3-4 % on
         // long K loops (GEMM-2, 8192^3), -3 % at K = 768 where the uneven per-wave DMA split of the 320-row tile shows

@@ -133,8 +133,15 @@ __global__ __launch_bounds__(ROUTER_THREADS, (MODE == 0 ? 4 : 2)) void router_ke
 
   // work items: MODE 0 -> tokens 0..T-1; MODE 1 with a list -> list entries 0..count-1
   int64_t n_items = T;
-  if (MODE == 1 && redo_list) n_items = *redo_count;
-  auto item_token = [&](int64_t it) -> int64_t { return (MODE == 1 && redo_list) ? (int64_t)redo_list[it] : it; };
+  if (MODE == 1 && redo_list) {  // a trip count read from device memory is never trusted: at most T tokens can be listed
+    n_items = *redo_count;
+    n_items = n_items < 0 ? 0 : (n_items > T ? T : n_items);
+  }
+  auto item_token = [&](int64_t it) -> int64_t {
+    if (!(MODE == 1 && redo_list)) return it;
+    const int64_t t = (int64_t)redo_list[it];
+    return t < 0 ? 0 : (t >= T ? T - 1 : t);  // list entries index x: keep them inside it
+  };
   for (int64_t it = wave_gid; it < n_items; it += wave_stride) {
     const int64_t t = item_token(it);
     load_row(t);  // latency is hidden by occupancy (4 blocks of 4 waves per CU), not by software prefetch

@@ -62,7 +62,10 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? 4 : (EB <= 16 
   if (MODE == 1 && redo_list && *redo_count == 0) return;  // nothing to redo (the common case): exit before any setup
 
   int64_t n_items = T;
-  if (MODE == 1 && redo_list) n_items = *redo_count;
+  if (MODE == 1 && redo_list) {  // a trip count read from device memory is never trusted: at most T tokens can be listed
+    n_items = *redo_count;
+    n_items = n_items < 0 ? 0 : (n_items > T ? T : n_items);
+  }
   const int64_t slot_gid = ((int64_t)blockIdx.x * (R16_THREADS / 64) + wave) * 4 + q;
   const int64_t slot_stride = (int64_t)gridDim.x * (R16_THREADS / 64) * 4;
   // The row of the NEXT item is fetched as soon as the current one's registers are free -- the first one before
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? 4 : (EB <= 16 
     live_next = it < n_items;
     const int64_t itc = live_next ? it : n_items - 1;
     t_next = (MODE == 1 && redo_list) ? (int64_t)redo_list[itc] : itc;
+    if (MODE == 1) t_next = t_next < 0 ? 0 : (t_next >= T ? T - 1 : t_next);  // list entries index x: keep them inside it
     const XT* src = x + t_next * (int64_t)(64 * NJ) + u * 4;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -393,18 +397,8 @@ int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, 
   const int64_t iters = (need + max_wg - 1) / max_wg;
   const int grid = (int)(need < 1 ? 1 : (need + iters - 1) / (iters < 1 ? 1 : iters));
   if (smem > 64 * 1024) {  // 16 experts x d 1024 (+ LayerNorm vectors): above the default dynamic-LDS limit
-    static bool attr_done = false;
-    if (!attr_done) {
-      hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(router16_kernel<XT, NJ, 0, LN, NT, EB>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(router16_kernel<XT, NJ, 1, LN, NT, EB>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (a0 != hipSuccess || a1 != hipSuccess) {
-        smoe_set_error("smoe_router_topk: hipFuncSetAttribute failed");
-        return 1;
-      }
-      attr_done = true;
-    }
+    SMOE_ENSURE_SMEM(router16_kernel<XT, NJ, 0, LN, NT, EB>);
+    SMOE_ENSURE_SMEM(router16_kernel<XT, NJ, 1, LN, NT, EB>);
   }
 #define R16_LAUNCH(MODE, GRID, RC, RL)                                                                               \
   hipLaunchKernelGGL((router16_kernel<XT, NJ, MODE, LN, NT, EB>), dim3(GRID), dim3(R16_THREADS), smem, s, (const XT*)x,  \

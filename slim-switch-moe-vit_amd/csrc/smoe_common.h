@@ -108,5 +108,28 @@ __device__ __forceinline__ void store8(bf16_bits* p, const float (&v)[8]) {
   *reinterpret_cast<s16x8*>(p) = t;
 }
 
+// ---- per-(kernel, device) launch attributes -------------------------------------------------------------------------
+// Kernels that need more dynamic LDS than the default limit register themselves at library load (a static object per
+// instantiation); smoe_init() raises the limit for every registered kernel on the CURRENT device, and every launcher
+// calls SMOE_ENSURE_SMEM as a thread-safe, per-device fallback (an atomic bit per device; setting the attribute twice
+// is harmless).  After smoe_init() no launcher touches function attributes any more, which is what makes the launches
+// graph-capturable.
+#include <atomic>
+struct SmoeKernelEntry {
+  const void* kern;
+  std::atomic<uint32_t> done;  // bit i: attribute set on device i (devices >= 32 are not cached)
+  SmoeKernelEntry* next;
+  explicit SmoeKernelEntry(const void* k);
+};
+int smoe_kernel_ensure(SmoeKernelEntry& e);  // api.hip
+int smoe_num_cus();                          // CU count of the current device (cached per device)
+template <auto KERN> struct SmoeKernelReg { static SmoeKernelEntry entry; };
+template <auto KERN> SmoeKernelEntry SmoeKernelReg<KERN>::entry{reinterpret_cast<const void*>(KERN)};
+#define SMOE_ENSURE_SMEM(...)                                                \
+  do {                                                                       \
+    const int rc__ = smoe_kernel_ensure(SmoeKernelReg<__VA_ARGS__>::entry);  \
+    if (rc__ != 0) return rc__;                                              \
+  } while (0)
+
 static inline int smoe_dtype_size(int code) { return code == SMOE_F32 ? 4 : 2; }
 static inline bool smoe_dtype_ok(int code) { return code == SMOE_F32 || code == SMOE_F16 || code == SMOE_BF16; }

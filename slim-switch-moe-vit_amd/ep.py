@@ -27,6 +27,8 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from ._cache import StreamCache
+
 
 class _DoneWork:
     """Stand-in for a collective's work handle when the exchange already completed synchronously."""
@@ -129,16 +131,13 @@ def segment_table(gec_c: torch.Tensor) -> Tuple[List[int], List[int]]:
     return offs, [e for _ in range(W) for e in range(E_local)]
 
 
-_gexp_cache = {}
+_gexp_cache = StreamCache()
 
 
 def _group_expert_ids(W: int, E_local: int, device) -> torch.Tensor:
     """Local expert id of every received row group ([w][e] order) -- constant per (W, E_local), kept on the device."""
-    key = (W, E_local, str(device))
-    t = _gexp_cache.get(key)
-    if t is None:
-        t = _gexp_cache[key] = torch.arange(E_local, dtype=torch.int32, device=device).repeat(W)
-    return t
+    return _gexp_cache.get((W, E_local, str(device)), 0,
+                           lambda: torch.arange(E_local, dtype=torch.int32, device=device).repeat(W))
 
 
 def all_to_all_rows(rows: torch.Tensor, send_rows: List[int], recv_rows: List[int], group=None, async_op: bool = False):

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._cache import StreamCache, param_version
 
 _COMPUTE_DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
 
@@ -39,7 +40,8 @@ class FMoELinear(nn.Module):
         else:
             self.register_parameter("bias", None)
         self.reset_parameters()
-        self._shadow = {}  # compute dtype -> (version, tensor)
+        self._shadow = StreamCache()  # compute dtype -> 16-bit copy, with the event of the cast that made it
+        self.register_load_state_dict_post_hook(lambda mod, _keys: mod._shadow.invalidate())
 
     def reset_parameters(self):
         # upstream: kaiming_uniform_(a=sqrt(5)) on the 3-D weight, zero bias
@@ -52,13 +54,7 @@ class FMoELinear(nn.Module):
         w = self.weight
         if w.dtype == dtype:
             return w.detach()
-        key = (dtype, w.device)
-        ver = (w._version, w.data_ptr())
-        hit = self._shadow.get(key)
-        if hit is None or hit[0] != ver:
-            hit = (ver, ops.cast(w.detach().contiguous(), dtype))
-            self._shadow[key] = hit
-        return hit[1]
+        return self._shadow.get((dtype, w.device), param_version(w), lambda: ops.cast(w.detach().contiguous(), dtype))
 
     def extra_repr(self):
         return f"num_expert={self.num_expert}, in_features={self.in_feat}, out_features={self.out_feat}"

@@ -11,6 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from ._cache import StreamCache
 
 F32, F16, BF16 = 0, 1, 2
 GATE_NAIVE, GATE_SWITCH = 0, 1
@@ -31,6 +32,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _stream(t: torch.Tensor):
+    _lib.init_device(t.device.index)  # first touch of a device: all launch attributes set before any launch
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -397,14 +399,11 @@ def grouped_wgrad(PT: torch.Tensor, QT: torch.Tensor, offsets_pad: torch.Tensor)
     return out
 
 
-_zero_pages = {}
+_zero_pages = StreamCache()
 
 
 def _zero16(device) -> torch.Tensor:
-    t = _zero_pages.get(str(device))
-    if t is None:
-        t = _zero_pages[str(device)] = torch.zeros(64, dtype=torch.uint8, device=device)
-    return t
+    return _zero_pages.get(str(device), 0, lambda: torch.zeros(64, dtype=torch.uint8, device=device))
 
 
 def grouped_wgrad_rows(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:

@@ -313,3 +313,24 @@ def test_grouped_wgrad_rows_matches_per_expert_matmul(counts, R1, R2, dtype, tol
     Lp = ops.padded_len(n + 3, E)
     old = ops.grouped_wgrad(ops.transpose_pad(P, offsets, offp, Lp), ops.transpose_pad(Q, offsets, offp, Lp), offp).cpu().double()
     assert (got - old).abs().max().item() <= 1e-3 * max(1.0, old.abs().max().item())
+
+
+def test_grouped_wgrad_rows_tail_rows_never_meet_foreign_bytes():
+    """Rows past an expert's range (the tail of its last 64-token K-tile) read a zero page for BOTH operands.  Round 1
+    substituted the first bytes of Q for the second operand and relied on 0 * x = 0: with an Inf there (an f16 overflow
+    in expert 0's rows) every other expert's gradient turned NaN."""
+    counts = [70, 37, 100, 5]
+    E, R1, R2 = len(counts), 136, 264
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device=DEV)
+    n = sum(counts)
+    g = _gen(4242)
+    P = (torch.randn(n, R1, generator=g) * 0.5).half()
+    Q = (torch.randn(n, R2, generator=g) * 0.5).half()
+    Q[0, :16] = float("inf")
+    P[0, :16] = float("inf")
+    got = ops.grouped_wgrad_rows(P.to(DEV), Q.to(DEV), offsets).cpu().double()
+    o = offsets.tolist()
+    for e in range(1, E):   # expert 0 owns the Inf row; everyone else must be untouched by it
+        ref = P[o[e]:o[e + 1]].double().t() @ Q[o[e]:o[e + 1]].double()
+        assert torch.isfinite(got[e]).all(), e
+        assert (got[e] - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item()), e

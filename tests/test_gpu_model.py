@@ -303,3 +303,42 @@ def test_expert_parallel_ranks_on_one_gpu_match_single_rank_model(world):
         assert res[2] <= 1e-3 and res[3] <= 1e-3, (rank, res)
         assert res["attribution"]["clean_images"] >= 2, (rank, res)
 
+
+
+def _two_stream_worker(q):
+    """Two compute streams (VisionTransformer.compute_streams = 2): each half of the batch must come out bit for bit
+    as it does alone on one stream, over several steps, with the derived tensors (16-bit weight shadows, the constant
+    offset tables keyed by the HALF batch's row count) first produced inside the two-stream run."""
+    torch.manual_seed(0)
+    model = _init(sm.create_model("moe_base_patch16_224_expert8_top1", num_classes=100, depth=4), 21).eval().to(DEV)
+    images = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(22)).to(DEV)
+    worst = 0.0
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        model.compute_streams = 2
+        first = model(images).float()          # caches are cold here: filled on one side stream, used by the other
+        for _ in range(25):
+            got = model(images).float()
+            worst = max(worst, float((got - first).abs().max()))
+        model.compute_streams = 1
+        alone = torch.cat([model(images[:16]).float(), model(images[16:]).float()], 0)
+    torch.cuda.synchronize()
+    q.put({"repeat_err": worst, "vs_single_stream": float((first - alone).abs().max())})
+
+
+def test_two_compute_streams_reproduce_the_single_stream_forward():
+    """Round 1 saw 2 of ~20 two-stream probe runs never finish.  What the code had that could explain it: derived
+    tensors (fp16 weight shadows, the [0, rows] int32 offset table of the single-group GEMMs, keyed by the half
+    batch's row count) were produced on whichever stream arrived first and consumed on the other WITHOUT an event --
+    a GEMM reading a not-yet-written offset table runs with wild row ranges; the router's redo pass took its trip
+    count from device memory unclamped; per-launcher `static bool` attribute flags.  All three are fixed
+    (_cache.StreamCache, clamps in router16.hip / router.hip, smoe_init + per-device atomic bits); this runs the
+    two-stream forward ONCE, in a child process with a finite timeout."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_two_stream_worker, args=(q,))
+    p.start()
+    _join_or_kill([p], 240)
+    res = q.get(timeout=10)
+    print("two compute streams:", res)
+    assert res["repeat_err"] == 0.0 and res["vs_single_stream"] == 0.0, res
