@@ -72,6 +72,34 @@ int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_gamma, const
                         int64_t T, int d, int E, int k, int gate_kind, int64_t* idx, float* score,
                         float* logits_out, float* probs, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Token-skip gate of the residual-MoE block (models/resMoE.py:32-85 `Gate`; used at 126-145), fused with the LayerNorm
+ * in front of it and -- for the MoE half -- with the router behind it: ONE pass over the activations replaces
+ * `x = norm(x); mask = gate(x); skip_tk = x * mask[..,0]; tk = x * mask[..,1]` (+ the router's own pass over tk).
+ *   xn   = with_ln ? LN(x) * gamma + beta : x                                  x [T,d] f32
+ *   z    = <xn, gate_w> + gate_b;   skipped <=> sigmoid(z) > *threshold  <=>  z > logit(*threshold)
+ *          (decided as if z were accumulated in f64: f32 pass with an error bound + f64 redo, like the router;
+ *           threshold is read from DEVICE memory -- the module's buffer -- so no host sync; NULL = gate disabled)
+ *   xn16 [T,d] (f16/bf16, may be NULL): the operand image of `tk`: xn, zeros for skipped tokens
+ *   xn32 [T,d] (f32, may be NULL): the residual image `tk + skip_tk` = xn, plus zero_out[d] (may be NULL) on skipped
+ *          rows -- the MoE output every all-zero row receives (smoe_zero_row_output), so the caller never dispatches them
+ *   mask [T,2] f32 (skip, keep) (may be NULL);  *skip_count += skipped tokens (may be NULL)
+ *   E > 0: NaiveGate routing of `tk` (a skipped token routes as the zero row it is: by the gate bias):
+ *          idx / score as smoe_router_topk; idx_plan [T,k] = idx, or -1 for skipped tokens (feed THIS to
+ *          smoe_dispatch_plan).  E == 0: gate only (the attention half).
+ * Shapes: smoe_gate_ln_router_supported(d, E, k): d in {192, 384, 768, 1024}, E <= 8, k <= 4.
+ * workspace as smoe_router_workspace_bytes(T).                                                              */
+int smoe_gate_ln_router_supported(int d, int E, int k);
+int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                        const float* gate_w, const float* gate_b, const float* threshold, void* xn16, int xn16_dtype,
+                        float* xn32, const float* zero_out, const float* wg, const float* bg, int64_t T, int d, int E,
+                        int k, int64_t* idx, int64_t* idx_plan, float* score, float* mask, int32_t* skip_count,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* What the MoE returns for an all-zero input row (every token the skip gate masks, resMoE.py:140-143):
+ *   out[d] = sum_j score_j (W2[e_j] gelu(b1[e_j]) + b2[e_j]),  (e_j, score_j) = NaiveGate top-k of the gate bias bg.
+ * w2 [E,d,h], b1 [E,h], b2 [E,d], bg [E] f32 (b1 / b2 / bg may be NULL = zeros).  Depends on parameters only.  */
+int smoe_zero_row_output(const float* bg, int E, int k, const float* w2, const float* b1, const float* b2, int d, int h,
+                         float* out, void* stream);
+
 /* LayerNorm alone (same arithmetic as the fused form; the `norm1` of models/vision_transformer.py:320 feeding the
  * attention GEMMs in 16 bit): d in {192, 384, 768, 1024}.                                              */
 int smoe_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, float eps, int64_t T, int d,

@@ -260,6 +260,75 @@ class FMoETransformerMLP(nn.Module):
             out = ops.gather_combine(y, inv_pos, score, T, k, x2.dtype, residual=x2)
         return out.reshape(shape)
 
+    # -- residual-MoE block half with the token-skip gate (models/resMoE.py:137-143) ---------------------------------
+    def norm_gate_fusable(self, x: torch.Tensor, norm: nn.Module) -> bool:
+        """Whether ``forward_norm_gate_add`` can take ``x``: inference, f32 activations, the reference's GELU expert
+        MLP on 16-bit MFMA operands, the naive gate with at most 8 experts, single rank."""
+        cd = self.compute_dtype or default_compute_dtype()
+        g = self.gate
+        return (x.is_cuda and x.dtype == torch.float32 and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine
+                and tuple(norm.normalized_shape) == (self.d_model,) and self._fused_gelu and not self.training
+                and cd in (torch.float16, torch.bfloat16) and self.gemm_variant == 4 and self.d_model % 64 == 0
+                and not torch.is_grad_enabled() and type(g) is NaiveGate and not self.ep_active()
+                and ops.gate_ln_router_supported(self.d_model, g.tot_expert, g.top_k))
+
+    def zero_row_output(self) -> torch.Tensor:
+        """[d] f32: what this operator returns for an all-zero input row -- the NaiveGate routes it by the gate bias,
+        the experts turn it into ``W2[e] gelu(b1[e]) + b2[e]`` -- computed once per parameter version (HIP GEMV)."""
+        g, ex = self.gate.gate, self.experts
+        ps = (g.bias, ex.h4toh.weight, ex.htoh4.bias, ex.h4toh.bias)
+        ver = tuple(param_version(p) if p is not None else None for p in ps)
+        cache = self.__dict__.get("_zero_row")
+        if cache is None:
+            cache = self.__dict__["_zero_row"] = StreamCache()
+            self.register_load_state_dict_post_hook(lambda m, _k: m.__dict__["_zero_row"].invalidate())
+
+        def make():
+            f = lambda p: None if p is None else p.detach().float().contiguous()
+            return ops.zero_row_output(f(g.bias), self.top_k, f(ex.h4toh.weight), f(ex.htoh4.bias), f(ex.h4toh.bias))
+        return cache.get(str(ex.h4toh.weight.device), ver, make)
+
+    def forward_norm_gate_add(self, x: torch.Tensor, norm: nn.Module, skip_gate) -> torch.Tensor:
+        """``xn = norm(x); m = skip_gate(xn); return self(xn * m[..., 1:]) + xn * m[..., 1:] + xn * m[..., :1]`` -- the
+        MoE half of models/resMoE.py:126-145 -- as: ONE pass over x for LayerNorm + skip gate + router
+        (ops.gate_ln_router), the dispatch plan over the tokens that enter the experts, GEMM-1 gathering its rows from
+        the 16-bit image, GEMM-2 (k = 1) or the combine (k > 1) adding into the f32 residual image in place.  Tokens the
+        gate masks are all-zero rows for the operator: they are not dispatched; their constant output
+        (``zero_row_output``) is added to their residual row by the first pass.  ``skip_gate`` is a resmoe.Gate."""
+        assert self.norm_gate_fusable(x, norm), "forward_norm_gate_add: preconditions (norm_gate_fusable) do not hold"
+        cd = self.compute_dtype or default_compute_dtype()
+        g, d, k = self.gate, self.d_model, self.top_k
+        shape = x.shape
+        x2 = x.reshape(-1, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T = x2.shape[0]
+        lin = skip_gate.head[1]
+        thr = skip_gate.active_threshold()
+        if thr is not None:
+            skip_gate._total_tokens += T
+        r = ops.gate_ln_router(
+            x2, lin.weight, lin.bias, thr,
+            ln=(norm.weight.detach(), norm.bias.detach() if norm.bias is not None else None, norm.eps),
+            wg=g.gate.weight.detach().float().contiguous(), bg=g.gate.bias.detach().float() if g.gate.bias is not None else None,
+            k=k, xn16_dtype=cd, want_xn32=True, zero_out=self.zero_row_output() if thr is not None else None,
+            skip_count=skip_gate.skip_counter(x.device) if thr is not None else None)
+        idx, score, out = r["idx"], r["score"], r["xn32"]
+        counts, offsets, pos, inv_pos, _ = ops.dispatch_plan(r["idx_plan"], g.tot_expert, -1)
+        self.last_plan = (idx, score, counts, offsets, pos, inv_pos)
+        ex = self.experts
+        w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
+        b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
+        b2 = ex.h4toh.bias.detach().float() if ex.h4toh.bias is not None else None
+        h = ops.grouped_gemm(r["xn16"], w1, b1, offsets, ops.EPI_GELU, cd, variant=4, a_gather=pos, a_div=k)
+        if k == 1:
+            ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, torch.float32, row_map=pos, row_scale=score.reshape(-1),
+                             out=out, variant=4, residual=out)
+        else:
+            y = ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, cd, variant=4)
+            ops.gather_combine(y, inv_pos, score, T, k, torch.float32, residual=out, out=out)
+        return out.reshape(shape)
+
     def forward(self, inp: torch.Tensor) -> torch.Tensor:
         if not inp.is_cuda:
             raise RuntimeError("FMoETransformerMLP: input must be on the GPU; this build has no CPU path "

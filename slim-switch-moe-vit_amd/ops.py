@@ -194,6 +194,83 @@ def ln_router_topk(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: 
     return xn16, xn32, idx, score, logits, probs
 
 
+def gate_ln_router_supported(d: int, E: int, k: int) -> bool:
+    return bool(_lib.load().smoe_gate_ln_router_supported(d, E, k))
+
+
+def gate_ln_router(x: torch.Tensor, gate_w: torch.Tensor, gate_b: Optional[torch.Tensor], threshold: Optional[torch.Tensor],
+                   ln: Optional[tuple] = None, wg: Optional[torch.Tensor] = None, bg: Optional[torch.Tensor] = None,
+                   k: int = 1, xn16_dtype: Optional[torch.dtype] = None, want_xn32: bool = False,
+                   zero_out: Optional[torch.Tensor] = None, want_mask: bool = False,
+                   skip_count: Optional[torch.Tensor] = None, xn32_out: Optional[torch.Tensor] = None):
+    """[LayerNorm +] token-skip gate (+ NaiveGate router) in one pass (smoe_gate_ln_router).  ``ln`` = (weight, bias,
+    eps) or None; ``threshold`` = the gate's 0-dim DEVICE buffer (None = gate disabled); ``wg`` None = no router.
+    Returns a dict: xn16, xn32, idx, idx_plan, score, mask (entries that were not asked for are None)."""
+    _chk(x, "x", torch.float32, 2)
+    T, d = x.shape
+    dev = x.device
+    gw = gate_w.detach().reshape(-1)
+    _chk(gw, "gate_w", torch.float32, 1, align=4)
+    if gw.numel() != d:
+        raise RuntimeError(f"gate_w: expected {d} elements")
+    gb = gate_b.detach().reshape(-1) if gate_b is not None else None
+    thr = threshold.detach().reshape(-1) if threshold is not None else None
+    for t, nm in ((gb, "gate_b"), (thr, "threshold")):
+        if t is not None:
+            _chk(t, nm, torch.float32, 1, align=4)
+    E = 0
+    if wg is not None:
+        _chk(wg, "wg", torch.float32, 2)
+        E = wg.shape[0]
+        if bg is not None:
+            _chk(bg, "bg", torch.float32, 1, align=4)
+    lg = lb = None
+    eps = 0.0
+    if ln is not None:
+        lg, lb, eps = ln
+        for t, nm in ((lg, "ln_weight"), (lb, "ln_bias")):
+            if t is not None:
+                _chk(t, nm, torch.float32, 1)
+    if zero_out is not None:
+        _chk(zero_out, "zero_out", torch.float32, 1)
+    xn16 = torch.empty((T, d), dtype=xn16_dtype, device=dev) if xn16_dtype is not None else None
+    xn32 = xn32_out if xn32_out is not None else (torch.empty((T, d), dtype=torch.float32, device=dev) if want_xn32 else None)
+    if xn32 is not None:
+        _chk(xn32, "xn32", torch.float32, 2)
+    idx = torch.empty((T, k), dtype=torch.int64, device=dev) if E else None
+    idx_plan = torch.empty((T, k), dtype=torch.int64, device=dev) if E else None
+    score = torch.empty((T, k), dtype=torch.float32, device=dev) if E else None
+    mask = torch.empty((T, 2), dtype=torch.float32, device=dev) if want_mask else None
+    if skip_count is not None:
+        _chk(skip_count, "skip_count", torch.int32, align=4)
+    lib = _lib.load()
+    ws_bytes = lib.smoe_router_workspace_bytes(T)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    nbytes = T * d * (4 + (2 if xn16 is not None else 0) + (4 if xn32 is not None else 0))
+    with _timed("gate_ln_router" if E else "gate_ln", {"bytes": nbytes}, x):
+        rc = lib.smoe_gate_ln_router(_ptr(x), F32, 1 if ln is not None else 0, _ptr(lg), _ptr(lb), float(eps), _ptr(gw),
+                                     _ptr(gb), _ptr(thr), _ptr(xn16),
+                                     dtype_code(xn16_dtype) if xn16_dtype is not None else F16, _ptr(xn32),
+                                     _ptr(zero_out), _ptr(wg), _ptr(bg), T, d, E, k, _ptr(idx), _ptr(idx_plan),
+                                     _ptr(score), _ptr(mask), _ptr(skip_count), _ptr(ws), ws_bytes, _stream(x))
+    _lib.check(rc, "smoe_gate_ln_router")
+    return {"xn16": xn16, "xn32": xn32, "idx": idx, "idx_plan": idx_plan, "score": score, "mask": mask}
+
+
+def zero_row_output(bg: Optional[torch.Tensor], k: int, w2: torch.Tensor, b1: Optional[torch.Tensor],
+                    b2: Optional[torch.Tensor]) -> torch.Tensor:
+    """out[d] = sum_j score_j (W2[e_j] gelu(b1[e_j]) + b2[e_j]) for the NaiveGate routing of an all-zero row."""
+    _chk(w2, "w2", torch.float32, 3)
+    E, d, h = w2.shape
+    for t, nm in ((bg, "bg"), (b1, "b1"), (b2, "b2")):
+        if t is not None:
+            _chk(t, nm, torch.float32, align=4)
+    out = torch.empty(d, dtype=torch.float32, device=w2.device)
+    rc = _lib.load().smoe_zero_row_output(_ptr(bg), E, k, _ptr(w2), _ptr(b1), _ptr(b2), d, h, _ptr(out), _stream(w2))
+    _lib.check(rc, "smoe_zero_row_output")
+    return out
+
+
 def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Optional[bool] = None):
     """(counts i32 [E], offsets i32 [E+1], pos i64 [n], inv_pos i64 [n], idx_pruned i64 [n] | None)."""
     _chk(idx, "idx", torch.int64, align=8)  # read element-wise: slices of a [T,k] tensor are fine

@@ -8,12 +8,12 @@ argument order; SURVEY.md note A).
 """
 from __future__ import annotations
 
-import math
 import typing as typ
 
 import torch as th
 import torch.nn as nn
 
+from . import ops
 from .fmoe import FMoETransformerMLP
 from .vit import Block, VisionTransformer, register_model, deit_tiny_patch16_224, _deit
 
@@ -27,115 +27,181 @@ __all__ = [
 
 
 class CustomizedMoEMLP(FMoETransformerMLP):
-    """models/resMoE.py:15-29 -- activation = Sequential(act_layer(), Dropout(drop)), naive gate."""
+    """The reference's expert MLP (models/resMoE.py:15-29): ``FMoETransformerMLP`` whose activation is
+    ``act_layer()`` followed by ``Dropout(drop)``, default (naive) gate, ``moe_top_k`` experts per token.
+    Positional arguments in the reference's order; everything after them is this build's keyword-only extension
+    (``gate``, ``capacity_factor``, ``world_size``, ``moe_group``, ``compute_dtype``, ``gemm_variant``)."""
 
-    def __init__(
-        self,
-        in_features: int,
-        hidden_features: int,
-        moe_num_experts: int,
-        moe_top_k: int,
-        drop: float,
-        act_layer: typ.Callable = th.nn.GELU,
-        **moe_kwargs,
-    ):
-        activation = nn.Sequential(*[act_layer(), nn.Dropout(p=drop)])
-        # use naive-gate
-        super().__init__(moe_num_experts, in_features, hidden_features, activation, top_k=moe_top_k, **moe_kwargs)
+    def __init__(self, in_features: int, hidden_features: int, moe_num_experts: int, moe_top_k: int, drop: float,
+                 act_layer: typ.Callable = th.nn.GELU, **moe_kwargs):
+        super().__init__(moe_num_experts, in_features, hidden_features, nn.Sequential(act_layer(), nn.Dropout(p=drop)),
+                         top_k=moe_top_k, **moe_kwargs)
 
 
 class Gate(nn.Module):
-    """Token-skip gate, models/resMoE.py:32-85.  ``forward(x[B,N,d]) -> mask[B,N,2]`` (skip, keep).
+    """Token-skip gate (models/resMoE.py:32-85).  ``forward(x[B,N,d]) -> mask[B,N,2]``: channel 0 marks the tokens
+    that bypass the following operator, channel 1 the tokens that enter it.
 
-    Difference from the reference that does not change results: the skipped-token counter is
-    accumulated on the device and only synchronised when ``_skipped_tokens`` is read (the reference
-    calls ``.item()`` inside forward, resMoE.py:83, which stalls the stream twice per block)."""
+        p = sigmoid(head(x));   skipped  <=>  p > threshold      (``_threshold`` while training, ``threshold`` in eval)
 
-    def __init__(
-        self,
-        in_dim: int,
-        tau: float,
-        dropout: float = 0.0,
-        target_threshold: float = 0.9,
-        starting_threshold: float = 1.0,
-        is_hard: float = True,
-    ):
+    Same constructor signature, sub-module (``head.0`` dropout, ``head.1`` linear), buffers (``_threshold``,
+    ``threshold``) and attributes (``disable``, ``is_hard``, ``_total_tokens``, ``_skipped_tokens``, ``step``) as the
+    reference, so ``isinstance(m, Gate)`` loops (main.py:812) and the ``"moe_gate"`` / ``"dense_gate"`` parameter-name
+    matching (main.py:623) keep working.  What is different underneath:
+
+    * inference runs ONE HIP kernel (ops.gate_ln_router: dot product, threshold decision defined on the f64-accurate
+      logit, mask, device-side skip counter) -- or none at all inside ``forward_residule_moe``'s fused path, where the
+      gate rides on the LayerNorm / router pass;
+    * the hard masks are exactly 0 / 1 in value; training keeps the straight-through estimator through ``p``;
+    * ``_skipped_tokens`` accumulates on the device and is read back only when somebody looks at it (the reference
+      synchronises the stream twice per block with ``.item()``, resMoE.py:83); ``step`` anneals on the device too."""
+
+    def __init__(self, in_dim: int, tau: float, dropout: float = 0.0, target_threshold: float = 0.9,
+                 starting_threshold: float = 1.0, is_hard: float = True):
         super().__init__()
         self.head = nn.Sequential(nn.Dropout(p=dropout), nn.Linear(in_dim, 1))
         self.register_buffer("_threshold", th.tensor(starting_threshold))
         self.register_buffer("threshold", th.tensor(target_threshold))
-
-        self._total_tokens = 0
-        self._skipped_acc = None
-        self._skipped_host = 0.0
-
+        self.tau = tau  # accepted and unused, as in the reference
         self.is_hard = is_hard
         self.disable = False
+        self._total_tokens = 0
+        self._skip_host = 0.0   # skipped tokens already read back
+        self._skip_dev = None   # int32[1] on the device: skipped tokens since the last read-back
+
+    # -- counters ------------------------------------------------------------------------------------------------
+    def skip_counter(self, device) -> th.Tensor:
+        """The device-side counter the HIP kernels add to."""
+        if self._skip_dev is None or self._skip_dev.device != device:
+            self._flush_counter()
+            self._skip_dev = th.zeros(1, dtype=th.int32, device=device)
+        return self._skip_dev
+
+    def _flush_counter(self):
+        if self._skip_dev is not None:
+            self._skip_host += float(self._skip_dev.item())
+            self._skip_dev.zero_()
 
     @property
     def _skipped_tokens(self):
-        if self._skipped_acc is not None:
-            self._skipped_host += float(self._skipped_acc.item())
-            self._skipped_acc = None
-        return self._skipped_host
+        self._flush_counter()
+        return self._skip_host
 
     @_skipped_tokens.setter
     def _skipped_tokens(self, v):
-        self._skipped_acc = None
-        self._skipped_host = float(v)
+        if self._skip_dev is not None:
+            self._skip_dev.zero_()
+        self._skip_host = float(v)
 
-    def step(self, delta: th.Tensor):
-        thresh = self._threshold - delta
-        self._threshold.data.copy_(max(thresh, self.threshold))
+    # -- schedule (main.py:812-815 calls step(delta) once per iteration) -------------------------------------------
+    def step(self, delta):
+        """``_threshold <- max(_threshold - delta, threshold)`` without leaving the device."""
+        th.maximum(self._threshold - delta, self.threshold, out=self._threshold)
+
+    def active_threshold(self) -> typ.Optional[th.Tensor]:
+        """The buffer the decision compares against right now; None when the gate is disabled (everything passes)."""
+        if self.disable:
+            return None
+        return self._threshold if self.training else self.threshold
+
+    def _hip_ok(self, x: th.Tensor) -> bool:
+        lin = self.head[1]
+        return (x.is_cuda and x.dtype == th.float32 and x.dim() == 3 and not (th.is_grad_enabled() and (
+            x.requires_grad or lin.weight.requires_grad)) and not (self.training and (self.head[0].p > 0 or not self.is_hard))
+            and ops.gate_ln_router_supported(x.shape[-1], 0, 1))
 
     def forward(self, x):
+        B, N = x.shape[0], x.shape[1]
         if self.disable:
-            ret = th.zeros((x.size(0), x.size(1), 2), device=x.device)
-            ret[:, :, 1] = 1
-            return ret
-
-        out = self.head(x)  # (B x Token x 1)
-
-        threshold = self._threshold if self.training else self.threshold
-        prob = th.sigmoid(out)
-        _prob = 1 - prob
-
+            return th.stack((x.new_zeros(B, N), x.new_ones(B, N)), dim=-1)
+        self._total_tokens += B * N
+        if self._hip_ok(x):
+            lin = self.head[1]
+            xr = x.reshape(B * N, x.shape[-1])
+            if not xr.is_contiguous():
+                xr = xr.contiguous()
+            r = ops.gate_ln_router(xr, lin.weight, lin.bias, self.active_threshold(), want_mask=True,
+                                   skip_count=self.skip_counter(x.device))
+            return r["mask"].reshape(B, N, 2)
+        # differentiable composition (training; CPU tensors; dtypes the kernel does not take)
+        p = th.sigmoid(self.head(x))
         if self.training and not self.is_hard:
-            skip_tk = _prob
-            tk = prob
+            bypass, enter = 1 - p, p
         else:
-            skip_tk = (prob > threshold).float() + _prob.detach() - _prob
-            tk = (prob <= threshold).float() + prob.detach() - prob
+            hard = (p > self.active_threshold()).to(p.dtype)
+            st = p.detach() - p                     # 0 in value, d/dp = -1: the straight-through estimator
+            bypass, enter = hard - st, (1 - hard) + st
+        skipped = bypass.detach().sum()
+        if skipped.is_cuda:
+            self.skip_counter(x.device).add_(skipped.round().to(th.int32))
+        else:
+            self._skip_host += float(skipped)
+        return th.cat((bypass, enter), dim=-1)
 
-        ret = th.cat([skip_tk, tk], dim=-1)
 
-        self._total_tokens += math.prod(out.shape[0:2])
-        s = skip_tk.sum().detach()
-        self._skipped_acc = s if self._skipped_acc is None else self._skipped_acc + s
-        return ret
+def _gated(x_normed, gate):
+    """(rows that enter the operator, rows that bypass it): the normed activations split by the gate's mask."""
+    mask = gate(x_normed)
+    return x_normed * mask[..., 1:2], x_normed * mask[..., 0:1]
+
+
+def _residual_block_composed(blk, x):
+    """models/resMoE.py:126-145 as a composition of modules (training, f32 / non-autocast inference, CPU): in both
+    halves the residual is the NORMED activation, split by the skip gate into the part the operator sees and the part
+    that bypasses it."""
+    x = blk.norm1(x)
+    enter, bypass = _gated(x, blk.dense_gate)
+    x = blk.drop_path(blk.attn(enter)) + enter + bypass
+    x = blk.norm2(x)
+    enter, bypass = _gated(x, blk.moe_gate)
+    return blk.drop_path(blk.mlp(enter)) + enter + bypass
+
+
+def _fused_ok(blk, x) -> bool:
+    from .vit import _autocast_half_inference, Attention
+    d = x.shape[-1]
+    return (x.is_cuda and x.dim() == 3 and x.dtype == th.float32 and x.is_contiguous() and not blk.training
+            and isinstance(blk.drop_path, nn.Identity) and _autocast_half_inference(x)
+            and isinstance(blk.attn, Attention) and isinstance(blk.dense_gate, Gate) and isinstance(blk.moe_gate, Gate)
+            and all(isinstance(n, nn.LayerNorm) and n.elementwise_affine and tuple(n.normalized_shape) == (d,)
+                    for n in (blk.norm1, blk.norm2))
+            and hasattr(blk.mlp, "norm_gate_fusable") and blk.mlp.norm_gate_fusable(x, blk.norm2)
+            and ops.gate_ln_router_supported(d, 0, 1))
+
+
+def _residual_block_fused(blk, x):
+    """The same block for fp16-autocast inference in six launches' worth of glue-free work per half:
+
+      attention half   norm1 + dense_gate in ONE pass over x (ops.gate_ln_router): the fp16 operand image of the
+                       tokens that enter attention (zero rows for the bypassing ones) and the f32 residual image;
+                       qkv GEMM -> attention kernel -> projection GEMM with `+ residual` in its store
+      MoE half         norm2 + moe_gate + router in ONE pass (FMoETransformerMLP.forward_norm_gate_add): bypassing tokens
+                       are all-zero rows for the experts, so they are not dispatched at all -- what they would receive
+                       (the per-layer constant of ops.zero_row_output) is added to their residual row by the same pass;
+                       GEMM-1 gathers its rows from the fp16 image, GEMM-2 adds into the residual image in place.
+    Preconditions: _fused_ok."""
+    B, N, d = x.shape
+    g = blk.dense_gate
+    lin = g.head[1]
+    n1 = blk.norm1
+    if not g.disable:
+        g._total_tokens += B * N
+    r = ops.gate_ln_router(x.reshape(B * N, d), lin.weight, lin.bias, g.active_threshold(),
+                           ln=(n1.weight.detach(), n1.bias.detach() if n1.bias is not None else None, n1.eps),
+                           xn16_dtype=th.float16, want_xn32=True,
+                           skip_count=None if g.disable else g.skip_counter(x.device))
+    res = r["xn32"].reshape(B, N, d)
+    a, added = blk.attn(r["xn16"].reshape(B, N, d), residual=res)
+    x = a if added else a + res
+    return blk.mlp.forward_norm_gate_add(x, blk.norm2, blk.moe_gate)
 
 
 def forward_residule_moe(self, x):
-    """models/resMoE.py:126-145: residual is taken from the *normed* activations; token-skip gates
-    zero the rows that bypass attention / the MoE."""
-    x = self.norm1(x)
-
-    mask = self.dense_gate(x)
-
-    skip_tk = x * mask[:, :, 0].unsqueeze(dim=-1)
-    tk = x * mask[:, :, 1].unsqueeze(dim=-1)
-
-    x = self.drop_path(self.attn(tk)) + tk + skip_tk
-    x = self.norm2(x)
-
-    mask = self.moe_gate(x)
-
-    skip_tk = x * mask[:, :, 0].unsqueeze(dim=-1)
-    tk = x * mask[:, :, 1].unsqueeze(dim=-1)
-
-    x = self.drop_path(self.mlp(tk)) + tk + skip_tk
-
-    return x
+    """Bound to every Block by the ``resmoe_*`` factories in place of ``Block.forward`` (models/resMoE.py:126-145,
+    185-186)."""
+    if _fused_ok(self, x):
+        return _residual_block_fused(self, x)
+    return _residual_block_composed(self, x)
 
 
 def patch_blocks_with_moe(model: VisionTransformer, num_experts: int, top_k: int, residual: bool,
