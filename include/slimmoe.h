@@ -105,7 +105,8 @@ int smoe_zero_row_output(const float* bg, int E, int k, const float* w2, const f
 int smoe_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, float eps, int64_t T, int d,
                    void* out, int out_dtype, void* stream);
 
-/* Self-attention forward of the block's attention half (models/vision_transformer.py:248-280), N <= 256 tokens,
+/* Self-attention forward of the block's attention half (models/vision_transformer.py:248-280), N <= 640 tokens
+ * (one pass for N <= 256; above that -- ViT-L/16 @384: N = 577 -- key chunks with an online softmax),
  * head dim 64: out[b,n,h*64+:] = softmax(q k^T * scale) v with qkv [B,N,3,H,64] as the fused qkv projection
  * writes it; f16 / bf16.  Caller-side kernel, not part of the MoE operator.       */
 int smoe_attention_supported(int N, int head_dim);

@@ -1,4 +1,4 @@
-// Self-attention forward for ViT token counts (N <= 256, head dim 64): softmax(q k^T * scale) v, models/
+// Self-attention forward for ViT token counts (N <= 256 in one pass, N <= 640 with an online softmax; head dim 64): softmax(q k^T * scale) v, models/
 // vision_transformer.py:248-280 -- the caller-side kernel next to the MoE hot path.
 //
 // One workgroup (4 waves) per (image, head): K and V of that head (N x 64, 16-bit) sit in LDS, every wave walks
@@ -232,6 +232,190 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __re
   }
 }
 
+// ---- long sequences (256 < N <= 640; ViT-L/16 @384: N = 577, models/vision_transformer.py:1227-1236) ------------------
+// Same layout and fragment roles as attn_fwd_kernel; K and V of the head still sit in LDS whole (N = 577: 2 x 74 KB), but
+// the scores of a query tile no longer fit the registers, so the keys are walked in CHUNKS of CH tiles with the online
+// softmax: running maximum m, running denominator l (kept on the matrix pipe, as above) and running output O are
+// rescaled by exp2((m_old - m_new) c) at every chunk -- unconditionally (no threshold, no data-dependent branch).
+// 8 waves per workgroup (one workgroup per CU: the LDS is full), each wave walks query tiles wave, wave + 8, ...
+constexpr int ATTL_THREADS = 512;
+template <typename HT, int NKT, int CH>
+__global__ __launch_bounds__(ATTL_THREADS, 2) void attn_fwd_long_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
+                                                                        int H, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(CH % 2 == 0, "chunks are whole 32-key k-steps");
+  constexpr int NCHUNK = (NKT + CH - 1) / CH;
+  char* Ks = smem;
+  char* Vs = smem + NKT * 16 * 128;
+  const int bh = blockIdx.x;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t tok_stride = (int64_t)3 * H * ATT_D;
+  const HT* base = qkv + (int64_t)b * N * tok_stride + h * ATT_D;
+  {
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int l_row = lane >> 3, l_pos = lane & 7;
+    for (int pc = wave_u; pc < NKT * 2; pc += ATTL_THREADS / 64) {
+      const int row = pc * 8 + l_row;
+      const int srow = row < N ? row : N - 1;
+      const HT* p = base + (int64_t)srow * tok_stride;
+      const int kc = l_pos ^ ((row >> 1) & 7);
+      const int vc = (((l_pos >> 1) ^ ((row >> 1) & 3)) << 1) | (l_pos & 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + H * ATT_D + kc * 8),
+                                       (__attribute__((address_space(3))) void*)(Ks + pc * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 2 * H * ATT_D + vc * 8),
+                                       (__attribute__((address_space(3))) void*)(Vs + pc * 1024), 16, 0, 0);
+    }
+  }
+  const int g = lane >> 4, qi = lane & 15;
+  const int nqt = (N + 15) >> 4;
+  auto load_q = [&](int qt, u32x4& f0, u32x4& f1) {
+    int qrow = qt * 16 + qi;
+    if (qrow >= N) qrow = N - 1;
+    const HT* qp = base + (int64_t)qrow * tok_stride + g * 8;
+    f0 = *reinterpret_cast<const u32x4*>(qp);
+    f1 = *reinterpret_cast<const u32x4*>(qp + 32);
+  };
+  u32x4 qn0 = u32x4{0u, 0u, 0u, 0u}, qn1 = qn0;
+  if (wave < nqt) load_q(wave, qn0, qn1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const u32x4 ones = std::is_same<HT, f16>::value ? u32x4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u}
+                                                  : u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const int tq = qi >> 2, tp = qi & 3;
+  for (int qt = wave; qt < nqt; qt += ATTL_THREADS / 64) {
+    const int q0 = qt * 16;
+    const u32x4 qf0 = qn0, qf1 = qn1;
+    if (qt + ATTL_THREADS / 64 < nqt) load_q(qt + ATTL_THREADS / 64, qn0, qn1);
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 lacc = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY;
+    // the chunk loop is NOT unrolled (one chunk's scores in registers at a time); every chunk has CH full tile slots,
+    // slots past the last tile held in LDS re-read tile NKT - 1 and are masked like every key >= N
+#pragma unroll 1
+    for (int c = 0; c < NCHUNK; ++c) {
+      const int t0 = __builtin_amdgcn_readfirstlane(c * CH);
+      f32x4 sacc[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) sacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // S^T tiles of the chunk, two tiles (4 fragment reads) ahead of their 4 MFMAs
+#pragma unroll
+      for (int i0 = 0; i0 < CH; i0 += 2) {
+        u32x4 kf[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int tl = (t0 + i0 + i < NKT) ? (t0 + i0 + i) : (NKT - 1);
+          kf[i][0] = *reinterpret_cast<const u32x4*>(Ks + k_lds_off(tl * 16 + qi, g));
+          kf[i][1] = *reinterpret_cast<const u32x4*>(Ks + k_lds_off(tl * 16 + qi, 4 + g));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if constexpr (std::is_same<HT, f16>::value)
+              sacc[i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, kf[i][hf]), __builtin_bit_cast(f16x8, hf ? qf1 : qf0), sacc[i0 + i], 0, 0, 0);
+            else
+              sacc[i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kf[i][hf]), __builtin_bit_cast(bf16x8_t, hf ? qf1 : qf0), sacc[i0 + i], 0, 0, 0);
+          }
+        }
+      }
+      if ((t0 + CH) * 16 > N) {  // wave-uniform: only the chunk(s) reaching past key N - 1 carry mask code
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((t0 + i) * 16 + g * 4 + r >= N) sacc[i][r] = -INFINITY;
+      }
+      float mc = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) mc = fmaxf(fmaxf(mc, fmaxf(sacc[i][0], sacc[i][1])), fmaxf(sacc[i][2], sacc[i][3]));
+      mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
+      mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+      const float m_new = fmaxf(m_run, mc);                  // finite from the first chunk on (it holds key 0 < N)
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);   // first chunk: exp2(-inf) = 0
+      m_run = m_new;
+      const float nmc = -m_new * scale_log2e;
+#pragma unroll
+      for (int i = 0; i < CH; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[i][r] = __builtin_amdgcn_exp2f(fmaf(sacc[i][r], scale_log2e, nmc));
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
+      lacc *= alpha;
+      // O^T += V^T P^T, l += 1^T P^T over the chunk's k-steps of 32 keys (masked slots carry P = 0 exactly)
+#pragma unroll
+      for (int ks = 0; ks < CH / 2; ++ks) {
+        u32x4 pf;
+        if constexpr (std::is_same<HT, f16>::value) {
+          f16x8 t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { t[r] = (f16)sacc[2 * ks][r]; t[4 + r] = (f16)sacc[2 * ks + 1][r]; }
+          pf = __builtin_bit_cast(u32x4, t);
+        } else {
+          s16x8 t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { t[r] = (short)f32_to_bf16(sacc[2 * ks][r]); t[4 + r] = (short)f32_to_bf16(sacc[2 * ks + 1][r]); }
+          pf = __builtin_bit_cast(u32x4, t);
+        }
+        const int ta = (t0 + 2 * ks < NKT) ? (t0 + 2 * ks) : (NKT - 1);
+        const int tb = (t0 + 2 * ks + 1 < NKT) ? (t0 + 2 * ks + 1) : (NKT - 1);
+        s16x4 v0[4], v1[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          v0[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + v_lds_off(ta * 16 + 4 * g + tq, dt) + tp * 8));
+          v1[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vs + v_lds_off(tb * 16 + 4 * g + tq, dt) + tp * 8));
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          s16x8 vf;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { vf[r] = v0[dt][r]; vf[4 + r] = v1[dt][r]; }
+          if constexpr (std::is_same<HT, f16>::value)
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vf), __builtin_bit_cast(f16x8, pf), oacc[dt], 0, 0, 0);
+          else
+            oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vf), __builtin_bit_cast(bf16x8_t, pf), oacc[dt], 0, 0, 0);
+        }
+        if constexpr (std::is_same<HT, f16>::value)
+          lacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, pf), lacc, 0, 0, 0);
+        else
+          lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ones), __builtin_bit_cast(bf16x8_t, pf), lacc, 0, 0, 0);
+      }
+    }
+    const float inv_l = 1.0f / lacc[0];
+    if (q0 + qi < N) {
+      HT* op = out + ((int64_t)b * N + q0 + qi) * (H * ATT_D) + h * ATT_D + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        if constexpr (std::is_same<HT, f16>::value) {
+          f16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (f16)(oacc[dt][r] * inv_l);
+          *reinterpret_cast<f16x4*>(op + dt * 16) = o;
+        } else {
+          s16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (short)f32_to_bf16(oacc[dt][r] * inv_l);
+          *reinterpret_cast<s16x4*>(op + dt * 16) = o;
+        }
+      }
+    }
+  }
+}
+
+template <typename HT, int NKT>
+int launch_attn_long(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s) {
+  constexpr int CH = 10;
+  const size_t smem = 2 * (size_t)NKT * 16 * 128;
+  SMOE_ENSURE_SMEM(attn_fwd_long_kernel<HT, NKT, CH>);
+  hipLaunchKernelGGL((attn_fwd_long_kernel<HT, NKT, CH>), dim3(B * H), dim3(ATTL_THREADS), smem, s, (const HT*)qkv, (HT*)out,
+                     N, H, scale * 1.4426950408889634f);
+  SMOE_CHECK_LAUNCH("smoe_attention_fwd/long");
+  return 0;
+}
+
 template <typename HT, int NKT, bool EXACT>
 int launch_attn(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s) {
   const size_t smem = 2 * (size_t)NKT * 16 * 128;
@@ -254,14 +438,19 @@ int attn_dispatch(const void* qkv, void* out, int B, int N, int H, float scale, 
   if (nkt < 8) return launch_attn<HT, 8, false>(qkv, out, B, N, H, scale, s);
   if (nkt < 13) return launch_attn<HT, 13, false>(qkv, out, B, N, H, scale, s);
   if (nkt < 16) return launch_attn<HT, 16, false>(qkv, out, B, N, H, scale, s);
-  smoe_set_error("smoe_attention_fwd: N=%d unsupported (N <= 256)", N);
+  // long sequences: K / V tiles held in LDS rounded up to the next instantiated size (rows >= N duplicate row N - 1)
+  if (nkt <= 20) return launch_attn_long<HT, 20>(qkv, out, B, N, H, scale, s);
+  if (nkt <= 30) return launch_attn_long<HT, 30>(qkv, out, B, N, H, scale, s);
+  if (nkt <= 37) return launch_attn_long<HT, 37>(qkv, out, B, N, H, scale, s);   // N = 577: ViT-L/16 @384 + cls
+  if (nkt <= 40) return launch_attn_long<HT, 40>(qkv, out, B, N, H, scale, s);
+  smoe_set_error("smoe_attention_fwd: N=%d unsupported (N <= 640)", N);
   return 1;
 }
 
 }  // namespace
 
 // qkv [B, N, 3, H, 64] (the output layout of the fused qkv projection), out [B, N, H*64]; f16 or bf16.
-extern "C" int smoe_attention_supported(int N, int head_dim) { return (N >= 1 && N <= 256 && head_dim == ATT_D) ? 1 : 0; }
+extern "C" int smoe_attention_supported(int N, int head_dim) { return (N >= 1 && N <= 640 && head_dim == ATT_D) ? 1 : 0; }
 
 extern "C" int smoe_attention_fwd(const void* qkv, void* out, int dtype, int B, int N, int H, int head_dim, float scale,
                                   void* stream) {
