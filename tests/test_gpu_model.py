@@ -140,7 +140,8 @@ def test_resmoe_factory_forward_matches_oracle_block_semantics():
 
 def test_cfg4_vit_large_384_e32_shapes_run_and_match_oracle():
     """BASELINE cfg 4 shapes (ViT-L/16 @384: 577 tokens, d 1024, h 4096, E=32, top-1) on a 1-block copy of the model:
-    general router (E > 8), SDPA fallback for N > 256, default GEMM variant; vs the oracle in fp32 mode."""
+    general router (E > 8), the long-sequence attention kernel (N = 577, under autocast), default GEMM variant; vs the
+    oracle."""
     torch.manual_seed(0)
     model = _init(sm.create_model("moe_large_patch16_384_expert32_top1", num_classes=10, depth=1,
                                   compute_dtype=torch.float32), 9).eval()

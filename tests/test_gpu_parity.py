@@ -376,6 +376,26 @@ def test_attention_kernel_matches_reference_attention(B, N, H, dt, tol):
     assert (got.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 577, 16), (1, 257, 2), (2, 300, 3), (1, 592, 2), (1, 640, 1), (3, 321, 4), (1, 480, 2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
+def test_attention_kernel_long_sequences_online_softmax(B, N, H, dt, tol):
+    """N > 256 (BASELINE cfg 4: ViT-L/16 @384 has N = 577): key chunks with an online softmax.  The second input makes
+    the running maximum jump by > 40 between chunks (a spiked key in every chunk region, larger in later ones), so the
+    rescale of the running output / denominator is exercised, not just present."""
+    g = _gen(B * 1000 + N + H)
+    for spike in (False, True):
+        qkv = (torch.randn(B, N, 3, H, 64, generator=g) * 1.5)
+        if spike:
+            for j, pos in enumerate(range(5, N, 97)):
+                qkv[:, pos, 1] = qkv[:, 3, 0] * (2.0 + 1.5 * j)      # key `pos` aligned with query 3, growing with pos
+        qkv = qkv.to(dt)
+        got = ops.attention(qkv.to(DEV), B, N, H, 64, 64 ** -0.5).cpu().float()
+        q, k, v = qkv.double().permute(2, 0, 3, 1, 4).unbind(0)
+        ref = (torch.softmax(q @ k.transpose(-2, -1) * 64 ** -0.5, -1) @ v).transpose(1, 2).reshape(B, N, H * 64)
+        assert torch.isfinite(got).all()
+        assert (got.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), spike
+
+
 def test_attention_path_matches_reference_attention_golden(golden_dir):
     """The REFERENCE's own ``Attention`` outputs (models/layers.py:227-269 == models/vision_transformer.py:248-280;
     tests/golden/ref_attention_tiny.npz): (1) smoe_attention_fwd on the qkv the reference weights give, then the
