@@ -1187,6 +1187,8 @@ int launch_pp256(const void* A, const void* W, const float* bias, const int32_t*
   return 0;
 }
 
+#include "gemm_persistent.h"
+
 template <typename AB>
 int launch_wgrad(const void* PT, const void* QT, const int32_t* offsets_pad, int E, int R1, int R2, int Lp, float* out,
                  hipStream_t s) {
@@ -1254,6 +1256,23 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
 #else
       case 5: return launch_pp256<AB, OT, 0, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
 #endif
+      case 9: {  // as 4 (auto tile height / schedule), on the persistent kernel
+        const int ntn = (N + 255) / 256;
+        const int64_t t256 = ((m_rows_max + 255) / 256 + E / 2) * ntn, t320 = ((m_rows_max + 319) / 320 + E / 2) * ntn;
+        const int cus = smoe_num_cus();
+        const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c320 = (double)((t320 + cus - 1) / cus) * 1.25;
+        const bool deep = K >= 2048;
+        if (c320 <= c256) {
+          if (deep) return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+          return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+        }
+        if (deep) return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+        return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+      }
+      case 10: return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+      case 11: return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+      case 12: return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+      case 13: return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
       case 6: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
       case 7: return launch_pp256<AB, OT, 16, 4>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
       case 8: return launch_pp256<AB, OT, 16, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
@@ -1308,8 +1327,8 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   if (m_rows_max == 0) return 0;
   SMOE_REQUIRE(A && W && out, "smoe_grouped_gemm: null pointer");
   if (K % 64 != 0 || smoe_dtype_size(ab_dtype) != 2) variant = 0;
-  SMOE_REQUIRE(!a_gather || (variant >= 4 && variant <= 8 && a_div >= 1),
-               "smoe_grouped_gemm: a_gather needs variant 4-8 (16-bit operands, K %% 64 == 0)");
+  SMOE_REQUIRE(!a_gather || (variant >= 4 && variant <= 13 && a_div >= 1),
+               "smoe_grouped_gemm: a_gather needs variant 4-13 (16-bit operands, K %% 64 == 0)");
   hipStream_t s = (hipStream_t)stream;
   switch (ab_dtype) {
     case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div);

@@ -1,0 +1,432 @@
+// Persistent form of the 8-wave ping-pong grouped GEMM (included by gemm.hip behind grouped_gemm_pp256; uses its helpers).
+//
+// One workgroup per CU walks tiles  slot, slot + G, slot + 2 G, ...  (G = grid size; inside a round the slots are
+// XCD-contiguous: workgroups that share an XCD take neighbouring tiles = shared operand panels in its L2).  What the
+// loop buys over one workgroup per tile:
+//   * the NEXT tile is located, its (gathered) row addresses are loaded and its first K-tile is on its way into LDS
+//     buffer 0 BEFORE the current tile's epilogue starts (the epilogue stages the output tile through buffer 1 and
+//     the 16 KiB of LDS behind the two buffers), so the ~3 us of tile lookup + gather-address latency + first operand
+//     fetch that opened every workgroup now run under the GELU / convert / store work;
+//   * no workgroup launch, LDS allocation and kernel-argument fetch per tile;
+//   * the epilogue's passes are separated by raw barriers (LDS ordering only): a pass no longer waits for the
+//     previous pass's global stores to be acknowledged (__syncthreads() drains the vector-memory counter).
+// Ordering of the operand DMA against the stores: vmcnt counts in issue order, so a counted wait that covers K-tile 0
+// of the next tile would also cover every store issued after it.  Instead each wave drains vmcnt(0) right before
+// the barrier of the LAST epilogue pass -- K-tile 0 was issued a whole epilogue earlier and has landed, the earlier
+// passes' stores are one GELU phase old -- and the last pass's stores then leave with nothing waiting on them: the
+// main loop's first counted wait comes a full K-tile (8 intervals) later.
+//
+// Main loop, LDS layout, fragment roles and both DMA schedules (DEEP = half-organised regions, two half-tiles in flight
+// across the tile boundary) are those of grouped_gemm_pp256; results are bit-identical to it (same accumulation order).
+template <typename AB, typename OT, int AFR, bool DEEP>
+__global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
+    const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* residual, OT* out, int n_tiles_n,
+    int group_m, const int64_t* __restrict__ a_gather, int a_div) {
+  static_assert(sizeof(AB) == 2, "16-bit operands");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TBM = 64 * AFR, TBN = 256, NT = 512, NW = 8;
+  constexpr int STAGE = (TBM + TBN) * BK_BYTES;  // 64 KiB (72 KiB for the 320-row tile)
+  constexpr int ASLOTS = TBM / 8 / NW;           // 1-KiB DMA pieces per wave per K-tile: A (= AFR)
+  constexpr int SLOTS = 4;                       //                                        W
+  constexpr int LDS_TOTAL = 160 * 1024;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l_row = lane >> 3, l_pos = lane & 7;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nk = K / 64;
+
+  // ---- tile enumeration ------------------------------------------------------------------------------------------------
+  int total_mt = 0;
+  for (int i = 0; i < E; ++i) total_mt += (offsets[i + 1] - offsets[i] + TBM - 1) / TBM;
+  const int per_group = group_m * n_tiles_n;
+  const int n_tiles = ((total_mt + group_m - 1) / group_m) * per_group;
+  const int G = gridDim.x, per_xcd = G >> 3;     // the launcher keeps G a multiple of 8
+  int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  int e = 0, m0 = 0, m_end = 0, n0 = 0;          // the tile whose operands are being set up / streamed
+  auto advance = [&]() -> bool {                 // first existing tile at or after `tile` on this workgroup's stride
+    while (tile < n_tiles) {
+      const int g = tile / per_group, rem = tile % per_group;
+      if (find_tile(offsets, E, g * group_m + rem % group_m, e, m0, m_end, TBM)) {
+        if (group_expert) e = group_expert[e];
+        n0 = (rem / group_m) * TBN;
+        return true;
+      }
+      tile += G;
+    }
+    return false;
+  };
+
+  // ---- operand source pointers of the current (e, m0, m_end, n0) -----------------------------------------------------
+  constexpr int A_HALF_PIECES = TBM / 16;                      // 8-row DMA pieces per A-half (16 / 20)
+  constexpr int A_HS = (A_HALF_PIECES + NW - 1) / NW;          // pieces per wave per A-half, rounded up (2 / 3)
+  const AB* a_src[DEEP ? 2 * A_HS : ASLOTS];
+  const AB* w_src[SLOTS];
+  auto setup = [&]() {
+    if constexpr (!DEEP) {
+#pragma unroll
+      for (int s = 0; s < ASLOTS; ++s) {
+        const int r = 8 * (s * NW + wave) + l_row;
+        int gr = m0 + r;
+        if (gr >= m_end) gr = m_end - 1;
+        const int64_t arow = a_gather ? a_gather[gr] / a_div : (int64_t)gr;   // fused MOEScatter
+        a_src[s] = A + arow * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+      }
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        const int r = 8 * (s * NW + wave) + l_row;
+        int gw = n0 + r;
+        if (gw >= N) gw = N - 1;
+        w_src[s] = W + ((int64_t)e * N + gw) * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int s2 = 0; s2 < A_HS; ++s2) {
+          int pi = wave + NW * s2;
+          if (pi >= A_HALF_PIECES) pi = A_HALF_PIECES - 1;       // never issued (guarded below); keep the pointer valid
+          const int r = pi * 8 + l_row;                          // row inside the half
+          const int trow = (r / (16 * AFR)) * (TBM / 2) + h * (16 * AFR) + r % (16 * AFR);
+          int gr = m0 + trow;
+          if (gr >= m_end) gr = m_end - 1;
+          const int64_t arow = a_gather ? a_gather[gr] / a_div : (int64_t)gr;
+          a_src[h * A_HS + s2] = A + arow * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int r = (wave + NW * s2) * 8 + l_row;            // row inside the half (0..127)
+          int gw = n0 + (r / 32) * 64 + h * 32 + r % 32;
+          if (gw >= N) gw = N - 1;
+          w_src[h * 2 + s2] = W + ((int64_t)e * N + gw) * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+        }
+      }
+    }
+  };
+#define PS_DMA(SRC, DST)                                                                             \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),             \
+                                   (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+  // non-DEEP pieces: "lo" (s0 == 0) = slots 0,1 (tile rows 0-127, read by wave group 0 only), "hi" = the rest
+  auto dma_a = [&](int kt, int buf, int s0) {
+    char* sa = smem + buf * STAGE;
+    if (s0 == 0) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) PS_DMA(a_src[s] + kt * 64, sa + (s * NW + wave) * 1024);
+    } else {
+#pragma unroll
+      for (int s = 2; s < ASLOTS; ++s) PS_DMA(a_src[s] + kt * 64, sa + (s * NW + wave) * 1024);
+    }
+  };
+  auto dma_w = [&](int kt, int buf, int s0) {
+    char* sw = smem + buf * STAGE + TBM * BK_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) PS_DMA(w_src[s0 + s] + kt * 64, sw + ((s0 + s) * NW + wave) * 1024);
+  };
+  // DEEP half-tiles
+  auto dma_ah = [&](int kt, int buf, int h) {
+    char* sa = smem + buf * STAGE + h * (TBM / 2) * BK_BYTES;
+#pragma unroll
+    for (int s2 = 0; s2 < A_HS; ++s2) {
+      if (A_HALF_PIECES % NW == 0 || s2 + 1 < A_HS || wave < A_HALF_PIECES % NW)
+        PS_DMA(a_src[h * A_HS + s2] + kt * 64, sa + (wave + NW * s2) * 1024);
+    }
+  };
+  auto dma_wh = [&](int kt, int buf, int h) {
+    char* sw = smem + buf * STAGE + (TBM + h * 128) * BK_BYTES;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) PS_DMA(w_src[h * 2 + s2] + kt * 64, sw + (wave + NW * s2) * 1024);
+  };
+  auto wait_keep2 = [&]() {  // leaves this wave's two newest half-tiles (one A-half, one B-half) in flight
+    if constexpr (A_HALF_PIECES % NW == 0) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      if (wave < A_HALF_PIECES % NW) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+  };
+  auto issue_kt0 = [&]() {   // the whole first K-tile of the tile just set up -> buffer 0
+    if constexpr (DEEP) { dma_ah(0, 0, 0); dma_wh(0, 0, 0); dma_ah(0, 0, 1); dma_wh(0, 0, 1); }
+    else { dma_a(0, 0, 0); dma_a(0, 0, 2); dma_w(0, 0, 0); dma_w(0, 0, 2); }
+  };
+  auto issue_kt1 = [&]() {   // what the main loop expects in flight for K-tile 1 at its head -> buffer 1
+    if (nk > 1) {
+      if constexpr (DEEP) { dma_ah(1, 1, 0); dma_wh(1, 1, 1); }
+      else { dma_a(1, 1, 0); dma_a(1, 1, 2); dma_w(1, 1, 0); dma_w(1, 1, 2); }
+    }
+  };
+
+  f32x4 acc[2 * AFR][4];
+  u32x4 ar[AFR][2], br[2][2];  // current A-half (AFR row fragments x 2 k-steps), B-half (2 col fragments x 2 k-steps)
+  auto read_a = [&](int buf, int half) {
+    const char* sa = smem + buf * STAGE + (DEEP ? half * (TBM / 2) + wr * (16 * AFR) : wr * (TBM / 2) + half * (16 * AFR)) * BK_BYTES;
+#pragma unroll
+    for (int i = 0; i < AFR; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) ar[i][kk] = *reinterpret_cast<const u32x4*>(sa + swz(i * 16 + fr, kk * 4 + fq));
+  };
+  auto read_b = [&](int buf, int half) {
+    const char* sw = smem + buf * STAGE + (TBM + (DEEP ? half * 128 + wc * 32 : wc * 64 + half * 32)) * BK_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) br[i][kk] = *reinterpret_cast<const u32x4*>(sw + swz(i * 16 + fr, kk * 4 + fq));
+  };
+#define PS_MFMA(AH, BH)                                                                                              \
+  do {                                                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int i = 0; i < AFR; ++i)                 \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+      if constexpr (std::is_same<AB, f16>::value)                                                                    \
+        acc[(AH)*AFR + i][(BH)*2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                        \
+            __builtin_bit_cast(f16x8, br[j][kk]), __builtin_bit_cast(f16x8, ar[i][kk]), acc[(AH)*AFR + i][(BH)*2 + j], 0, 0, 0); \
+      else                                                                                                           \
+        acc[(AH)*AFR + i][(BH)*2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                       \
+            __builtin_bit_cast(bf16x8_t, br[j][kk]), __builtin_bit_cast(bf16x8_t, ar[i][kk]), acc[(AH)*AFR + i][(BH)*2 + j], 0, 0, 0); \
+    }                                                                                                                \
+    __builtin_amdgcn_s_setprio(0);                                                                                   \
+  } while (0)
+
+  // ---- epilogue geometry (as grouped_gemm_pp256; the staging region is buffer 1 + the LDS behind the buffers) -----------
+  constexpr int TM = TBM / 2, TN = 64, MI = 2 * AFR, NI = 4;
+  constexpr int OB = OutPack<OT>::bytes;
+  constexpr int C_STRIDE = TBN * OB + C_PAD;
+  constexpr int BIAS_BYTES = 2048;        // two 1-KiB bias tiles (256 f32) at the top of the LDS, alternating per tile
+  constexpr int EPI_BYTES = LDS_TOTAL - STAGE - BIAS_BYTES;
+  constexpr int NPASS = (TBM * C_STRIDE <= EPI_BYTES) ? 1 : ((TBM / 2) * C_STRIDE <= EPI_BYTES ? 2 : (AFR == 4 ? 4 : 5));
+  constexpr int RP = TBM / NPASS;
+  static_assert(RP * C_STRIDE <= EPI_BYTES, "epilogue pass does not fit behind buffer 0");
+  constexpr int CHUNKS = TBN * OB / 16;   // 16-B chunks per tile row
+  constexpr int TPR = 16;                 // threads per output row: 16 consecutive threads = 256 contiguous bytes
+  constexpr int CPT = CHUNKS / TPR;       // chunks per thread per row (strided by 256 B)
+  constexpr int ROWS_PER_IT = NT / TPR;   // 32
+  constexpr int ITS = RP / ROWS_PER_IT;
+  static_assert(CHUNKS % TPR == 0 && RP % ROWS_PER_IT == 0, "epilogue thread map");
+  constexpr int HALF = RP / 2;
+  constexpr int MPP = HALF / 16;
+  static_assert(HALF % 16 == 0 && MPP * NPASS == MI, "epilogue pass split");
+  char* const cst = smem + STAGE;         // output staging
+  const int trow = tid / TPR, tcol = tid % TPR;
+  // The tile's bias row reaches the epilogue through LDS by DMA (one 1-KiB piece, wave 0), issued with the tile's first
+  // operand pieces: an ordinary load in the epilogue would make hipcc drain the whole vector-memory queue -- the next
+  // tile's operand DMAs included -- at its first use (cdna_hip_programming.md section 5, "Pipelining across barriers").
+  char* const bias_lds = smem + LDS_TOTAL - BIAS_BYTES;
+  int bias_par = 0;
+  auto issue_bias = [&](int par) {
+    if (bias && wave == 0) {
+      int col = n0 + lane * 4;
+      if (col > N - 4) col = N - 4;       // columns past N are never stored
+      PS_DMA(bias + (int64_t)e * N + col, bias_lds + par * 1024);
+    }
+  };
+
+  if (!advance()) return;
+  setup();
+  // ---- prologue of this workgroup's first tile ------------------------------------------------------------------------
+  issue_bias(0);
+  issue_kt0();
+  if (nk > 1) {
+    issue_kt1();
+    if constexpr (DEEP) wait_keep2();
+    else if constexpr (AFR == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 1's pieces may stay in flight
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  PP_BARRIER();
+
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < 2 * AFR; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wr == 1) PP_BARRIER();  // stagger: group 1 runs one interval behind group 0
+    if constexpr (DEEP) {
+      // Invariant at the head of tile t: tile t is in LDS; A-half 0 and B-half 1 of tile t+1 are in flight.
+      for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const bool n1 = (t + 1 < nk), n2 = (t + 2 < nk);
+        read_b(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(cur, 0);
+        if (n1) dma_ah(t + 1, nxt, 1);
+        PP_BARRIER();
+        PS_MFMA(0, 0);
+        PP_BARRIER();
+        read_b(cur, 1);
+        if (n1) dma_wh(t + 1, nxt, 0);
+        PP_BARRIER();
+        PS_MFMA(0, 1);
+        PP_BARRIER();
+        read_a(cur, 1);
+        if (n2) dma_ah(t + 2, cur, 0);
+        PP_BARRIER();
+        PS_MFMA(1, 1);
+        PP_BARRIER();
+        read_b(cur, 0);
+        if (n2) dma_wh(t + 2, cur, 1);
+        if (wr == 1) {  // group 1: its program interval 6 is global interval 8t+7, the last one of tile t
+          if (n2) wait_keep2();
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BARRIER();
+        PS_MFMA(1, 0);
+        if (wr == 0) {  // group 0: program interval 7 = global 8t+7
+          if (n2) wait_keep2();
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BARRIER();
+      }
+    } else {
+      // R1(t): A rows 128.. of tile t+1   R2(t): W rows 0-127 of t+1   R3(t): W rows 128-255 of t+1
+      // R4(t): A rows 0-127 of tile t+2 (that region of tile t's buffer was last read in R3(t))
+      for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const bool pre1 = (t >= 1) && (t + 1 < nk);
+        const bool pre2 = (t + 2 < nk);
+        read_b(cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(cur, 0);
+        if (pre1) dma_a(t + 1, nxt, 2);
+        PP_BARRIER();
+        PS_MFMA(0, 0);
+        PP_BARRIER();
+        read_b(cur, 1);
+        if (pre1) dma_w(t + 1, nxt, 0);
+        PP_BARRIER();
+        PS_MFMA(0, 1);
+        PP_BARRIER();
+        read_a(cur, 1);
+        if (pre1) dma_w(t + 1, nxt, 2);
+        PP_BARRIER();
+        PS_MFMA(1, 1);
+        PP_BARRIER();
+        read_b(cur, 0);
+        if (pre2) dma_a(t + 2, cur, 0);
+        if (wr == 1) {
+          if (pre2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BARRIER();
+        PS_MFMA(1, 0);
+        if (wr == 0) {
+          if (pre2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_BARRIER();
+      }
+    }
+    if (wr == 0) PP_BARRIER();  // equalise barrier counts; after it every wave is done with the operand buffers
+
+    // ---- the tile just computed, and the next one ----------------------------------------------------------------------
+    const int ce = e, cm0 = m0, cm_end = m_end, cn0 = n0;
+    tile += G;
+    const bool more = advance();
+    if (more) {
+      setup();        // gather-address loads + pointer arithmetic of the next tile
+      issue_bias(bias_par ^ 1);
+      issue_kt0();    // its first K-tile streams into buffer 0 under the epilogue below
+    }
+
+    // ---- epilogue of (ce, cm0, cm_end, cn0) in row passes through LDS ------------------------------------------------
+    (void)ce;
+    f32x4 bv[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int nl = wc * TN + ni * 16 + fq * 4;
+      bv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (bias) bv[ni] = *reinterpret_cast<const f32x4*>(bias_lds + bias_par * 1024 + nl * 4);
+    }
+    bias_par ^= 1;
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      // (1) resolve this pass's output rows and start the residual loads: their latency hides under (2)
+      int64_t orow[ITS];
+      float oscale[ITS];
+      u32x4 resv[ITS][CPT];
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        const int r = trow + it * ROWS_PER_IT;
+        const int m = cm0 + (r / HALF) * TM + p * HALF + (r % HALF);
+        orow[it] = -1;
+        oscale[it] = 1.f;
+        if (m < cm_end) {
+          orow[it] = row_map ? row_map[m] : (int64_t)m;
+          if (row_map && row_scale) oscale[it] = row_scale[orow[it]];
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          resv[it][j] = u32x4{0u, 0u, 0u, 0u};
+          const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
+          if (residual && orow[it] >= 0 && ncol < N)
+            resv[it][j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) +
+                                                          (orow[it] * (int64_t)N + ncol) * OB);
+        }
+      }
+      // (2) bias (+GELU), convert, stage this pass's fragments in LDS
+#pragma unroll
+      for (int mm = 0; mm < MPP; ++mm) {
+        const int mi = p * MPP + mm;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          f32x4 v = acc[mi][ni] + bv[ni];
+          if (epilogue == SMOE_EPI_GELU) v = gelu_fast4(v);
+          const int nl = wc * TN + ni * 16 + fq * 4;
+          OutPack<OT>::write4(cst + (wr * HALF + mm * 16 + fr) * C_STRIDE + nl * OB, v);
+        }
+      }
+      // LDS ordering only (no vector-memory drain): every wave's staging writes done, then the barrier.  On the last
+      // pass each wave also retires its own outstanding vector-memory operations -- the next tile's K-tile 0 (issued
+      // before pass 0) and the earlier passes' stores -- so that after this barrier buffer 0 is valid for everybody.
+      if (p == NPASS - 1 && more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      // (3) whole-row-segment stores (combine scale and residual / gelu' fused)
+#pragma unroll
+      for (int it = 0; it < ITS; ++it) {
+        if (orow[it] >= 0) {
+          const int r = trow + it * ROWS_PER_IT;
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) {
+            const int ch = tcol + j * TPR;
+            const int ncol = cn0 + ch * (16 / OB);
+            if (ncol < N) {
+              u32x4 v = *reinterpret_cast<const u32x4*>(cst + r * C_STRIDE + ch * 16);
+              if (row_map && row_scale) v = scale16<OT>(v, oscale[it]);
+              if (residual) v = fuse_aux<OT>(epilogue, resv[it][j], v);
+              *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow[it] * (int64_t)N + ncol) * OB) = v;
+            }
+          }
+        }
+      }
+      // the staging reads above are complete when their stores have issued; the next pass (or the next tile's K-tile 1)
+      // may overwrite the region once every wave is here
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_BARRIER();
+    }
+    if (!more) break;
+    issue_kt1();   // into buffer 1 = the staging region just released; lands during the first K-tile's 8 intervals
+  }
+#undef PS_MFMA
+#undef PS_DMA
+}
+
+template <typename AB, typename OT, int AFR, bool DEEP>
+int launch_ps(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert, int E,
+              int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
+              const void* residual, void* out, int group_m, hipStream_t s, const int64_t* a_gather, int a_div) {
+  constexpr int TBM = 64 * AFR, TBN = 256;
+  const int n_tiles_n = (N + TBN - 1) / TBN;
+  const int64_t max_tiles = ((m_rows_max + TBM - 1) / TBM + E) * n_tiles_n;
+  int grid = smoe_num_cus() & ~7;                 // one workgroup per CU (the LDS is full); a multiple of 8 (XCD slots)
+  if (grid < 8) grid = 8;
+  if (max_tiles < grid) grid = (int)((max_tiles + 7) & ~(int64_t)7);
+  SMOE_ENSURE_SMEM(grouped_gemm_ps<AB, OT, AFR, DEEP>);
+  hipLaunchKernelGGL((grouped_gemm_ps<AB, OT, AFR, DEEP>), dim3(grid), dim3(512), 160 * 1024, s, (const AB*)A, (const AB*)W,
+                     bias, offsets, group_expert, E, K, N, epilogue, row_map, row_scale, (const OT*)residual, (OT*)out,
+                     n_tiles_n, group_m, a_gather, a_div);
+  SMOE_CHECK_LAUNCH("smoe_grouped_gemm/persistent");
+  return 0;
+}

@@ -47,9 +47,9 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
 }
 // round-to-nearest-even; NaN stays NaN (plain cast path, see MI355X_MICROARCH 'Correctness boundaries')
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  const unsigned int u = __float_as_uint(f);
+  const unsigned int quiet = (u >> 16) | 0x40u, rounded = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  return (unsigned short)(((u & 0x7fffffffu) > 0x7f800000u) ? quiet : rounded);  // a select, not a branch
 }
 
 // dtype tags

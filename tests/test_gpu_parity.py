@@ -181,7 +181,7 @@ def _gemm_ref(A, W, bias, offsets, gelu):
                                         ([700, 650, 600, 800, 655, 690, 710, 640], 768, 3072)])
 @pytest.mark.parametrize("cd,tol", [(torch.float32, 2e-5), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("gelu", [False, True])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu, variant):
     if variant and (cd == torch.float32 or K % 64):
         pytest.skip("glds variants take 16-bit operands and K % 64 == 0")
@@ -202,7 +202,7 @@ def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu, varian
     assert torch.all(got[M:] == 7.0), "rows past the last expert must stay untouched"
 
 
-@pytest.mark.parametrize("variant", [0, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 3, 5, 6, 7, 8, 10, 12])
 def test_grouped_gemm_gelu_epilogue_over_the_whole_input_range(variant):
     """The fused GELU (a fitted sigmoid form without a range clamp in the MFMA kernels, erf form in variant 0) must
     follow the exact-erf GELU from the saturated negative side to the saturated positive side: pre-activations
@@ -229,7 +229,8 @@ def test_grouped_gemm_gelu_epilogue_over_the_whole_input_range(variant):
 @pytest.mark.parametrize("variant,cd", [(0, torch.float32), (0, torch.float16), (1, torch.float16), (3, torch.float16),
                                         (3, torch.bfloat16), (4, torch.float16), (4, torch.bfloat16), (5, torch.float16),
                                         (5, torch.bfloat16), (6, torch.float16), (7, torch.float16), (8, torch.float16),
-                                        (8, torch.bfloat16)])
+                                        (8, torch.bfloat16), (9, torch.float16), (10, torch.float16), (10, torch.bfloat16),
+                                        (11, torch.float16), (12, torch.float16), (13, torch.float16), (13, torch.bfloat16)])
 def test_grouped_gemm_fused_combine_row_map(variant, cd):
     E, K, N, T = 4, 128, 64, 1000
     g = _gen(3)
@@ -251,7 +252,7 @@ def test_grouped_gemm_fused_combine_row_map(variant, cd):
     assert (out.cpu().double() - ref).abs().max() < (2e-5 if cd == torch.float32 else 1e-4)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6, 9, 10, 11, 12, 13])
 def test_grouped_gemm_variants_are_race_free_and_agree_bitwise(variant):
     """The staged variants hand tiles between waves through LDS DMA + barriers; a missing wait shows up as
     rare wrong tiles.  Same inputs, 15 launches, ragged groups, long K: every launch must be bit-identical
@@ -695,3 +696,40 @@ def test_expert_parallel_data_path_simulated_ranks(W_ranks, E_local, k):
         got = ops.gather_combine(back, plans[r][3], scores[r], T, k, torch.float32).cpu()
         ref = mo.moe_forward(xs[r], wg, bg, w1, b1, w2, b2, k).out
         _float_bar(got, ref, 1e-3)
+
+
+@pytest.mark.parametrize("variant", [9, 10, 11, 12, 13])
+def test_persistent_gemm_equals_one_workgroup_per_tile_kernel_bitwise(variant):
+    """grouped_gemm_ps (one workgroup per CU walking tiles, the next tile's operands streaming under the epilogue) must
+    reproduce grouped_gemm_pp256 bit for bit in every fused form it is used in: gathered A rows + bias + GELU (GEMM-1),
+    row-mapped scaled store + in-place residual (GEMM-2), many more tiles than CUs, ragged / empty groups, N tails."""
+    counts = [5000, 0, 333, 7001, 64, 2900, 1, 4100]
+    E, d, h = len(counts), 256, 1096                       # h: n-tile tail (1096 = 4 * 256 + 72)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device=DEV)
+    M = int(offsets[-1])
+    g = _gen(variant)
+    x16 = torch.randn(M, d, generator=g).half().to(DEV)
+    pos = torch.randperm(M, generator=g).to(DEV)           # a_gather: any permutation of the rows
+    w1 = (torch.randn(E, h, d, generator=g) * 0.05).half().to(DEV)
+    b1 = (torch.randn(E, h, generator=g) * 0.1).to(DEV)
+    w2 = (torch.randn(E, d, h + 56, generator=g) * 0.05).half().to(DEV)[:, :, :h].contiguous()
+    b2 = (torch.randn(E, d, generator=g) * 0.1).to(DEV)
+    score = torch.rand(M, generator=g).to(DEV)
+    res = torch.randn(M, d, generator=g).to(DEV)
+    base = {9: 4, 10: 5, 11: 6, 12: 7, 13: 8}[variant]     # the same tile height / schedule, one workgroup per tile
+    if h % 64:
+        pytest.skip("K of GEMM-2 must be a multiple of 64")
+    for _ in range(3):
+        h_ref = ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_GELU, torch.float16, variant=base, a_gather=pos)
+        h_ps = ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_GELU, torch.float16, variant=variant, a_gather=pos)
+        assert torch.equal(h_ps, h_ref)
+    hk = h_ref[:, :1088].contiguous()                      # K = 1088 = 17 * 64
+    w2k = w2[:, :, :1088].contiguous()
+    for _ in range(3):
+        o_ref = res.clone()
+        ops.grouped_gemm(hk, w2k, b2, offsets, ops.EPI_NONE, torch.float32, row_map=pos, row_scale=score, out=o_ref,
+                         variant=base, residual=o_ref)
+        o_ps = res.clone()
+        ops.grouped_gemm(hk, w2k, b2, offsets, ops.EPI_NONE, torch.float32, row_map=pos, row_scale=score, out=o_ps,
+                         variant=variant, residual=o_ps)
+        assert torch.equal(o_ps, o_ref)
