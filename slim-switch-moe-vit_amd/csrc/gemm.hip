@@ -212,7 +212,7 @@ template <typename AB, typename OT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void grouped_gemm_t128(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
-    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* __restrict__ residual, OT* __restrict__ out, int n_tiles_n,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* residual, OT* out, int n_tiles_n,
     int group_m) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(AB);
@@ -401,7 +401,7 @@ template <typename AB, typename OT, int TBM, int TBN, int WM, int WN, int MINW>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void grouped_gemm_glds(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
-    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* __restrict__ residual, OT* __restrict__ out, int n_tiles_n,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* residual, OT* out, int n_tiles_n,
     int group_m) {
   static_assert(sizeof(AB) == 2, "glds variants take 16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -616,7 +616,7 @@ template <typename AB, typename OT, int ABL = 0, int MODE = 0, int AFR = 4>
 __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
-    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* __restrict__ residual, OT* __restrict__ out, int n_tiles_n,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* residual, OT* out, int n_tiles_n,
     int group_m, int m_rows, const int64_t* __restrict__ a_gather, int a_div) {
   static_assert(sizeof(AB) == 2, "16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -120,13 +120,54 @@ class SwitchGate(NaiveGate):
 
 
 class _Expert(nn.Module):
-    """fmoe.transformer._Expert: htoh4 -> activation -> h4toh over expert-sorted rows."""
+    """fmoe.transformer._Expert: htoh4 -> activation -> h4toh over expert-sorted rows.
+
+    State-dict layouts accepted on load (main.py:703-724 resume / 893-907 save):
+      * ``experts.htoh4.weight [E,h,d]`` ... -- one module holding all local experts (FastMoE < 1.1; what this class saves);
+      * ``experts.{e}.htoh4.weight [1,h,d]`` ... -- FastMoE >= 1.1's ``ModuleList`` of single-expert modules: stacked
+        along dim 0 here, in expert order (``fastmoe_v11_state_dict`` writes that layout back)."""
+
+    _PARTS = ("htoh4.weight", "htoh4.bias", "h4toh.weight", "h4toh.bias")
 
     def __init__(self, num_expert: int, d_model: int, d_hidden: int, activation, rank: int = 0):
         super().__init__()
         self.htoh4 = FMoELinear(num_expert, d_model, d_hidden, bias=True, rank=rank)
         self.h4toh = FMoELinear(num_expert, d_hidden, d_model, bias=True, rank=rank)
         self.activation = activation
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        E = self.htoh4.num_expert
+        if prefix + "0.htoh4.weight" in state_dict:
+            for part in self._PARTS:
+                keys = [f"{prefix}{e}.{part}" for e in range(E)]
+                have = [k for k in keys if k in state_dict]
+                if not have:
+                    continue
+                if len(have) != E or f"{prefix}{E}.{part}" in state_dict:
+                    error_msgs.append(f"{prefix}: per-expert layout holds {len(have)} (+?) entries of {part}, this module "
+                                      f"has {E} local experts")
+                    continue
+                pieces = [state_dict.pop(k) for k in keys]
+                if any(t.shape[0] != 1 for t in pieces):
+                    error_msgs.append(f"{prefix}*.{part}: expected a leading dimension of 1 per expert")
+                    continue
+                state_dict[prefix + part] = torch.cat(pieces, dim=0)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+
+def fastmoe_v11_state_dict(state_dict: dict) -> dict:
+    """A copy of ``state_dict`` with every ``...experts.{htoh4,h4toh}.{weight,bias}`` [E, ...] entry split into FastMoE
+    >= 1.1's ``...experts.{e}.{...}`` [1, ...] entries (what a checkpoint written by that version holds)."""
+    out = {}
+    for k, v in state_dict.items():
+        hit = next((p for p in _Expert._PARTS if k.endswith("experts." + p)), None)
+        if hit is None:
+            out[k] = v
+            continue
+        stem = k[: -len(hit)]
+        for e in range(v.shape[0]):
+            out[f"{stem}{e}.{hit}"] = v[e:e + 1].clone()
+    return out
 
 
 def _parse_activation(act):
@@ -182,6 +223,18 @@ class FMoETransformerMLP(nn.Module):
         self.ep_chunks = 1  # micro-batches of the expert-parallel pipeline (ep.py); > 1 overlaps a2a with GEMMs
         self._fused_gelu, self._drop_p, self._generic_act = _parse_activation(activation)
         self.last_plan = None  # (idx, score, counts, offsets, pos, inv_pos) of the latest forward, for inspection
+        self.mark_parallel_comm()
+
+    # -- data-parallel bookkeeping (fmoe.layers.FMoE.mark_parallel_comm) -----------------------------------------------
+    def mark_parallel_comm(self, expert_dp_comm: Optional[str] = None):
+        """Tag every parameter with the group its gradient is reduced over, as FastMoE does: the router (replicated on
+        all ranks) ``"dp"`` under expert parallelism (``"gate"`` upstream when a separate gate group exists), the
+        experts ``expert_dp_comm`` (``"none"``: rank-private, never all-reduced)."""
+        comm = expert_dp_comm or self.expert_dp_comm
+        for p in self.experts.parameters():
+            p.dp_comm = comm
+        for p in self.gate.parameters():
+            p.dp_comm = "dp" if self.world_size > 1 else "none"
 
     # -- hot path ------------------------------------------------------------------------------------
     def forward_add(self, inp: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
@@ -405,3 +458,22 @@ class FMoETransformerMLP(nn.Module):
             y = self._experts_fwd(buf, offsets, cd, out_dtype=cd)
             out = ops.gather_combine(y, inv_pos, score, T, k, inp.dtype, residual=res)
         return out.reshape(shape)
+
+
+def ddp_ignore_expert_parameters(model: nn.Module) -> list:
+    """Call BEFORE wrapping ``model`` in ``torch.nn.parallel.DistributedDataParallel`` (the reference wraps the whole
+    model, main.py:611).  Under expert parallelism every rank holds DIFFERENT experts behind the same parameter names:
+    plain DDP would broadcast rank 0's expert slices over everybody's at construction and then average the gradients of
+    unrelated experts.  This registers every parameter tagged ``dp_comm == "none"`` on an expert-parallel MoE module
+    (``world_size > 1``) in ``model._ddp_params_and_buffers_to_ignore`` -- DDP then neither broadcasts nor reduces them --
+    and returns the names.  (FastMoE ships its own ``DistributedGroupedDataParallel`` for the same purpose.)"""
+    names = []
+    for mod_name, mod in model.named_modules():
+        if isinstance(mod, FMoETransformerMLP) and mod.world_size > 1:
+            for p_name, p in mod.named_parameters():
+                if getattr(p, "dp_comm", None) == "none":
+                    names.append(f"{mod_name}.{p_name}" if mod_name else p_name)
+    if names:
+        have = list(getattr(model, "_ddp_params_and_buffers_to_ignore", []))
+        model._ddp_params_and_buffers_to_ignore = have + [n for n in names if n not in have]
+    return names

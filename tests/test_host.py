@@ -117,3 +117,53 @@ def test_dense_shell_runs_on_cpu():
     with torch.no_grad():
         y = m(torch.randn(1, 3, 224, 224))
     assert y.shape == (1, 10)
+
+
+def test_checkpoint_round_trip_in_both_fastmoe_layouts(tmp_path):
+    """main.py:893-907 saves ``model.state_dict()``, main.py:703-724 loads it back: a reference-layout checkpoint
+    (FastMoE < 1.1 keys ``experts.htoh4.weight [E,h,d]``) and FastMoE >= 1.1's per-expert layout
+    (``experts.{e}.htoh4.weight [1,h,d]``) must both load into the modules here and give back the same tensors."""
+    torch.manual_seed(0)
+    a = sm.create_model("resmoe_tiny_patch16_224_expert8", num_classes=7, depth=2)
+    sd = a.state_dict()
+    assert "blocks.0.mlp.experts.htoh4.weight" in sd and "blocks.1.moe_gate.head.1.weight" in sd
+    path = tmp_path / "ckpt.pth"
+    torch.save({"model": sd, "epoch": 3}, path)
+    ck = torch.load(path, map_location="cpu")
+    torch.manual_seed(1)
+    b = sm.create_model("resmoe_tiny_patch16_224_expert8", num_classes=7, depth=2)
+    b.load_state_dict(ck["model"])                                   # strict
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
+    v11 = sm.fastmoe_v11_state_dict(sd)
+    assert "blocks.0.mlp.experts.3.h4toh.bias" in v11 and "blocks.0.mlp.experts.htoh4.weight" not in v11
+    assert tuple(v11["blocks.0.mlp.experts.3.htoh4.weight"].shape) == (1, 768, 192)
+    torch.manual_seed(2)
+    c = sm.create_model("resmoe_tiny_patch16_224_expert8", num_classes=7, depth=2)
+    c.load_state_dict(v11)                                           # strict: nothing missing, nothing unexpected
+    for (ka, va), (kc, vc) in zip(a.state_dict().items(), c.state_dict().items()):
+        assert ka == kc and torch.equal(va, vc), ka
+    # a per-expert checkpoint with the wrong number of experts is an error, not a silent truncation
+    bad = {k: v for k, v in v11.items() if ".experts.7." not in k}
+    with pytest.raises(RuntimeError):
+        c.load_state_dict(bad)
+    # an in-place load refreshes the 16-bit weight shadows (they are keyed on tensor versions, which .data updates skip)
+    lin = c.blocks[0].mlp.experts.htoh4
+    lin._shadow._c[("probe", None)] = (0, torch.zeros(1), None, None)
+    c.load_state_dict(v11)
+    assert ("probe", None) not in lin._shadow._c
+
+
+def test_expert_parameters_are_tagged_and_kept_out_of_ddp():
+    """under expert parallelism plain DDP would broadcast / average DIFFERENT experts.  Parameters carry
+    FastMoE's dp_comm tags and ddp_ignore_expert_parameters registers the rank-private ones with DDP's ignore list."""
+    m = sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=5, depth=2, world_size=2)
+    mlp = m.blocks[0].mlp
+    assert all(p.dp_comm == "none" for p in mlp.experts.parameters())
+    assert all(p.dp_comm == "dp" for p in mlp.gate.parameters())
+    names = sm.ddp_ignore_expert_parameters(m)
+    assert "blocks.0.mlp.experts.htoh4.weight" in names and "blocks.1.mlp.experts.h4toh.bias" in names
+    assert not any("gate" in n for n in names)
+    assert set(names) <= set(m._ddp_params_and_buffers_to_ignore)
+    single = sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=5, depth=1)
+    assert sm.ddp_ignore_expert_parameters(single) == []            # single rank: ordinary data parallelism is right
