@@ -42,8 +42,8 @@ def parse():
                     help="expert parallel only: micro-batches of the local batch interleaved through the model so that "
                          "count read-backs and all-to-alls of one run under the other's compute (1 = off; 0 = time "
                          "1, 2 and 3 during warm-up and keep the fastest -- the right depth depends on the link rate)")
-    ap.add_argument("--cpu-batch", type=int, default=16, help="images in the CPU-oracle sample")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-batch", type=int, default=128, help="images in the CPU-oracle sample")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU budget: 5 timed forwards if they fit ~2x this, else 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=4)
     ap.add_argument("--force-ep", action="store_true",
@@ -90,8 +90,9 @@ def build_model(args, world, rank, device):
 
 
 def cpu_baseline(sd, images, seconds):
-    """The CPU oracle (oracle/moe_oracle.py: 'port' of the path, fp32 torch on the host cores) on a bounded
-    sample of the same workload."""
+    """The CPU oracle (oracle/moe_oracle.py: 'port' of the path, fp32 torch on ALL host cores torch sees) on a bounded
+    sample of the same workload: one warm-up forward, then >= 5 timed forwards of the same batch (3 if a forward takes
+    longer than `seconds` / 5); the reported rate is batch / median forward time."""
     from oracle import moe_oracle as mo
 
     n = images.shape[0]
@@ -99,13 +100,16 @@ def cpu_baseline(sd, images, seconds):
         t0 = time.perf_counter()
         logits = mo.vit_forward(images, sd, depth=12, num_heads=12, k=1, residual_moe=False)
         first = time.perf_counter() - t0
-        iters, t_acc = 0, 0.0
-        while t_acc < seconds and iters < 50:
+        iters = 5 if first * 5 <= 2.0 * seconds else 3
+        times = []
+        for _ in range(iters):
             t0 = time.perf_counter()
             mo.vit_forward(images, sd, depth=12, num_heads=12, k=1, residual_moe=False)
-            t_acc += time.perf_counter() - t0
-            iters += 1
-    return n * iters / t_acc, logits, {"iters": iters, "first_call_s": round(first, 3)}
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return n / med, logits, {"iters": iters, "first_call_s": round(first, 3), "median_s": round(med, 3),
+                             "min_s": round(times[0], 3), "max_s": round(times[-1], 3)}
 
 
 def hot_path_parity(model, sd_cpu, device):
@@ -204,12 +208,16 @@ def main():
     # ~110 other launches of a step cost ~0.5 ms per step).  The other kernels' table comes from a few extra,
     # untimed steps below.
     ops.profile_begin({"grouped_gemm"})
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times (median reported)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
     prof = ops.profile_end()
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     side_steps = 0
     if world == 1 and not args.force_ep:
         side_steps = max(1, min(5, args.steps))
@@ -313,6 +321,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step_median": round(step_ms[len(step_ms) // 2], 3),
+            "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -336,8 +346,10 @@ def main():
             ips, cpu_logits, info = cpu_baseline(sd_cpu, images_cpu[: args.cpu_batch], args.cpu_seconds)
             out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": torch.get_num_threads(),
                                    "kind": "port",
-                                   "sample": f"oracle vit_forward (fp32 torch CPU), same model, batch {args.cpu_batch}, "
-                                             f"{info['iters']} iterations"}
+                                   "sample": f"oracle vit_forward (fp32 torch CPU, torch.get_num_threads() = "
+                                             f"{torch.get_num_threads()} of os.cpu_count() = {os.cpu_count()}), same model, "
+                                             f"batch {args.cpu_batch}, median of {info['iters']} forwards "
+                                             f"({info['median_s']} s; min {info['min_s']}, max {info['max_s']})"}
             out["speedup_vs_cpu"] = round(out["value"] / ips, 1)
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                 gl = model(images[: args.cpu_batch]).float().cpu()
