@@ -207,6 +207,29 @@ size_t smoe_group_colsum_workspace_bytes(int64_t n_rows_max, int E, int C);
 int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int64_t n_rows_max, int C, float* out,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- optimizer side of the training step (engine.py:68-74: timm NativeScaler around torch.optim.AdamW; SURVEY.md 8f
+ * rank 3).  Everything stays on the device -- loss scale, non-finite flag, clip coefficient, step count -- so a step has
+ * no host sync, and a gradient is read twice in all (norm pass, update pass) instead of four times.
+ * smoe_grad_sumsq : partial[b] = sum over block b (smoe_grad_sumsq_blocks(n) blocks of 16384 elements) of
+ *                   (g * *inv_scale)^2, deterministic; *found_inf = 1 when any scaled-back element is inf / nan
+ *                   (GradScaler.unscale_'s check; the caller zeroes found_inf once per step); inv_scale may be NULL (= 1)
+ * smoe_adamw_step : torch.optim.AdamW arithmetic on f32 p / m / v with the gradient g (f32 / f16 / bf16) multiplied by
+ *                   *grad_mult (NULL = 1: e.g. inv_scale x clip coefficient): p *= 1 - lr wd; m = lerp(m, g, 1 - b1);
+ *                   v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t = *step
+ *                   (device f32, already advanced); the whole update is skipped when *found_inf != 0 (found_inf may be NULL)
+ * smoe_amp_update : GradScaler.update(): found_inf ? (scale *= backoff, tracker = 0)
+ *                                                 : (++tracker == interval ? (scale *= growth, tracker = 0) : -)
+ * smoe_step_advance: *step += 1 unless *found_inf != 0                                                                  */
+int64_t smoe_grad_sumsq_blocks(int64_t n);
+int smoe_grad_sumsq(const void* g, int g_dtype, int64_t n, const float* inv_scale, float* partial, float* found_inf,
+                    void* stream);
+int smoe_adamw_step(float* p, const void* g, int g_dtype, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, const float* step, const float* grad_mult, const float* found_inf,
+                    void* stream);
+int smoe_amp_update(float* scale, float* growth_tracker, const float* found_inf, float growth_factor, float backoff_factor,
+                    int growth_interval, void* stream);
+int smoe_step_advance(float* step, const float* found_inf, void* stream);
+
 /* ---- small helpers ------------------------------------------------------------------------------------
  * elementwise cast between dtypes (weight shadow copies; not on the per-step path)                  */
 int smoe_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);

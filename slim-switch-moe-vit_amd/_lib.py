@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: the library resolves libamd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -54,6 +54,12 @@ SIGNATURES = {
     "smoe_gate_ln_router": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "smoe_grad_sumsq_blocks": (c_int64, [c_int64]),
+    "smoe_grad_sumsq": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "smoe_adamw_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,
+                                ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "smoe_amp_update": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
+    "smoe_step_advance": (c_int, [c_void_p, c_void_p, c_void_p]),
     "smoe_zero_row_output": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 

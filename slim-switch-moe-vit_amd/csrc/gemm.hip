@@ -1329,6 +1329,12 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   if (K % 64 != 0 || smoe_dtype_size(ab_dtype) != 2) variant = 0;
   SMOE_REQUIRE(!a_gather || (variant >= 4 && variant <= 13 && a_div >= 1),
                "smoe_grouped_gemm: a_gather needs variant 4-13 (16-bit operands, K %% 64 == 0)");
+  if (variant >= 9 && variant <= 13) {
+    // the persistent kernel addresses both operands with 32-bit byte offsets; operands of 4 GiB and more take the
+    // one-workgroup-per-tile kernel of the same tile height / schedule (9 -> 4, 10 -> 5, 11 -> 6, 12 -> 7, 13 -> 8)
+    const uint64_t a_bytes = (uint64_t)m_rows_max * (uint64_t)K * 2u, w_bytes = (uint64_t)n_experts * (uint64_t)N * (uint64_t)K * 2u;
+    if (a_bytes >= (1ull << 32) || w_bytes >= (1ull << 32)) variant -= 5;
+  }
   hipStream_t s = (hipStream_t)stream;
   switch (ab_dtype) {
     case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div);

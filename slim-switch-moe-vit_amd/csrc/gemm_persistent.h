@@ -35,7 +35,6 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int l_row = lane >> 3, l_pos = lane & 7;
   const int fr = lane & 15, fq = lane >> 4;
   const int nk = K / 64;
 
@@ -63,9 +62,17 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   // ---- operand source pointers of the current (e, m0, m_end, n0) -----------------------------------------------------
   constexpr int A_HALF_PIECES = TBM / 16;                      // 8-row DMA pieces per A-half (16 / 20)
   constexpr int A_HS = (A_HALF_PIECES + NW - 1) / NW;          // pieces per wave per A-half, rounded up (2 / 3)
-  const AB* a_src[DEEP ? 2 * A_HS : ASLOTS];
-  const AB* w_src[SLOTS];
-  auto setup = [&]() {
+  // 32-bit BYTE offsets from A / W (the launcher guarantees both operands span < 4 GiB): half the registers of
+  // per-lane 64-bit pointers -- the 320-row tile has none to spare -- and the DMA takes (uniform base, 32-bit offset)
+  uint32_t a_src[DEEP ? 2 * A_HS : ASLOTS];
+  uint32_t w_src[SLOTS];
+  const char* const Ab = reinterpret_cast<const char*>(A);
+  const char* const Wb = reinterpret_cast<const char*>(W);
+  // `lo` = the lane id behind a per-call opaque zero: everything derived from it (per-slot swizzle constants, row
+  // numbers) is recomputed per tile instead of being hoisted out of the tile loop and kept in registers through the
+  // main loop, where there are none to spare
+  auto setup = [&](int lo) {
+    const int l_row = lo >> 3, l_pos = lo & 7;
     if constexpr (!DEEP) {
 #pragma unroll
       for (int s = 0; s < ASLOTS; ++s) {
@@ -73,14 +80,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
         int gr = m0 + r;
         if (gr >= m_end) gr = m_end - 1;
         const int64_t arow = a_gather ? a_gather[gr] / a_div : (int64_t)gr;   // fused MOEScatter
-        a_src[s] = A + arow * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+        a_src[s] = (uint32_t)((arow * K + ((l_pos ^ ((r >> 1) & 7)) << 3)) * 2);
       }
 #pragma unroll
       for (int s = 0; s < SLOTS; ++s) {
         const int r = 8 * (s * NW + wave) + l_row;
         int gw = n0 + r;
         if (gw >= N) gw = N - 1;
-        w_src[s] = W + ((int64_t)e * N + gw) * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+        w_src[s] = (uint32_t)((((int64_t)e * N + gw) * K + ((l_pos ^ ((r >> 1) & 7)) << 3)) * 2);
       }
     } else {
 #pragma unroll
@@ -94,14 +101,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
           int gr = m0 + trow;
           if (gr >= m_end) gr = m_end - 1;
           const int64_t arow = a_gather ? a_gather[gr] / a_div : (int64_t)gr;
-          a_src[h * A_HS + s2] = A + arow * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+          a_src[h * A_HS + s2] = (uint32_t)((arow * K + ((l_pos ^ ((r >> 1) & 7)) << 3)) * 2);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const int r = (wave + NW * s2) * 8 + l_row;            // row inside the half (0..127)
           int gw = n0 + (r / 32) * 64 + h * 32 + r % 32;
           if (gw >= N) gw = N - 1;
-          w_src[h * 2 + s2] = W + ((int64_t)e * N + gw) * K + ((l_pos ^ ((r >> 1) & 7)) << 3);
+          w_src[h * 2 + s2] = (uint32_t)((((int64_t)e * N + gw) * K + ((l_pos ^ ((r >> 1) & 7)) << 3)) * 2);
         }
       }
     }
@@ -114,16 +121,16 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     char* sa = smem + buf * STAGE;
     if (s0 == 0) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) PS_DMA(a_src[s] + kt * 64, sa + (s * NW + wave) * 1024);
+      for (int s = 0; s < 2; ++s) PS_DMA(Ab + (a_src[s] + (uint32_t)kt * 128u), sa + (s * NW + wave) * 1024);
     } else {
 #pragma unroll
-      for (int s = 2; s < ASLOTS; ++s) PS_DMA(a_src[s] + kt * 64, sa + (s * NW + wave) * 1024);
+      for (int s = 2; s < ASLOTS; ++s) PS_DMA(Ab + (a_src[s] + (uint32_t)kt * 128u), sa + (s * NW + wave) * 1024);
     }
   };
   auto dma_w = [&](int kt, int buf, int s0) {
     char* sw = smem + buf * STAGE + TBM * BK_BYTES;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) PS_DMA(w_src[s0 + s] + kt * 64, sw + ((s0 + s) * NW + wave) * 1024);
+    for (int s = 0; s < 2; ++s) PS_DMA(Wb + (w_src[s0 + s] + (uint32_t)kt * 128u), sw + ((s0 + s) * NW + wave) * 1024);
   };
   // DEEP half-tiles
   auto dma_ah = [&](int kt, int buf, int h) {
@@ -131,13 +138,13 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
 #pragma unroll
     for (int s2 = 0; s2 < A_HS; ++s2) {
       if (A_HALF_PIECES % NW == 0 || s2 + 1 < A_HS || wave < A_HALF_PIECES % NW)
-        PS_DMA(a_src[h * A_HS + s2] + kt * 64, sa + (wave + NW * s2) * 1024);
+        PS_DMA(Ab + (a_src[h * A_HS + s2] + (uint32_t)kt * 128u), sa + (wave + NW * s2) * 1024);
     }
   };
   auto dma_wh = [&](int kt, int buf, int h) {
     char* sw = smem + buf * STAGE + (TBM + h * 128) * BK_BYTES;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) PS_DMA(w_src[h * 2 + s2] + kt * 64, sw + (wave + NW * s2) * 1024);
+    for (int s2 = 0; s2 < 2; ++s2) PS_DMA(Wb + (w_src[h * 2 + s2] + (uint32_t)kt * 128u), sw + (wave + NW * s2) * 1024);
   };
   auto wait_keep2 = [&]() {  // leaves this wave's two newest half-tiles (one A-half, one B-half) in flight
     if constexpr (A_HALF_PIECES % NW == 0) {
@@ -208,7 +215,6 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   constexpr int MPP = HALF / 16;
   static_assert(HALF % 16 == 0 && MPP * NPASS == MI, "epilogue pass split");
   char* const cst = smem + STAGE;         // output staging
-  const int trow = tid / TPR, tcol = tid % TPR;
   // The tile's bias row reaches the epilogue through LDS by DMA (one 1-KiB piece, wave 0), issued with the tile's first
   // operand pieces: an ordinary load in the epilogue would make hipcc drain the whole vector-memory queue -- the next
   // tile's operand DMAs included -- at its first use (cdna_hip_programming.md section 5, "Pipelining across barriers").
@@ -223,7 +229,11 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   };
 
   if (!advance()) return;
-  setup();
+  {
+    int oz = 0;
+    asm volatile("" : "+v"(oz));
+    setup(lane + oz);
+  }
   // ---- prologue of this workgroup's first tile ------------------------------------------------------------------------
   issue_bias(0);
   issue_kt0();
@@ -324,14 +334,19 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     const int ce = e, cm0 = m0, cm_end = m_end, cn0 = n0;
     tile += G;
     const bool more = advance();
+    int oz = 0;
+    asm volatile("" : "+v"(oz));          // per-tile opaque zero (see setup)
+    const int tid_e = tid + oz, lane_e = tid_e & 63;
     if (more) {
-      setup();        // gather-address loads + pointer arithmetic of the next tile
+      setup(lane_e);  // gather-address loads + pointer arithmetic of the next tile
       issue_bias(bias_par ^ 1);
       issue_kt0();    // its first K-tile streams into buffer 0 under the epilogue below
     }
 
     // ---- epilogue of (ce, cm0, cm_end, cn0) in row passes through LDS ------------------------------------------------
     (void)ce;
+    const int fr = lane_e & 15, fq = lane_e >> 4;          // shadow the main loop's copies: epilogue-only address math
+    const int trow = tid_e / TPR, tcol = tid_e % TPR;
     f32x4 bv[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -342,10 +357,9 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     bias_par ^= 1;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      // (1) resolve this pass's output rows and start the residual loads: their latency hides under (2)
-      int64_t orow[ITS];
+      // (1) resolve this pass's output rows (32-bit: a row index, not an address) and their combine scales
+      int orow[ITS];
       float oscale[ITS];
-      u32x4 resv[ITS][CPT];
 #pragma unroll
       for (int it = 0; it < ITS; ++it) {
         const int r = trow + it * ROWS_PER_IT;
@@ -353,16 +367,8 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
         orow[it] = -1;
         oscale[it] = 1.f;
         if (m < cm_end) {
-          orow[it] = row_map ? row_map[m] : (int64_t)m;
+          orow[it] = row_map ? (int)row_map[m] : m;
           if (row_map && row_scale) oscale[it] = row_scale[orow[it]];
-        }
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-          resv[it][j] = u32x4{0u, 0u, 0u, 0u};
-          const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
-          if (residual && orow[it] >= 0 && ncol < N)
-            resv[it][j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) +
-                                                          (orow[it] * (int64_t)N + ncol) * OB);
         }
       }
       // (2) bias (+GELU), convert, stage this pass's fragments in LDS
@@ -383,11 +389,21 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       if (p == NPASS - 1 && more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       PP_BARRIER();
-      // (3) whole-row-segment stores (combine scale and residual / gelu' fused)
+      // (3) whole-row-segment stores (combine scale and residual / gelu' fused); a row's residual segments are fetched
+      //     right here, per row: holding a whole pass of them across (2) costs registers the 320-row tile does not have
 #pragma unroll
       for (int it = 0; it < ITS; ++it) {
         if (orow[it] >= 0) {
           const int r = trow + it * ROWS_PER_IT;
+          const int64_t rbase = (int64_t)orow[it] * N;
+          u32x4 resv[CPT];
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) {
+            const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
+            resv[j] = u32x4{0u, 0u, 0u, 0u};
+            if (residual && ncol < N)
+              resv[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + (rbase + ncol) * OB);
+          }
 #pragma unroll
           for (int j = 0; j < CPT; ++j) {
             const int ch = tcol + j * TPR;
@@ -395,8 +411,8 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
             if (ncol < N) {
               u32x4 v = *reinterpret_cast<const u32x4*>(cst + r * C_STRIDE + ch * 16);
               if (row_map && row_scale) v = scale16<OT>(v, oscale[it]);
-              if (residual) v = fuse_aux<OT>(epilogue, resv[it][j], v);
-              *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (orow[it] * (int64_t)N + ncol) * OB) = v;
+              if (residual) v = fuse_aux<OT>(epilogue, resv[j], v);
+              *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (rbase + ncol) * OB) = v;
             }
           }
         }

@@ -1,0 +1,225 @@
+"""Optimizer side of the reference's training step on the HIP path.
+
+The reference trains with ``timm.optim.create_optimizer_v2(..., opt="adamw")`` (main.py:729-731; ``--opt adamw``,
+``--opt-eps 1e-8``, ``--weight-decay 0.05``) = ``torch.optim.AdamW``, stepped through ``timm.utils.NativeScaler``
+(main.py:732, engine.py:68-74):
+
+    loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=is_second_order)
+
+i.e. ``scaler.scale(loss).backward(); scaler.unscale_(optimizer); clip_grad_norm_(parameters, clip_grad);
+scaler.step(optimizer); scaler.update()``.  The MoE's expert tensors are ``[E,h,d]`` / ``[E,d,h]`` f32 -- 150 MB per layer
+at ViT-B, E = 8 -- and every one of those calls is a full HBM pass (or two) over them and their gradients.  Here the
+same step is TWO passes: ``ops``-level kernels ``smoe_grad_sumsq`` (norm + non-finite check on the still-scaled
+gradient) and ``smoe_adamw_step`` (the update, reading the gradient times ``inv_scale x clip coefficient``), with the loss
+scale, the non-finite flag, the clip coefficient and the step count all living on the device: no host sync in the step.
+
+``AdamW`` and ``NativeScaler`` keep the call signatures, ``state_dict`` keys and numerics of what they replace; CPU
+tensors (and non-f32 parameters) fall back to the torch composition, which is also what the tests compare against.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+
+from . import _lib, ops
+
+
+def _hip_ok(p: torch.Tensor) -> bool:
+    return p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+
+
+class AdamW(torch.optim.Optimizer):
+    """``torch.optim.AdamW(params, lr, betas, eps, weight_decay)`` (no amsgrad / maximize) with a fused HIP step.
+
+    ``step(grad_mult=None, found_inf=None)``: optional device scalars (f32[1]) -- every gradient is multiplied by
+    ``grad_mult`` on the fly, and the whole step (including the step count) is skipped when ``found_inf`` is non-zero;
+    this is how ``NativeScaler`` drives it without unscaling gradients in memory or asking the host."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("AdamW: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._step_dev = {}   # device -> f32[1] number of updates applied so far (advanced on the device)
+
+    supports_device_scalars = True
+
+    def _step_counter(self, device) -> torch.Tensor:
+        t = self._step_dev.get(device)
+        if t is None:
+            t = self._step_dev[device] = torch.zeros(1, dtype=torch.float32, device=device)
+        return t
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_mult: Optional[torch.Tensor] = None, found_inf: Optional[torch.Tensor] = None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = None
+        advanced = set()
+        for group in self.param_groups:
+            lr, (b1, b2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["step"] = 0
+                g = p.grad
+                if _hip_ok(p) and g.is_cuda and g.is_contiguous() and g.dtype in ops._DT:
+                    if lib is None:
+                        lib = _lib.load()
+                    dev = p.device
+                    step_t = self._step_counter(dev)
+                    if dev not in advanced:   # one counter per device: every parameter of a step sees the same t
+                        _lib.check(lib.smoe_step_advance(step_t.data_ptr(), ops._ptr(found_inf), ops._stream(p)),
+                                   "smoe_step_advance")
+                        advanced.add(dev)
+                    rc = lib.smoe_adamw_step(p.data_ptr(), g.data_ptr(), ops.dtype_code(g.dtype), st["exp_avg"].data_ptr(),
+                                             st["exp_avg_sq"].data_ptr(), p.numel(), float(lr), float(b1), float(b2),
+                                             float(eps), float(wd), step_t.data_ptr(), ops._ptr(grad_mult),
+                                             ops._ptr(found_inf), ops._stream(p))
+                    _lib.check(rc, "smoe_adamw_step")
+                    st["step"] += 1   # host-side count of step() calls (the device counter skips non-finite steps)
+                else:                 # torch composition (CPU tensors, other dtypes): same arithmetic
+                    if found_inf is not None and float(found_inf) != 0.0:
+                        continue
+                    gg = g.float() * (float(grad_mult) if grad_mult is not None else 1.0)
+                    st["step"] += 1
+                    t = st["step"]
+                    p.mul_(1 - lr * wd)
+                    st["exp_avg"].lerp_(gg, 1 - b1)
+                    st["exp_avg_sq"].mul_(b2).addcmul_(gg, gg, value=1 - b2)
+                    denom = (st["exp_avg_sq"].sqrt() / (1 - b2 ** t) ** 0.5).add_(eps)
+                    p.addcdiv_(st["exp_avg"], denom, value=-lr / (1 - b1 ** t))
+        return loss
+
+
+class NativeScaler:
+    """``timm.utils.NativeScaler`` (main.py:732; called at engine.py:68-74) on device-side state.
+
+    ``__call__(loss, optimizer, clip_grad=None, parameters=None, create_graph=False)``: scaled backward, gradient-norm
+    clipping to ``clip_grad`` when it is not None (``parameters`` then required, as in timm), optimizer step skipped on
+    non-finite gradients, scale update (growth 2.0 every 2000 clean steps, backoff 0.5) -- ``torch.cuda.amp.GradScaler``
+    defaults.  With an optimizer that takes device scalars (``optim.AdamW``) nothing in the step syncs with the host and
+    the gradients stay SCALED in ``.grad`` (``grad_multiplier`` holds ``inv_scale x clip coefficient``); any other optimizer
+    gets the stock sequence (unscale in place, ``clip_grad_norm_``, host-checked step).
+    ``state_dict()`` has GradScaler's keys (main.py:903 saves it, 723 loads it)."""
+
+    state_dict_key = "amp_scaler"
+
+    def __init__(self, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000, enabled: bool = True):
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.enabled = enabled
+        self._init_scale = float(init_scale)
+        self._scale = None            # f32[1] on the device, created at the first call
+        self._growth_tracker = None   # f32[1]
+        self.grad_multiplier = None   # f32[1]: what the last step multiplied the stored gradients by
+        self.last_grad_norm = None    # f32[1]: total norm of the unscaled gradients of the last clipped step
+
+    def _lazy(self, device):
+        if self._scale is None or self._scale.device != device:
+            s = self._init_scale if self._scale is None else float(self._scale)
+            t = 0.0 if self._growth_tracker is None else float(self._growth_tracker)
+            self._scale = torch.full((1,), s, dtype=torch.float32, device=device)
+            self._growth_tracker = torch.full((1,), t, dtype=torch.float32, device=device)
+
+    def get_scale(self) -> float:
+        return self._init_scale if self._scale is None else float(self._scale)
+
+    def state_dict(self):
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval,
+                "_growth_tracker": 0 if self._growth_tracker is None else int(self._growth_tracker)}
+
+    def load_state_dict(self, sd):
+        self.growth_factor, self.backoff_factor = sd["growth_factor"], sd["backoff_factor"]
+        self.growth_interval = sd["growth_interval"]
+        self._init_scale = float(sd["scale"])
+        dev = None if self._scale is None else self._scale.device
+        self._scale = self._growth_tracker = None
+        if dev is not None:
+            self._lazy(dev)
+        if self._growth_tracker is not None:
+            self._growth_tracker.fill_(float(sd["_growth_tracker"]))
+        else:
+            self._pending_tracker = float(sd["_growth_tracker"])
+
+    def __call__(self, loss, optimizer, clip_grad=None, parameters: Optional[Iterable] = None, create_graph: bool = False):
+        if not self.enabled:
+            loss.backward(create_graph=create_graph)
+            if clip_grad is not None:
+                assert parameters is not None
+                torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
+            optimizer.step()
+            return
+        dev = loss.device
+        self._lazy(dev)
+        if getattr(self, "_pending_tracker", None) is not None:
+            self._growth_tracker.fill_(self._pending_tracker)
+            self._pending_tracker = None
+        (loss * self._scale[0]).backward(create_graph=create_graph)
+        params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+        fused = bool(getattr(optimizer, "supports_device_scalars", False)) and dev.type == "cuda" and all(
+            p.grad.is_cuda and p.grad.is_contiguous() and p.grad.dtype in ops._DT for p in params)
+        if not fused:
+            self._stock_step(optimizer, params, clip_grad, parameters)
+            return
+        lib = _lib.load()
+        found_inf = torch.zeros(1, dtype=torch.float32, device=dev)
+        inv_scale = self._scale.reciprocal()
+        clip_over = list(parameters) if (clip_grad is not None and parameters is not None) else None
+        if clip_grad is not None:
+            assert parameters is not None, "clip_grad needs `parameters` (timm NativeScaler)"
+        # pass 1 over every gradient the optimizer will use: non-finite check (+ the norm's partial sums where clipped)
+        grads = [p.grad for p in params]
+        clip_ids = {id(p) for p in clip_over if p.grad is not None} if clip_over is not None else set()
+        n_blocks = [int(lib.smoe_grad_sumsq_blocks(g.numel())) for g in grads]
+        partial = torch.zeros(max(1, sum(n_blocks)), dtype=torch.float32, device=dev)
+        clip_mask = torch.zeros(max(1, sum(n_blocks)), dtype=torch.bool)
+        at = 0
+        for p, g, nb in zip(params, grads, n_blocks):
+            if nb:
+                rc = lib.smoe_grad_sumsq(g.data_ptr(), ops.dtype_code(g.dtype), g.numel(), inv_scale.data_ptr(),
+                                         partial[at:].data_ptr(), found_inf.data_ptr(), ops._stream(g))
+                _lib.check(rc, "smoe_grad_sumsq")
+                if id(p) in clip_ids:
+                    clip_mask[at:at + nb] = True
+            at += nb
+        mult = inv_scale
+        if clip_grad is not None:
+            total = partial[clip_mask.to(dev)].sum().sqrt() if bool(clip_mask.any()) else partial.new_zeros(())
+            self.last_grad_norm = total.reshape(1)
+            coef = (float(clip_grad) / (total + 1e-6)).clamp(max=1.0)      # torch.nn.utils.clip_grad_norm_
+            mult = inv_scale * coef
+        self.grad_multiplier = mult.reshape(1).contiguous()
+        optimizer.step(grad_mult=self.grad_multiplier, found_inf=found_inf)
+        rc = lib.smoe_amp_update(self._scale.data_ptr(), self._growth_tracker.data_ptr(), found_inf.data_ptr(),
+                                 float(self.growth_factor), float(self.backoff_factor), int(self.growth_interval),
+                                 ops._stream(self._scale))
+        _lib.check(rc, "smoe_amp_update")
+
+    def _stock_step(self, optimizer, params, clip_grad, parameters):
+        """GradScaler's sequence for optimizers that know nothing of device scalars (and for CPU tensors)."""
+        inv = 1.0 / float(self._scale)
+        finite = True
+        for p in params:
+            p.grad.mul_(inv)
+            finite = finite and bool(torch.isfinite(p.grad).all())
+        if clip_grad is not None:
+            assert parameters is not None, "clip_grad needs `parameters` (timm NativeScaler)"
+            self.last_grad_norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad).reshape(1)
+        self.grad_multiplier = None
+        if finite:
+            optimizer.step()
+            self._growth_tracker += 1
+            if int(self._growth_tracker) >= self.growth_interval:
+                self._scale *= self.growth_factor
+                self._growth_tracker.zero_()
+        else:
+            self._scale *= self.backoff_factor
+            self._growth_tracker.zero_()
