@@ -129,15 +129,12 @@ class _GroupFFN(torch.autograd.Function):
         n = rows.shape[0]
         dY = dY.contiguous()
         w2t = ex.h4toh.weight_as(cd).transpose(1, 2).contiguous()                        # [E, h, d]  (N = h, K = d)
+        # dH = (dY W2) * gelu'(H) [* dropout mask]: gelu' rides in the dgrad GEMM's epilogue; the (elementwise, commuting)
+        # dropout mask of the rare drop > 0 training configuration is one multiply behind it
+        dH = ops.grouped_gemm(dY, w2t, None, offsets, ops.EPI_GELU_GRAD, cd, variant=mod.gemm_variant,
+                              group_expert=gexp, residual=Hp)
         if ctx.has_drop:
-            dA = ops.grouped_gemm(dY, w2t, None, offsets, ops.EPI_NONE, cd, variant=mod.gemm_variant, group_expert=gexp)
-            dA = dA * drop_mask
-            hp = Hp.float()  # gelu'(H) unfused on this (rare) path
-            cdf = 0.5 * (1 + torch.erf(hp * 0.7071067811865476))
-            dH = (dA.float() * (cdf + hp * torch.exp(-0.5 * hp * hp) * 0.3989422804014327)).to(cd)
-        else:
-            dH = ops.grouped_gemm(dY, w2t, None, offsets, ops.EPI_GELU_GRAD, cd, variant=mod.gemm_variant,
-                                  group_expert=gexp, residual=Hp)
+            dH = dH * drop_mask
         # dW2[e] = dY_e^T A_e, dW1[e] = dH_e^T R_e straight from the token-major tensors (transposing LDS reads;
         # smoe_transpose_pad + smoe_grouped_wgrad is the older two-step form, kept in ops for A/B tests)
         dW2 = ops.grouped_wgrad_rows(dY, A, offsets)

@@ -42,3 +42,43 @@ def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: to
     dt = time.perf_counter() - t0
     n = max(n, 1)
     return {"loss": loss_sum / n, "acc1": a1 / n, "acc5": a5 / n, "images_per_sec": n / dt}
+
+
+def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]],
+                    optimizer: torch.optim.Optimizer, device, epoch: int, loss_scaler, max_norm=None,
+                    aux_loss_weight: float = 0.0, gate_delta=None, autocast: bool = True):
+    """The reference's training loop body (engine.py:21-84) around the HIP path: autocast forward, criterion,
+    ``loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters())`` (optim.NativeScaler keeps the
+    whole step on the device), then the token-skip gates' threshold schedule (``Gate.step(delta)`` for every gate, as
+    main.py:812-815 does after the epoch's steps).  ``criterion(outputs, targets)`` -- the reference's distillation
+    criterion also takes the inputs (losses.py, off the hot path).  ``aux_loss_weight`` adds the MoE gates' load-balance
+    losses (SwitchGate, BASELINE cfg 5).  Mixup, EMA and the metric logger are training-driver plumbing (out of scope).
+    Returns {"loss": mean loss, "steps": n}."""
+    from .fmoe import FMoETransformerMLP
+    from .resmoe import Gate
+
+    model.train(True)
+    dev = torch.device(device)
+    moes = [m for m in model.modules() if isinstance(m, FMoETransformerMLP)]
+    loss_sum, n = torch.zeros((), device=dev), 0
+    for samples, targets in data_loader:
+        samples = samples.to(dev, non_blocking=True)
+        targets = targets.to(dev, non_blocking=True)
+        with torch.autocast(device_type=dev.type, dtype=torch.float16, enabled=autocast and dev.type == "cuda"):
+            outputs = model(samples)
+            loss = criterion(outputs, targets)
+            if aux_loss_weight:
+                for m in moes:
+                    aux = m.gate.get_loss()
+                    if aux is not None:
+                        loss = loss + aux_loss_weight * aux
+        optimizer.zero_grad()
+        loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=False)
+        loss_sum += loss.detach().float()
+        n += 1
+    if gate_delta is not None:
+        for m in model.modules():
+            if isinstance(m, Gate):
+                m.step(gate_delta)
+    mean = float(loss_sum) / max(n, 1)   # the epoch's single host read
+    return {"loss": mean, "steps": n}

@@ -1,0 +1,109 @@
+"""GPU tests of the optimizer side of the training step (engine.py:68-74; optim.AdamW / optim.NativeScaler on the HIP
+kernels smoe_grad_sumsq / smoe_adamw_step / smoe_amp_update) against torch.optim.AdamW + torch GradScaler semantics +
+torch.nn.utils.clip_grad_norm_."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import slim_switch_moe_vit_amd as sm  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _params(seed, shapes):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(s, generator=g) for s in shapes]
+
+
+SHAPES = [(8, 96, 64), (8, 64, 96), (8, 96), (3, 7), (1,), (40001,)]   # expert-tensor shaped, odd sizes, a scalar
+
+
+@pytest.mark.parametrize("gdt", [torch.float32, torch.float16])
+def test_adamw_kernel_matches_torch_adamw(gdt):
+    init = _params(0, SHAPES)
+    ours = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().double()) for t in init]
+    a = sm.AdamW(ours, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    b = torch.optim.AdamW(ref, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    for it in range(12):
+        grads = _params(100 + it, SHAPES)
+        for p, q, g in zip(ours, ref, grads):
+            gg = g.to(gdt)
+            p.grad = gg.to(DEV)
+            q.grad = gg.double()
+        a.step()
+        b.step()
+    for p, q in zip(ours, ref):
+        assert (p.detach().cpu().double() - q.detach()).abs().max().item() <= 2e-6 * max(1.0, float(q.abs().max()))
+    assert float(a._step_counter(torch.device(DEV))) == 12.0
+
+
+def test_native_scaler_step_matches_the_stock_sequence_and_skips_on_inf():
+    """scale -> backward -> (unscale, clip, step, update) on device scalars == the stock sequence on a float64 twin:
+    clipping engages (norm > max_norm), a step with an inf gradient is skipped (parameters, Adam moments AND the step
+    count untouched) and backs the scale off, clean steps grow it after `growth_interval`."""
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.GELU(), torch.nn.Linear(128, 10)).to(DEV)
+    twin = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.GELU(), torch.nn.Linear(128, 10)).double()
+    twin.load_state_dict({k: v.double().cpu() for k, v in lin.state_dict().items()})
+    opt = sm.AdamW(lin.parameters(), lr=1e-2, weight_decay=0.05)
+    ropt = torch.optim.AdamW(twin.parameters(), lr=1e-2, weight_decay=0.05)
+    sc = sm.NativeScaler(init_scale=1024.0, growth_interval=3)
+    max_norm = 0.5
+    g = torch.Generator().manual_seed(1)
+    scales = []
+    for it in range(7):
+        x = torch.randn(32, 64, generator=g)
+        y = torch.randint(0, 10, (32,), generator=g)
+        poison = (it == 4)
+        loss = torch.nn.functional.cross_entropy(lin(x.to(DEV)), y.to(DEV))
+        if poison:
+            loss = loss + float("inf") * lin[0].weight.sum() * 0   # nan gradients on one tensor
+        opt.zero_grad()
+        before = [p.detach().clone() for p in lin.parameters()]
+        sc(loss, opt, clip_grad=max_norm, parameters=lin.parameters())
+        scales.append(sc.get_scale())
+        if poison:
+            for p, q in zip(lin.parameters(), before):
+                assert torch.equal(p.detach(), q), "a non-finite step must leave the parameters alone"
+            continue
+        rl = torch.nn.functional.cross_entropy(twin(x.double()), y)
+        ropt.zero_grad()
+        rl.backward()
+        norm = torch.nn.utils.clip_grad_norm_(twin.parameters(), max_norm)
+        assert float(norm) > max_norm, "the test must exercise clipping"
+        assert abs(float(sc.last_grad_norm) - float(norm)) <= 1e-4 * float(norm)
+        ropt.step()
+    for p, q in zip(lin.parameters(), twin.parameters()):
+        assert (p.detach().cpu().double() - q.detach()).abs().max().item() <= 5e-5
+    assert float(opt._step_counter(torch.device(DEV))) == 6.0, "the skipped step does not count"
+    # 1024 -> (3 clean) 2048 -> (1 clean) -> inf: 1024 -> (2 clean)
+    assert scales == [1024.0, 1024.0, 2048.0, 2048.0, 1024.0, 1024.0, 1024.0], scales
+    sd = sc.state_dict()
+    assert set(sd) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"} and sd["_growth_tracker"] == 2
+    sc2 = sm.NativeScaler()
+    sc2.load_state_dict(sd)
+    assert sc2.get_scale() == 1024.0
+
+
+def test_cfg5_training_step_through_the_harness():
+    """BASELINE cfg 5 shape of a step, end to end on the HIP path: ViT with SwitchGate MoE blocks (capacity 1.0, token
+    dropping, aux loss), fp16 autocast forward, backward, NativeScaler + AdamW; the loss goes down over a few steps on a
+    fixed batch and every expert tensor receives updates."""
+    torch.manual_seed(0)
+    model = sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=10, depth=2, gate="switch",
+                            capacity_factor=1.0).to(DEV)
+    opt = sm.AdamW(model.parameters(), lr=2e-3, weight_decay=0.05)
+    sc = sm.NativeScaler()
+    g = torch.Generator().manual_seed(3)
+    batch = [(torch.randn(8, 3, 224, 224, generator=g), torch.randint(0, 10, (8,), generator=g))]
+    w0 = model.blocks[0].mlp.experts.htoh4.weight.detach().clone()
+    losses = []
+    for _ in range(6):
+        st = sm.train_one_epoch(model, torch.nn.CrossEntropyLoss(), batch, opt, DEV, 0, sc, max_norm=1.0, aux_loss_weight=0.01)
+        losses.append(st["loss"])
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+    assert float((model.blocks[0].mlp.experts.htoh4.weight.detach() - w0).abs().max()) > 0
