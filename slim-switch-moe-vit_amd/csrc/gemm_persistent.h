@@ -18,6 +18,18 @@
 //
 // Main loop, LDS layout, fragment roles and both DMA schedules (DEEP = half-organised regions, two half-tiles in flight
 // across the tile boundary) are those of grouped_gemm_pp256; results are bit-identical to it (same accumulation order).
+#ifdef SMOE_DIAG
+// diagnostic build only: s_memtime stamps of wave 0 / lane 0 of every workgroup, 16 stamps per tile, first 12 tiles
+__device__ unsigned long long smoe_diag_stamps[256 * 12 * 16];
+#define PS_STAMP(i)                                                                                              \
+  do {                                                                                                           \
+    if (wave == 0 && lane == 0 && tile_no < 12 && blockIdx.x < 256)                                              \
+      smoe_diag_stamps[(blockIdx.x * 12 + tile_no) * 16 + (i)] = __builtin_amdgcn_s_memtime();                   \
+  } while (0)
+#else
+#define PS_STAMP(i) do {} while (0)
+#endif
+
 template <typename AB, typename OT, int AFR, bool DEEP>
 __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
@@ -247,7 +259,10 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   }
   PP_BARRIER();
 
-  for (;;) {
+  int tile_no = 0;
+  (void)tile_no;
+  for (;; ++tile_no) {
+    PS_STAMP(0);
 #pragma unroll
     for (int i = 0; i < 2 * AFR; ++i)
 #pragma unroll
@@ -329,19 +344,23 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       }
     }
     if (wr == 0) PP_BARRIER();  // equalise barrier counts; after it every wave is done with the operand buffers
+    PS_STAMP(1);
 
     // ---- the tile just computed, and the next one ----------------------------------------------------------------------
     const int ce = e, cm0 = m0, cm_end = m_end, cn0 = n0;
     tile += G;
     const bool more = advance();
+    PS_STAMP(2);
     int oz = 0;
     asm volatile("" : "+v"(oz));          // per-tile opaque zero (see setup)
     const int tid_e = tid + oz, lane_e = tid_e & 63;
     if (more) {
       setup(lane_e);  // gather-address loads + pointer arithmetic of the next tile
       issue_bias(bias_par ^ 1);
+      PS_STAMP(3);
       issue_kt0();    // its first K-tile streams into buffer 0 under the epilogue below
     }
+    PS_STAMP(4);
 
     // ---- epilogue of (ce, cm0, cm_end, cn0) in row passes through LDS ------------------------------------------------
     (void)ce;
@@ -386,9 +405,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       // LDS ordering only (no vector-memory drain): every wave's staging writes done, then the barrier.  On the last
       // pass each wave also retires its own outstanding vector-memory operations -- the next tile's K-tile 0 (issued
       // before pass 0) and the earlier passes' stores -- so that after this barrier buffer 0 is valid for everybody.
+      if (p == 0) PS_STAMP(5);
+      if (p == NPASS - 1) PS_STAMP(8);
       if (p == NPASS - 1 && more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (p == NPASS - 1) PS_STAMP(9);
       PP_BARRIER();
+      if (p == 0) PS_STAMP(6);
+      if (p == NPASS - 1) PS_STAMP(10);
       // (3) whole-row-segment stores (combine scale and residual / gelu' fused); a row's residual segments are fetched
       //     right here, per row: holding a whole pass of them across (2) costs registers the 320-row tile does not have
 #pragma unroll
@@ -419,30 +443,15 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       }
       // the staging reads above are complete when their stores have issued; the next pass (or the next tile's K-tile 1)
       // may overwrite the region once every wave is here
+      if (p == 0) PS_STAMP(7);
+      if (p == NPASS - 1) PS_STAMP(11);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       PP_BARRIER();
     }
+    PS_STAMP(12);
     if (!more) break;
     issue_kt1();   // into buffer 1 = the staging region just released; lands during the first K-tile's 8 intervals
   }
 #undef PS_MFMA
 #undef PS_DMA
-}
-
-template <typename AB, typename OT, int AFR, bool DEEP>
-int launch_ps(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert, int E,
-              int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
-              const void* residual, void* out, int group_m, hipStream_t s, const int64_t* a_gather, int a_div) {
-  constexpr int TBM = 64 * AFR, TBN = 256;
-  const int n_tiles_n = (N + TBN - 1) / TBN;
-  const int64_t max_tiles = ((m_rows_max + TBM - 1) / TBM + E) * n_tiles_n;
-  int grid = smoe_num_cus() & ~7;                 // one workgroup per CU (the LDS is full); a multiple of 8 (XCD slots)
-  if (grid < 8) grid = 8;
-  if (max_tiles < grid) grid = (int)((max_tiles + 7) & ~(int64_t)7);
-  SMOE_ENSURE_SMEM(grouped_gemm_ps<AB, OT, AFR, DEEP>);
-  hipLaunchKernelGGL((grouped_gemm_ps<AB, OT, AFR, DEEP>), dim3(grid), dim3(512), 160 * 1024, s, (const AB*)A, (const AB*)W,
-                     bias, offsets, group_expert, E, K, N, epilogue, row_map, row_scale, (const OT*)residual, (OT*)out,
-                     n_tiles_n, group_m, a_gather, a_div);
-  SMOE_CHECK_LAUNCH("smoe_grouped_gemm/persistent");
-  return 0;
 }

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Diagnostic (library built with `make DIAG=-DSMOE_DIAG`): per-tile phase times of the persistent grouped GEMM from
+s_memtime stamps (wave 0 / lane 0 of every workgroup).  usage: gemm_stamps.py <variant 9..13> <fc1|fc2>"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from slim_switch_moe_vit_amd import ops, _lib  # noqa: E402
+
+
+def main():
+    variant, shape = int(sys.argv[1]), sys.argv[2]
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    T, d, h, E = 256 * 197, 768, 3072, 8
+    idx = torch.randint(0, E, (T, 1), device=dev)
+    counts, offsets, pos, inv_pos, _ = ops.dispatch_plan(idx, E)
+    x16 = torch.randn(T, d, device=dev).half()
+    w1 = (torch.randn(E, h, d, device=dev) * 0.02).half()
+    w2 = (torch.randn(E, d, h, device=dev) * 0.02).half()
+    b1 = torch.randn(E, h, device=dev) * 0.02
+    b2 = torch.randn(E, d, device=dev) * 0.02
+    score = torch.rand(T, device=dev)
+    hbuf = ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_GELU, torch.float16, variant=4, a_gather=pos)
+    out = torch.zeros(T, d, device=dev)
+    res = torch.randn(T, d, device=dev)
+
+    def run():
+        if shape == "fc1":
+            ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_GELU, torch.float16, variant=variant, a_gather=pos, out=hbuf)
+        else:
+            ops.grouped_gemm(hbuf, w2, b2, offsets, ops.EPI_NONE, row_map=pos, row_scale=score, out=out, variant=variant,
+                             residual=res)
+    lib = _lib.load()
+    rd = lib.__getattr__("smoe_diag_read_stamps"); rd.restype = ctypes.c_int; rd.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    clr = lib.__getattr__("smoe_diag_clear_stamps"); clr.restype = ctypes.c_int; clr.argtypes = []
+    for _ in range(200):   # let the clock settle under load
+        run()
+    torch.cuda.synchronize()
+    clr()
+    run()
+    torch.cuda.synchronize()
+    n = 256 * 12 * 16
+    buf = np.zeros(n, dtype=np.uint64)
+    rc = rd(buf.ctypes.data, n)
+    assert rc == 0, rc
+    st = buf.reshape(256, 12, 16).astype(np.int64)
+    names = {(0, 1): "main loop", (1, 2): "advance", (2, 3): "setup (gather addresses)", (3, 4): "issue kt0",
+             (4, 5): "pass0: rows + GELU + LDS write", (5, 6): "pass0: wait + barrier", (6, 7): "pass0: LDS read + stores",
+             (8, 9): "last pass: vmcnt(0)", (9, 10): "last pass: barrier", (10, 11): "last pass: stores", (11, 12): "last barrier",
+             (0, 12): "whole tile", (1, 12): "tile boundary (everything but the main loop)"}
+    sel = st[:, 1:6, :]          # tiles 1..5 of every workgroup (steady state, a next tile exists)
+    ok = (sel[:, :, 12] > 0) & (sel[:, :, 0] > 0)
+    print(f"variant {variant} {shape}: {int(ok.sum())} tiles sampled; s_memtime ticks at 100 MHz -> us = ticks / 100")
+    for (a, b), nm in names.items():
+        dlt = (sel[:, :, b] - sel[:, :, a])[ok & (sel[:, :, a] > 0) & (sel[:, :, b] > 0)]
+        if dlt.size:
+            print(f"  {nm:46s} median {np.median(dlt) / 100:7.2f} us   p10 {np.percentile(dlt, 10) / 100:7.2f}   p90 {np.percentile(dlt, 90) / 100:7.2f}")
+    t0 = st[:, 0, 0][st[:, 0, 0] > 0]
+    tend = st[:, :, 12].max(axis=1)
+    print(f"  kernel span (first stamp -> last stamp)     {(tend.max() - t0.min()) / 100:.1f} us; tiles per workgroup: "
+          f"{np.bincount((st[:, :, 12] > 0).sum(axis=1))}")
+
+
+if __name__ == "__main__":
+    main()
