@@ -1317,24 +1317,6 @@ extern "C" int smoe_diag_clear_stamps() {
 }
 #endif
 
-template <typename AB, typename OT, int AFR, bool DEEP>
-int launch_ps(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert, int E,
-              int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
-              const void* residual, void* out, int group_m, hipStream_t s, const int64_t* a_gather, int a_div) {
-  constexpr int TBM = 64 * AFR, TBN = 256;
-  const int n_tiles_n = (N + TBN - 1) / TBN;
-  const int64_t max_tiles = ((m_rows_max + TBM - 1) / TBM + E) * n_tiles_n;
-  int grid = smoe_num_cus() & ~7;                 // one workgroup per CU (the LDS is full); a multiple of 8 (XCD slots)
-  if (grid < 8) grid = 8;
-  if (max_tiles < grid) grid = (int)((max_tiles + 7) & ~(int64_t)7);
-  SMOE_ENSURE_SMEM(grouped_gemm_ps<AB, OT, AFR, DEEP>);
-  hipLaunchKernelGGL((grouped_gemm_ps<AB, OT, AFR, DEEP>), dim3(grid), dim3(512), 160 * 1024, s, (const AB*)A, (const AB*)W,
-                     bias, offsets, group_expert, E, K, N, epilogue, row_map, row_scale, (const OT*)residual, (OT*)out,
-                     n_tiles_n, group_m, a_gather, a_div);
-  SMOE_CHECK_LAUNCH("smoe_grouped_gemm/persistent");
-  return 0;
-}
-
 extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int32_t* offsets,
                                  const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
                                  int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,

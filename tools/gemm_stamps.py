@@ -32,7 +32,8 @@ def main():
 
     def run():
         if shape == "fc1":
-            ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_GELU, torch.float16, variant=variant, a_gather=pos, out=hbuf)
+            ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_NONE if os.environ.get("SMOE_EPI") == "none" else ops.EPI_GELU,
+                             torch.float16, variant=variant, a_gather=pos, out=hbuf)
         else:
             ops.grouped_gemm(hbuf, w2, b2, offsets, ops.EPI_NONE, row_map=pos, row_scale=score, out=out, variant=variant,
                              residual=res)
@@ -56,15 +57,14 @@ def main():
              (0, 12): "whole tile", (1, 12): "tile boundary (everything but the main loop)"}
     sel = st[:, 1:6, :]          # tiles 1..5 of every workgroup (steady state, a next tile exists)
     ok = (sel[:, :, 12] > 0) & (sel[:, :, 0] > 0)
-    print(f"variant {variant} {shape}: {int(ok.sum())} tiles sampled; s_memtime ticks at 100 MHz -> us = ticks / 100")
+    print(f"variant {variant} {shape} grid={os.environ.get('SMOE_PS_GRID', 'all')} epi={os.environ.get('SMOE_EPI', 'default')}: {int(ok.sum())} tiles sampled; s_memtime = shader cycles (k = 1000 cycles)")
     for (a, b), nm in names.items():
         dlt = (sel[:, :, b] - sel[:, :, a])[ok & (sel[:, :, a] > 0) & (sel[:, :, b] > 0)]
         if dlt.size:
-            print(f"  {nm:46s} median {np.median(dlt) / 100:7.2f} us   p10 {np.percentile(dlt, 10) / 100:7.2f}   p90 {np.percentile(dlt, 90) / 100:7.2f}")
+            print(f"  {nm:46s} median {np.median(dlt) / 1000:7.2f} k   p10 {np.percentile(dlt, 10) / 1000:7.2f}   p90 {np.percentile(dlt, 90) / 1000:7.2f}")
     t0 = st[:, 0, 0][st[:, 0, 0] > 0]
     tend = st[:, :, 12].max(axis=1)
-    print(f"  kernel span (first stamp -> last stamp)     {(tend.max() - t0.min()) / 100:.1f} us; tiles per workgroup: "
-          f"{np.bincount((st[:, :, 12] > 0).sum(axis=1))}")
+    print(f"  tiles per workgroup (histogram): {np.bincount((st[:, :, 12] > 0).sum(axis=1))}")
 
 
 if __name__ == "__main__":
