@@ -1344,7 +1344,7 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
     // the persistent kernel addresses both operands with 32-bit byte offsets; operands of 4 GiB and more take the
     // one-workgroup-per-tile kernel of the same tile height / schedule (9 -> 4, 10 -> 5, 11 -> 6, 12 -> 7, 13 -> 8)
     const uint64_t a_bytes = (uint64_t)m_rows_max * (uint64_t)K * 2u, w_bytes = (uint64_t)n_experts * (uint64_t)N * (uint64_t)K * 2u;
-    if (a_bytes >= (1ull << 32) || w_bytes >= (1ull << 32)) variant -= 5;
+    if (a_bytes >= (1ull << 32) || w_bytes >= (1ull << 32) || G > 63) variant -= 5;   // (its group table: 64 lanes)
   }
   hipStream_t s = (hipStream_t)stream;
   switch (ab_dtype) {

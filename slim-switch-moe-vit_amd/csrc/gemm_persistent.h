@@ -35,7 +35,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
     const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* residual, OT* out, int n_tiles_n,
-    int group_m, const int64_t* __restrict__ a_gather, int a_div) {
+    int group_m, const int64_t* __restrict__ a_gather, int a_div, int gather_len) {
   static_assert(sizeof(AB) == 2, "16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TBM = 64 * AFR, TBN = 256, NT = 512, NW = 8;
@@ -51,8 +51,26 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   const int nk = K / 64;
 
   // ---- tile enumeration ------------------------------------------------------------------------------------------------
-  int total_mt = 0;
-  for (int i = 0; i < E; ++i) total_mt += (offsets[i + 1] - offsets[i] + TBM - 1) / TBM;
+  // Row-group table in two registers (E <= 63 groups, the launcher checks): lane l holds offsets[l] and the number of
+  // m-tiles in front of group l (lane E: offsets[E] and the total).  Locating a tile is then a ballot, a count-leading-
+  // zeros and three v_readlane -- no memory access; the scalar scan over `offsets` it replaces cost ~2,300 cycles per
+  // tile (stamps: tools/gemm_stamps.py).
+  int t_off = 0, t_tb = 0, t_ge = lane;
+  {
+    const int li = lane <= E ? lane : E;
+    t_off = offsets[li];
+    const int nxt = offsets[li < E ? li + 1 : E];
+    int cnt = lane < E ? (nxt - t_off + TBM - 1) / TBM : 0;
+    int incl = cnt;                                 // inclusive scan over the wave
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const int up = __shfl_up(incl, sft, 64);
+      if (lane >= sft) incl += up;
+    }
+    t_tb = incl - cnt;                              // exclusive prefix; lanes >= E hold the total
+    if (group_expert && lane < E) t_ge = group_expert[lane];
+  }
+  const int total_mt = __builtin_amdgcn_readlane(t_tb, 63);
   const int per_group = group_m * n_tiles_n;
   const int n_tiles = ((total_mt + group_m - 1) / group_m) * per_group;
   const int G = gridDim.x, per_xcd = G >> 3;     // the launcher keeps G a multiple of 8
@@ -61,8 +79,15 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   auto advance = [&]() -> bool {                 // first existing tile at or after `tile` on this workgroup's stride
     while (tile < n_tiles) {
       const int g = tile / per_group, rem = tile % per_group;
-      if (find_tile(offsets, E, g * group_m + rem % group_m, e, m0, m_end, TBM)) {
-        if (group_expert) e = group_expert[e];
+      const int mt = g * group_m + rem % group_m;
+      if (mt < total_mt) {
+        // groups in front of or holding m-tile mt form a lane prefix; the owner is its last lane (an empty group has the
+        // same prefix count as its successor, so it is never last)
+        const unsigned long long msk = __ballot(lane < E && t_tb <= mt);
+        const int gi = 63 - __builtin_clzll(msk);
+        m0 = __builtin_amdgcn_readlane(t_off, gi) + (mt - __builtin_amdgcn_readlane(t_tb, gi)) * TBM;
+        m_end = __builtin_amdgcn_readlane(t_off, gi + 1);
+        e = __builtin_amdgcn_readlane(t_ge, gi);
         n0 = (rem / group_m) * TBN;
         return true;
       }
@@ -83,6 +108,13 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   // `lo` = the lane id behind a per-call opaque zero: everything derived from it (per-slot swizzle constants, row
   // numbers) is recomputed per tile instead of being hoisted out of the tile loop and kept in registers through the
   // main loop, where there are none to spare
+  const int* const rowbuf = reinterpret_cast<const int*>(smem + LDS_TOTAL - 2048 - TBM * 4);
+  bool rows_in_lds = false;               // true once a tile's gather rows were prefetched into rowbuf
+  auto gathered_row = [&](int gr) -> int64_t {   // source row of tile row gr (already clamped to the group's range)
+    if (!a_gather) return gr;
+    const int64_t v = rows_in_lds ? (int64_t)rowbuf[gr - m0] : a_gather[gr];
+    return a_div == 1 ? v : (int64_t)((uint32_t)v / (uint32_t)a_div);
+  };
   auto setup = [&](int lo) {
     const int l_row = lo >> 3, l_pos = lo & 7;
     if constexpr (!DEEP) {
@@ -91,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
         const int r = 8 * (s * NW + wave) + l_row;
         int gr = m0 + r;
         if (gr >= m_end) gr = m_end - 1;
-        const int64_t arow = a_gather ? a_gather[gr] / a_div : (int64_t)gr;   // fused MOEScatter
+        const int64_t arow = gathered_row(gr);   // fused MOEScatter
         a_src[s] = (uint32_t)((arow * K + ((l_pos ^ ((r >> 1) & 7)) << 3)) * 2);
       }
 #pragma unroll
@@ -112,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
           const int trow = (r / (16 * AFR)) * (TBM / 2) + h * (16 * AFR) + r % (16 * AFR);
           int gr = m0 + trow;
           if (gr >= m_end) gr = m_end - 1;
-          const int64_t arow = a_gather ? a_gather[gr] / a_div : (int64_t)gr;
+          const int64_t arow = gathered_row(gr);
           a_src[h * A_HS + s2] = (uint32_t)((arow * K + ((l_pos ^ ((r >> 1) & 7)) << 3)) * 2);
         }
 #pragma unroll
@@ -213,7 +245,8 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   constexpr int OB = OutPack<OT>::bytes;
   constexpr int C_STRIDE = TBN * OB + C_PAD;
   constexpr int BIAS_BYTES = 2048;        // two 1-KiB bias tiles (256 f32) at the top of the LDS, alternating per tile
-  constexpr int EPI_BYTES = LDS_TOTAL - STAGE - BIAS_BYTES;
+  constexpr int ROWBUF_BYTES = TBM * 4;   // below them: the next tile's gathered row numbers (i32), prefetched by DMA
+  constexpr int EPI_BYTES = LDS_TOTAL - STAGE - BIAS_BYTES - ROWBUF_BYTES;
   constexpr int NPASS = (TBM * C_STRIDE <= EPI_BYTES) ? 1 : ((TBM / 2) * C_STRIDE <= EPI_BYTES ? 2 : (AFR == 4 ? 4 : 5));
   constexpr int RP = TBM / NPASS;
   static_assert(RP * C_STRIDE <= EPI_BYTES, "epilogue pass does not fit behind buffer 0");
@@ -232,6 +265,17 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   // tile's operand DMAs included -- at its first use (cdna_hip_programming.md section 5, "Pipelining across barriers").
   char* const bias_lds = smem + LDS_TOTAL - BIAS_BYTES;
   int bias_par = 0;
+  // the NEXT tile's gather rows: low words of a_gather[min(m0 + r, m_end - 1)], 64 rows per DMA piece (waves 0 .. TBM/64-1),
+  // issued at the head of the current tile's main loop and read by setup() a whole main loop later
+  auto prefetch_rows = [&]() {
+    if (a_gather && wave < TBM / 64) {
+      int gr = m0 + wave * 64 + lane;
+      if (gr >= m_end) gr = m_end - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_gather + gr),
+                                       (__attribute__((address_space(3))) void*)(smem + LDS_TOTAL - 2048 - TBM * 4 + wave * 256),
+                                       4, 0, 0);
+    }
+  };
   auto issue_bias = [&](int par) {
     if (bias && wave == 0) {
       int col = n0 + lane * 4;
@@ -263,6 +307,11 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   (void)tile_no;
   for (;; ++tile_no) {
     PS_STAMP(0);
+    // ---- look ahead: where this workgroup goes next; that tile's gather rows start streaming into LDS now ----------------
+    const int ce = e, cm0 = m0, cm_end = m_end, cn0 = n0;   // the tile computed in this iteration
+    tile += G;
+    const bool more = advance();                            // (e, m0, m_end, n0) = the next tile from here on
+    if (more) prefetch_rows();
 #pragma unroll
     for (int i = 0; i < 2 * AFR; ++i)
 #pragma unroll
@@ -346,16 +395,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     if (wr == 0) PP_BARRIER();  // equalise barrier counts; after it every wave is done with the operand buffers
     PS_STAMP(1);
 
-    // ---- the tile just computed, and the next one ----------------------------------------------------------------------
-    const int ce = e, cm0 = m0, cm_end = m_end, cn0 = n0;
-    tile += G;
-    const bool more = advance();
+    // ---- tile boundary: the next tile's operands start streaming, then this tile's epilogue -----------------------------
     PS_STAMP(2);
     int oz = 0;
     asm volatile("" : "+v"(oz));          // per-tile opaque zero (see setup)
     const int tid_e = tid + oz, lane_e = tid_e & 63;
     if (more) {
-      setup(lane_e);  // gather-address loads + pointer arithmetic of the next tile
+      rows_in_lds = a_gather != nullptr;
+      setup(lane_e);  // the next tile's row numbers (from LDS) and operand offsets
       issue_bias(bias_par ^ 1);
       PS_STAMP(3);
       issue_kt0();    // its first K-tile streams into buffer 0 under the epilogue below
@@ -472,7 +519,7 @@ int launch_ps(const void* A, const void* W, const float* bias, const int32_t* of
   SMOE_ENSURE_SMEM(grouped_gemm_ps<AB, OT, AFR, DEEP>);
   hipLaunchKernelGGL((grouped_gemm_ps<AB, OT, AFR, DEEP>), dim3(grid), dim3(512), 160 * 1024, s, (const AB*)A, (const AB*)W,
                      bias, offsets, group_expert, E, K, N, epilogue, row_map, row_scale, (const OT*)residual, (OT*)out,
-                     n_tiles_n, group_m, a_gather, a_div);
+                     n_tiles_n, group_m, a_gather, a_div, (int)m_rows_max);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm/persistent");
   return 0;
 }
