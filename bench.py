@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=128, help="images in the CPU-oracle sample")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU budget: 5 timed forwards if they fit ~2x this, else 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gemm-variant", type=int, default=4)
+    ap.add_argument("--gemm-variant", type=int, default=None,
+                    help="grouped-GEMM kernel (default: ops.DEFAULT_GEMM_VARIANT = 9, the persistent kernel; 4 = one "
+                         "workgroup per tile, bit-identical results)")
     ap.add_argument("--force-ep", action="store_true",
                     help="diagnostic: drive the expert-parallel code path on one GPU (world of one rank)")
     return ap.parse_args()
@@ -298,12 +300,20 @@ def main():
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                     "flops_per_launch": a["flops"] / a["launches"]}
-        # the same launches under the names rocprofv3 --stats gives them (profiles/r01_bench_kernel_stats.csv):
-        # grouped_gemm_pp256<operand, out, ABL, MODE, AFR>; ABL 16 = the deep schedule variant 4 picks for K >= 2048
+        # the same launches under the names rocprofv3 --stats gives them (profiles/r02_bench_kernel_stats.csv):
+        # grouped_gemm_ps<operand, out, AFR, DEEP> (AFR 5 = 320-row tile; DEEP = the half-tile prefetch schedule picked for
+        # K >= 2048); with --gemm-variant 4: grouped_gemm_pp256<operand, out, ABL, MODE, AFR>
+        pers = (args.gemm_variant or ops.DEFAULT_GEMM_VARIANT) == 9
+        names = ({"grouped_gemm_fc1": "grouped_gemm_ps<f16,f16,5,false> = GEMM-1 (K 768, gathered rows, bias + GELU)",
+                  "grouped_gemm_fc2": "grouped_gemm_ps<f16,f32,5,true> = GEMM-2 (K 3072, combine + residual)",
+                  "attn_proj_gemm": "grouped_gemm_ps<f16,f32,5,false> = attention projection (K 768, + residual)",
+                  "qkv_gemm": "grouped_gemm_ps<f16,f16,5,false> (shared with GEMM-1) = qkv projection (K 768, N 2304)"}
+                 if pers else
+                 {"grouped_gemm_fc1": "grouped_gemm_pp256<f16,f16,0,0,5> = GEMM-1 (K 768, GELU)",
+                  "grouped_gemm_fc2": "grouped_gemm_pp256<f16,f32,16,0,5> = GEMM-2 (K 3072, combine + residual)",
+                  "attn_proj_gemm": "grouped_gemm_pp256<f16,f32,0,0,5> = attention projection (K 768, + residual)"})
         sym = {}
-        for label, key in (("grouped_gemm_pp256<f16,f16,0,0,5> = GEMM-1 (K 768, GELU)", "grouped_gemm_fc1"),
-                           ("grouped_gemm_pp256<f16,f32,16,0,5> = GEMM-2 (K 3072, combine + residual)", "grouped_gemm_fc2"),
-                           ("grouped_gemm_pp256<f16,f32,0,0,5> = attention projection (K 768, + residual)", "attn_proj_gemm")):
+        for key, label in names.items():
             a2 = agg.get(key)
             if a2:
                 sym[label] = {"launches_per_step": a2["launches"] / (args.steps if key.startswith("grouped_gemm") else max(1, side_steps)),

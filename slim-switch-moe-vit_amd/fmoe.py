@@ -200,7 +200,7 @@ class FMoETransformerMLP(nn.Module):
     def __init__(self, num_expert: int = 32, d_model: int = 1024, d_hidden: int = 4096, activation=None,
                  expert_dp_comm: str = "none", expert_rank: int = 0, *, top_k: int = 2, world_size: int = 1,
                  moe_group=None, gate="naive", capacity_factor=None, capacity_mode: str = "switch",
-                 compute_dtype: Optional[torch.dtype] = None, gemm_variant: int = 4):
+                 compute_dtype: Optional[torch.dtype] = None, gemm_variant: Optional[int] = None):
         super().__init__()
         if activation is None:
             activation = nn.GELU()
@@ -219,7 +219,7 @@ class FMoETransformerMLP(nn.Module):
             self.gate = gate(d_model, num_expert, world_size, top_k)
         self.experts = _Expert(num_expert, d_model, d_hidden, activation, rank=expert_rank)
         self.compute_dtype = compute_dtype
-        self.gemm_variant = gemm_variant
+        self.gemm_variant = ops.DEFAULT_GEMM_VARIANT if gemm_variant is None else gemm_variant
         self.ep_chunks = 1  # micro-batches of the expert-parallel pipeline (ep.py); > 1 overlaps a2a with GEMMs
         self._fused_gelu, self._drop_p, self._generic_act = _parse_activation(activation)
         self.last_plan = None  # (idx, score, counts, offsets, pos, inv_pos) of the latest forward, for inspection
@@ -267,7 +267,7 @@ class FMoETransformerMLP(nn.Module):
         ok = (x.is_cuda and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine
               and tuple(norm.normalized_shape) == (self.d_model,) and self._fused_gelu
               and not (self._drop_p > 0 and self.training) and cd in (torch.float16, torch.bfloat16)
-              and self.gemm_variant == 4 and self.d_model % 64 == 0
+              and self.gemm_variant in (4, 9) and self.d_model % 64 == 0
               and not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())
                                                     or any(p.requires_grad for p in norm.parameters())))
               and ops.ln_router_supported(self.d_model, g.tot_expert, g.top_k))
@@ -303,13 +303,13 @@ class FMoETransformerMLP(nn.Module):
         w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
         b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
         b2 = ex.h4toh.bias.detach().float() if ex.h4toh.bias is not None else None
-        h = ops.grouped_gemm(xn16, w1, b1, offsets, ops.EPI_GELU, cd, variant=4, a_gather=pos, a_div=k)
+        h = ops.grouped_gemm(xn16, w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant, a_gather=pos, a_div=k)
         if k == 1:
             out = x2.clone() if cap >= 0 else torch.empty_like(x2)
             ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, x2.dtype, row_map=pos, row_scale=score.reshape(-1),
-                             out=out, variant=4, residual=x2)
+                             out=out, variant=self.gemm_variant, residual=x2)
         else:
-            y = ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, cd, variant=4)
+            y = ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, cd, variant=self.gemm_variant)
             out = ops.gather_combine(y, inv_pos, score, T, k, x2.dtype, residual=x2)
         return out.reshape(shape)
 
@@ -321,7 +321,7 @@ class FMoETransformerMLP(nn.Module):
         g = self.gate
         return (x.is_cuda and x.dtype == torch.float32 and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine
                 and tuple(norm.normalized_shape) == (self.d_model,) and self._fused_gelu and not self.training
-                and cd in (torch.float16, torch.bfloat16) and self.gemm_variant == 4 and self.d_model % 64 == 0
+                and cd in (torch.float16, torch.bfloat16) and self.gemm_variant in (4, 9) and self.d_model % 64 == 0
                 and not torch.is_grad_enabled() and type(g) is NaiveGate and not self.ep_active()
                 and ops.gate_ln_router_supported(self.d_model, g.tot_expert, g.top_k))
 
@@ -373,12 +373,12 @@ class FMoETransformerMLP(nn.Module):
         w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
         b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
         b2 = ex.h4toh.bias.detach().float() if ex.h4toh.bias is not None else None
-        h = ops.grouped_gemm(r["xn16"], w1, b1, offsets, ops.EPI_GELU, cd, variant=4, a_gather=pos, a_div=k)
+        h = ops.grouped_gemm(r["xn16"], w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant, a_gather=pos, a_div=k)
         if k == 1:
             ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, torch.float32, row_map=pos, row_scale=score.reshape(-1),
-                             out=out, variant=4, residual=out)
+                             out=out, variant=self.gemm_variant, residual=out)
         else:
-            y = ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, cd, variant=4)
+            y = ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, cd, variant=self.gemm_variant)
             ops.gather_combine(y, inv_pos, score, T, k, torch.float32, residual=out, out=out)
         return out.reshape(shape)
 

@@ -18,6 +18,10 @@ GATE_NAIVE, GATE_SWITCH = 0, 1
 EPI_NONE, EPI_GELU, EPI_GELU_GRAD = 0, 1, 2
 
 _DT = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+# grouped GEMM variant the modules use: 9 = the persistent kernel (one workgroup per CU walking tiles; auto tile height and
+# schedule), bit-identical to 4 = one workgroup per tile (kept for A/B: SLIMMOE_GEMM_VARIANT=4)
+import os as _os
+DEFAULT_GEMM_VARIANT = int(_os.environ.get("SLIMMOE_GEMM_VARIANT", "9"))
 
 
 def dtype_code(dt: torch.dtype) -> int:

@@ -8,6 +8,7 @@ patch.  It is the *caller* of the hot path, not the hot path: dense pieces run a
 """
 from __future__ import annotations
 
+import os
 from functools import partial
 from typing import Callable, Dict
 
@@ -108,6 +109,12 @@ class _HalfCache(StreamCache):
     def get(self, p: torch.Tensor) -> torch.Tensor:  # noqa: D102
         return super().get(id(p), param_version(p), lambda: p.detach().half())
 
+    def get_f32(self, p: torch.Tensor) -> torch.Tensor:
+        """f32 view of a (bias) parameter: the parameter itself unless it is stored in another dtype."""
+        if p.dtype == torch.float32:
+            return p.detach()
+        return super().get(("f32", id(p)), param_version(p), lambda: p.detach().float())
+
 
 def _half_cache(mod: nn.Module) -> "_HalfCache":
     hc = mod.__dict__.get("_half")
@@ -115,6 +122,27 @@ def _half_cache(mod: nn.Module) -> "_HalfCache":
         hc = mod.__dict__["_half"] = _HalfCache()
         mod.register_load_state_dict_post_hook(lambda m, _keys: m.__dict__["_half"].invalidate())
     return hc
+
+
+DENSE_GEMM = os.environ.get("SLIMMOE_DENSE_GEMM", "own")   # "own": the grouped MFMA GEMM (one group); "blas": F.linear (A/B)
+
+
+def _linear16(hc: "_HalfCache", x16: torch.Tensor, weight: torch.Tensor, bias, out_dtype=torch.float16, residual=None,
+              name: str = "dense_gemm"):
+    """``x16 @ weight^T + bias`` (+ residual) for fp16 rows ``x16 [M, K]`` on the hand-written grouped MFMA GEMM with a
+    single row group -- the dense projections around the MoE (qkv, attention output, patch embedding, classifier head:
+    models/vision_transformer.py:262-266, 276, 819, 847) -- returning ``[M, N]`` in ``out_dtype``.  Same arithmetic as
+    the fp16 GEMM autocast would run (f16 operands, f32 accumulate, one rounding).  Returns None when the shape is not
+    the kernel's (K % 64, N % 8), so the caller can fall back to ``F.linear``."""
+    from . import ops
+    M, K = x16.shape
+    N = weight.shape[0]
+    if DENSE_GEMM != "own" or K % 64 or N % 8 or M == 0 or not x16.is_contiguous():
+        return None
+    w = hc.get(weight).reshape(N, K)[None]
+    b = hc.get_f32(bias)[None] if bias is not None else None
+    return ops.grouped_gemm(x16, w, b, hc.offsets(M, x16.device), ops.EPI_NONE, out_dtype, residual=residual,
+                            variant=ops.DEFAULT_GEMM_VARIANT, prof_name=name)
 
 
 class Attention(nn.Module):
@@ -138,7 +166,9 @@ class Attention(nn.Module):
         if x.dtype == torch.float16 and _autocast_half_inference(x):
             # same arithmetic as autocast (fp16 GEMM operands), without re-casting the weights on every call
             hc = _half_cache(self)
-            qkv = F.linear(x, hc.get(self.qkv.weight), hc.get(self.qkv.bias) if self.qkv.bias is not None else None)
+            qkv = _linear16(hc, x.reshape(B * N, C), self.qkv.weight, self.qkv.bias, name="qkv_gemm")
+            if qkv is None:
+                qkv = F.linear(x, hc.get(self.qkv.weight), hc.get(self.qkv.bias) if self.qkv.bias is not None else None)
             from . import ops
             hd = C // self.num_heads
             if ops.attention_supported(N, hd) and qkv.is_contiguous():
@@ -150,12 +180,10 @@ class Attention(nn.Module):
             if residual is not None and C % 64 == 0 and residual.dtype == torch.float32 and residual.is_contiguous():
                 # projection + bias + residual add in one launch of the grouped MFMA GEMM (a single group):
                 # residual + proj(o), f32 out -- the same arithmetic as the unfused `x + attn(...)`
-                from . import ops
-                offs = hc.offsets(B * N, x.device)
-                pb = self.proj.bias.detach().float()[None] if self.proj.bias is not None else None
-                out = ops.grouped_gemm(o, hc.get(self.proj.weight)[None], pb, offs, ops.EPI_NONE, torch.float32,
-                                       residual=residual.reshape(B * N, C), variant=4, prof_name="attn_proj_gemm")
-                return out.reshape(B, N, C), True
+                out = _linear16(hc, o, self.proj.weight, self.proj.bias, torch.float32,
+                                residual=residual.reshape(B * N, C), name="attn_proj_gemm")
+                if out is not None:
+                    return out.reshape(B, N, C), True
             return F.linear(o, hc.get(self.proj.weight), hc.get(self.proj.bias)).reshape(B, N, C), False
         return self._forward(x), False
 
@@ -274,8 +302,11 @@ class VisionTransformer(nn.Module):
             p16 = torch.empty((B, gh, gw, C, ph, pw), dtype=torch.float16, device=x.device)
             p16.copy_(x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5))
             w = hc.get(pe.proj.weight).reshape(pe.proj.weight.shape[0], -1)
-            tok = F.linear(p16.reshape(B, gh * gw, C * ph * pw), w,
-                           hc.get(pe.proj.bias) if pe.proj.bias is not None else None)
+            tok = _linear16(hc, p16.reshape(B * gh * gw, C * ph * pw), pe.proj.weight, pe.proj.bias, name="patch_embed_gemm")
+            if tok is None:
+                tok = F.linear(p16.reshape(B, gh * gw, C * ph * pw), w,
+                               hc.get(pe.proj.bias) if pe.proj.bias is not None else None)
+            tok = tok.reshape(B, gh * gw, -1)
             out = torch.empty((B, gh * gw + 1, tok.shape[-1]), dtype=torch.float32, device=x.device)
             torch.add(tok, self.pos_embed[:, 1:], out=out[:, 1:])
             out[:, 0] = self.cls_token[0, 0] + self.pos_embed[0, 0]
@@ -388,7 +419,11 @@ class VisionTransformer(nn.Module):
         f = self.forward_features(x)
         if isinstance(self.head, nn.Linear) and _autocast_half_inference(f):
             hc = _half_cache(self)  # what autocast computes, minus the per-call weight casts
-            return F.linear(f.to(torch.float16), hc.get(self.head.weight),
+            f16 = f.to(torch.float16)
+            out = _linear16(hc, f16.reshape(-1, f16.shape[-1]), self.head.weight, self.head.bias, name="head_gemm") if f16.dim() == 2 else None
+            if out is not None:
+                return out
+            return F.linear(f16, hc.get(self.head.weight),
                             hc.get(self.head.bias) if self.head.bias is not None else None)
         return self.head(f)
 
