@@ -207,6 +207,35 @@ size_t smoe_group_colsum_workspace_bytes(int64_t n_rows_max, int E, int C);
 int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int64_t n_rows_max, int C, float* out,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- expert exchange (expert parallelism over RCCL / xGMI) ----------------------------------------------------------
+ * Replaces fmoe_cuda.ensure_nccl / expert_exchange / global_scatter / global_gather (reached from
+ * models/resMoE.py:27-29 when world_size > 1).  A context owns ONE RCCL communicator (built from a unique-id blob that
+ * rank 0 creates with smoe_unique_id and the caller distributes by whatever means it has -- MPI, a file, torch's store),
+ * ONE communication stream and two events.  Every exchange is enqueued on the context's stream behind an event recorded
+ * on the caller's `stream` (so it sees the send buffer the compute stream produced) and ends with an event the caller's
+ * stream waits on: immediately when wait != 0, or later through smoe_a2a_wait -- in between the compute stream is free
+ * to run other work (the expert GEMMs of another micro-batch) while rows move over xGMI.  All peers' transfers of one
+ * call are posted as one RCCL group: on the point-to-point xGMI mesh every link then carries its pair's rows concurrently.
+ * RCCL is resolved at run time from the librccl.so already in the process (or the system's): no link-time dependency.
+ *   smoe_a2a_counts : send_counts[w*E_local + e] = rows this rank routes to rank w's local expert e  ->  recv_counts[w*E_local
+ *                     + e] = rows rank w routes to this rank's local expert e   (i32 [W*E_local], device memory)
+ *   smoe_a2a_tokens : all-to-all-v of d-element rows; `send` holds the rows for rank 0, 1, ... (send_rows[w] each: the
+ *                     expert-sorted send buffer has that order), `recv` receives recv_rows[w] rows from rank w, rank-major
+ *                     (the [source rank][local expert] layout smoe_grouped_gemm takes through group_expert);
+ *                     send_rows / recv_rows are HOST i64 [W]                                                        */
+typedef struct smoe_ctx smoe_ctx;
+int smoe_unique_id_bytes(void);
+int smoe_unique_id(void* out_id);
+int smoe_ctx_create(const void* unique_id, int world_size, int rank, smoe_ctx** out);   /* on the current device */
+int smoe_ctx_destroy(smoe_ctx* ctx);
+void* smoe_ctx_comm_stream(smoe_ctx* ctx);
+int smoe_ctx_world_size(smoe_ctx* ctx);
+int smoe_ctx_rank(smoe_ctx* ctx);
+int smoe_a2a_counts(smoe_ctx* ctx, const int32_t* send_counts, int32_t* recv_counts, int E_local, void* stream, int wait);
+int smoe_a2a_tokens(smoe_ctx* ctx, const void* send, const int64_t* send_rows, void* recv, const int64_t* recv_rows, int d,
+                    int dtype, void* stream, int wait);
+int smoe_a2a_wait(smoe_ctx* ctx, void* stream);
+
 /* ---- optimizer side of the training step (engine.py:68-74: timm NativeScaler around torch.optim.AdamW; SURVEY.md 8f
  * rank 3).  Everything stays on the device -- loss scale, non-finite flag, clip coefficient, step count -- so a step has
  * no host sync, and a gradient is read twice in all (norm pass, update pass) instead of four times.

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: the library resolves libamd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -60,6 +60,16 @@ SIGNATURES = {
                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_amp_update": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
     "smoe_step_advance": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "smoe_unique_id_bytes": (c_int, []),
+    "smoe_unique_id": (c_int, [c_void_p]),
+    "smoe_ctx_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "smoe_ctx_destroy": (c_int, [c_void_p]),
+    "smoe_ctx_comm_stream": (c_void_p, [c_void_p]),
+    "smoe_ctx_world_size": (c_int, [c_void_p]),
+    "smoe_ctx_rank": (c_int, [c_void_p]),
+    "smoe_a2a_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
+    "smoe_a2a_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int]),
+    "smoe_a2a_wait": (c_int, [c_void_p, c_void_p]),
     "smoe_zero_row_output": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 

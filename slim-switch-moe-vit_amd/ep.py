@@ -22,6 +22,7 @@ are exercised on CPU with the gloo backend in tests/test_ep_gloo.py.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -37,6 +38,30 @@ class _DoneWork:
         return True
 
 
+_ctx_cache = {}
+
+
+def _cabi_context(group, device):
+    """The library's own RCCL communicator for this group (SLIMMOE_EP_TRANSPORT=cabi), created once per (group, device)."""
+    from .comm import ExchangeContext
+    key = (id(group) if group is not None else 0, str(device))
+    ctx = _ctx_cache.get(key)
+    if ctx is None:
+        ctx = _ctx_cache[key] = ExchangeContext.from_process_group(group, device)
+    return ctx
+
+
+class _CtxWork:
+    """Work handle of an exchange on the library's communication stream: wait() fences torch's current stream."""
+
+    def __init__(self, ctx, ref):
+        self.ctx, self.ref = ctx, ref
+
+    def wait(self):
+        self.ctx.wait_stream(self.ref)
+        return True
+
+
 def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None, async_op: bool = False):
     """``dist.all_to_all_single`` on the group's own transport.  RCCL ("nccl") moves device buffers directly; a gloo
     group cannot take CUDA tensors through all-to-all, so there the buffers are staged through the host -- slow, but
@@ -48,6 +73,18 @@ def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, 
         dist.all_to_all_single(h_out, h_in, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
         out.copy_(h_out)
         return _DoneWork() if async_op else None
+    if inp.is_cuda and os.environ.get("SLIMMOE_EP_TRANSPORT", "torch") == "cabi":
+        # the C-ABI transport (include/slimmoe.h smoe_a2a_*): own communicator, own stream, event fences
+        ctx = _cabi_context(group, inp.device)
+        W = ctx.world_size
+        rows_in = inp.reshape(inp.shape[0], -1) if inp.dim() > 1 else inp.reshape(-1, 1)
+        rows_out = out.reshape(out.shape[0], -1) if out.dim() > 1 else out.reshape(-1, 1)
+        if not rows_in.is_contiguous():
+            rows_in = rows_in.contiguous()
+        sr = in_splits if in_splits is not None else [rows_in.shape[0] // W] * W
+        rr = out_splits if out_splits is not None else [rows_out.shape[0] // W] * W
+        ctx.all_to_all_rows(rows_in, sr, rr, wait=not async_op, out=rows_out)
+        return _CtxWork(ctx, out) if async_op else None
     return dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
                                   async_op=async_op)
 

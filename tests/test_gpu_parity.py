@@ -733,3 +733,54 @@ def test_persistent_gemm_equals_one_workgroup_per_tile_kernel_bitwise(variant):
         ops.grouped_gemm(hk, w2k, b2, offsets, ops.EPI_NONE, torch.float32, row_map=pos, row_scale=score, out=o_ps,
                          variant=variant, residual=o_ps)
         assert torch.equal(o_ps, o_ref)
+
+
+def test_cabi_exchange_context_world_of_one_and_ep_transport():
+    """include/slimmoe.h smoe_ctx_* / smoe_a2a_*: RCCL communicator from a unique-id blob, dedicated communication
+    stream, event fences.  One GPU = a world of one rank (what hardware this box has): counts and rows come back
+    unchanged, blocking and split (wait=False + wait_stream) forms; then the expert-parallel forward on this
+    transport (SLIMMOE_EP_TRANSPORT=cabi) reproduces the torch.distributed transport bit for bit."""
+    import socket
+    import torch.distributed as dist
+    from slim_switch_moe_vit_amd.comm import ExchangeContext
+    from slim_switch_moe_vit_amd import ep
+
+    ctx = ExchangeContext(ExchangeContext.new_unique_id(), 1, 0, torch.device(DEV))
+    try:
+        cnt = torch.tensor([5, 0, 7, 1], dtype=torch.int32, device=DEV)
+        assert torch.equal(ctx.exchange_counts(cnt, 4), cnt)
+        rows = torch.randn(1000, 192, generator=_gen(1)).half().to(DEV)
+        got = ctx.all_to_all_rows(rows, [777], [777])
+        assert torch.equal(got, rows[:777])
+        big = torch.randn(50000, 768, generator=_gen(2)).half().to(DEV)
+        got2 = ctx.all_to_all_rows(big, [50000], [50000], wait=False)   # rows travel on the context's stream ...
+        busy = (big.float() @ torch.randn(768, 64, device=DEV)).sum()   # ... while this stream computes
+        ctx.wait_stream(got2)
+        assert torch.equal(got2, big) and torch.isfinite(busy)
+        empty = ctx.all_to_all_rows(rows[:0], [0], [0])
+        assert empty.shape == (0, 192)
+    finally:
+        ctx.close()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        d, h, E, T = 192, 768, 8, 2500
+        x, wg, bg, w1, b1, w2, b2 = _mk(T, d, h, E, seed=61)
+        mod = _load_module(sm.CustomizedMoEMLP(d, h, E, 2, 0.0), wg, bg, w1, b1, w2, b2)
+        mod.force_ep, mod.ep_chunks = True, 2
+        with torch.no_grad():
+            ref = mod(x.to(DEV))
+            os.environ["SLIMMOE_EP_TRANSPORT"] = "cabi"
+            try:
+                got = mod(x.to(DEV))
+            finally:
+                os.environ.pop("SLIMMOE_EP_TRANSPORT", None)
+        assert len(ep._ctx_cache) == 1, "the C-ABI transport must have been the one that ran"
+        assert torch.equal(got, ref)
+    finally:
+        for c in ep._ctx_cache.values():
+            c.close()
+        ep._ctx_cache.clear()
+        dist.destroy_process_group()
