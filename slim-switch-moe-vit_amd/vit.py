@@ -141,8 +141,11 @@ def _linear16(hc: "_HalfCache", x16: torch.Tensor, weight: torch.Tensor, bias, o
         return None
     w = hc.get(weight).reshape(N, K)[None]
     b = hc.get_f32(bias)[None] if bias is not None else None
+    # a handful of rows (the classifier head sees one row per image): 128 x 128 tiles spread the few output tiles over
+    # more CUs than the 320 x 256 tile of the big GEMMs would
+    variant = 1 if M <= 1024 else ops.DEFAULT_GEMM_VARIANT
     return ops.grouped_gemm(x16, w, b, hc.offsets(M, x16.device), ops.EPI_NONE, out_dtype, residual=residual,
-                            variant=ops.DEFAULT_GEMM_VARIANT, prof_name=name)
+                            variant=variant, prof_name=name)
 
 
 class Attention(nn.Module):

@@ -32,6 +32,8 @@ def test_adamw_kernel_matches_torch_adamw(gdt):
         grads = _params(100 + it, SHAPES)
         for p, q, g in zip(ours, ref, grads):
             gg = g.to(gdt)
+            if gdt != torch.float32:
+                p.grad_dtype = gdt          # torch >= 2.10: a gradient dtype other than the parameter's must be declared
             p.grad = gg.to(DEV)
             q.grad = gg.double()
         a.step()
