@@ -69,27 +69,36 @@ class ExchangeContext:
                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """all-to-all-v of whole rows (``rows[:sum(send_rows)]`` split by destination rank); returns the receive buffer.
         With ``wait=False`` the caller's stream does NOT wait for the exchange: call ``wait_stream()`` before reading it."""
-        ops._chk(rows, "rows", ndim=2)
+        ops._chk(rows, "rows", ndim=2, align=4)
         W = self.world_size
         if len(send_rows) != W or len(recv_rows) != W:
             raise RuntimeError("send_rows / recv_rows: one entry per rank")
         if out is None:
             out = torch.empty((int(sum(recv_rows)), rows.shape[1]), dtype=rows.dtype, device=rows.device)
         else:
-            ops._chk(out, "out", rows.dtype, 2)
+            ops._chk(out, "out", rows.dtype, 2, align=4)
             if out.shape[0] < int(sum(recv_rows)) or out.shape[1] != rows.shape[1]:
                 raise RuntimeError("out: too small for the received rows")
         s_arr = (ctypes.c_int64 * W)(*[int(v) for v in send_rows])
         r_arr = (ctypes.c_int64 * W)(*[int(v) for v in recv_rows])
         rc = _lib.load().smoe_a2a_tokens(self._h, rows.data_ptr() if rows.numel() else None, s_arr,
                                          out.data_ptr() if out.numel() else None, r_arr, rows.shape[1],
-                                         ops.dtype_code(rows.dtype), ops._stream(rows), 1 if wait else 0)
+                                         self._size_code(rows), ops._stream(rows), 1 if wait else 0)
         _lib.check(rc, "smoe_a2a_tokens")
         # both buffers are in use on the context's stream: keep the allocator from recycling them under it
         cs = torch.cuda.ExternalStream(_lib.load().smoe_ctx_comm_stream(self._h), device=rows.device)
         rows.record_stream(cs)
         out.record_stream(cs)
         return out
+
+    @staticmethod
+    def _size_code(t: torch.Tensor) -> int:
+        """Rows travel as bytes: any 2- or 4-byte element type maps to the dtype code of that size."""
+        if t.element_size() == 4:
+            return ops.F32
+        if t.element_size() == 2:
+            return ops.F16
+        raise TypeError(f"all_to_all_rows: element size {t.element_size()} not supported (2 or 4 bytes)")
 
     def wait_stream(self, ref: torch.Tensor):
         """Make torch's current stream (on ``ref``'s device) wait for the context's last exchange."""
