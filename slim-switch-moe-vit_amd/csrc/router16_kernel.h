@@ -263,7 +263,12 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             f32x4 v = xv[j];
-            if (GATE != 0 && skip && ga.zero_out) v += *reinterpret_cast<const f32x4*>(ga.zero_out + u * 4 + 64 * j);
+            if constexpr (GATE != 0) {
+              if (ga.zero_out) {  // wave-uniform; the per-token part is a select (four tokens of a wave may differ)
+                const f32x4 z = *reinterpret_cast<const f32x4*>(ga.zero_out + u * 4 + 64 * j);
+                v += skip ? z : f32x4{0.f, 0.f, 0.f, 0.f};
+              }
+            }
             *reinterpret_cast<f32x4*>(xn32 + rowoff + 64 * j) = v;
           }
         }
@@ -392,7 +397,9 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3
 #pragma unroll
       for (int r = 0; r < R16_MAX_K; ++r)
         if (r + 1 < kc) ambiguous |= !((cval[r] - cval[r + 1]) > bound);
-      redo = ambiguous || gate_ambiguous;
+      // an all-zero row (a skipped token, or a genuinely zero input) has logits that ARE the biases -- no arithmetic, no
+      // rounding: a tie between biases is resolved by the lowest id here exactly as the f64 pass would resolve it
+      redo = (ambiguous && xs > 0.f) || gate_ambiguous;
       if (redo && live && u == 0) redo_list[atomicAdd(redo_count, 1)] = (int32_t)t;
     }
     if constexpr (GATE != 0) {
