@@ -187,6 +187,8 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3
     g_bias = (float)lds_gz[2];
   }
 
+  int my_skips = 0;  // skipped tokens this wave decided (GATE): ONE global atomic per workgroup at the end -- thousands of
+                     // waves adding to the single counter word one by one serialise at the memory side (~100 us per launch)
   while (it0 < n_items) {
     const int64_t t = t_next;
     const bool live = live_next;
@@ -288,10 +290,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3
         ga.mask[t * 2] = skip ? 1.f : 0.f;
         ga.mask[t * 2 + 1] = skip ? 0.f : 1.f;
       }
-      if (ga.skip_count) {
-        const unsigned long long m = __ballot(live && u == 0 && skip && !redo);
-        if (lane == 0 && m) atomicAdd(ga.skip_count, __popcll(m));
-      }
+      my_skips += __popcll(__ballot(live && u == 0 && skip && !redo));
       if (it0 < n_items) fetch(it0);
       continue;
     } else {
@@ -407,10 +406,8 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3
         ga.mask[t * 2] = skip ? 1.f : 0.f;
         ga.mask[t * 2 + 1] = skip ? 0.f : 1.f;
       }
-      if (ga.skip_count) {  // tokens handed to the redo pass are counted there, by their final decision
-        const unsigned long long m = __ballot(live && u == 0 && skip && !redo);
-        if (lane == 0 && m) atomicAdd(ga.skip_count, __popcll(m));
-      }
+      // tokens handed to the redo pass are counted there, by their final decision
+      my_skips += __popcll(__ballot(live && u == 0 && skip && !redo));
     }
     if (live && u == 0) {
       if (gate_kind == SMOE_GATE_NAIVE) {
@@ -448,6 +445,17 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3
       }
     }
     }  // ROUTE
+  }
+  if constexpr (GATE != 0) {
+    if (ga.skip_count) {   // kernel-uniform
+      __syncthreads();     // the weight image in LDS is dead from here on: reuse its first word
+      int* wg_cnt = reinterpret_cast<int*>(smem);
+      if (tid == 0) *wg_cnt = 0;
+      __syncthreads();
+      if (lane == 0 && my_skips) atomicAdd(wg_cnt, my_skips);
+      __syncthreads();
+      if (tid == 0 && *wg_cnt) atomicAdd(ga.skip_count, *wg_cnt);
+    }
   }
 }
 
