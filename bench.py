@@ -307,7 +307,9 @@ def main():
         names = ({"grouped_gemm_fc1": "grouped_gemm_ps<f16,f16,5,false> = GEMM-1 (K 768, gathered rows, bias + GELU)",
                   "grouped_gemm_fc2": "grouped_gemm_ps<f16,f32,5,true> = GEMM-2 (K 3072, combine + residual)",
                   "attn_proj_gemm": "grouped_gemm_ps<f16,f32,5,false> = attention projection (K 768, + residual)",
-                  "qkv_gemm": "grouped_gemm_ps<f16,f16,5,false> (shared with GEMM-1) = qkv projection (K 768, N 2304)"}
+                  "qkv_gemm": "grouped_gemm_ps<f16,f16,4,false> = qkv projection (K 768, N 2304; 256-row tiles)",
+                  "patch_embed_gemm": "grouped_gemm_ps<f16,f16,5,false> (the GEMM-1 instantiation: its rocprof average "
+                                      "includes these launches) = patch embedding (K 768, N 768)"}
                  if pers else
                  {"grouped_gemm_fc1": "grouped_gemm_pp256<f16,f16,0,0,5> = GEMM-1 (K 768, GELU)",
                   "grouped_gemm_fc2": "grouped_gemm_pp256<f16,f32,16,0,5> = GEMM-2 (K 3072, combine + residual)",
