@@ -94,8 +94,11 @@ template <typename XT, int NJ, bool LN, typename NT, int EB>
 int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, const float* noise, int64_t T, int d,
              int E, int k, int gate_kind, int force_f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score,
              float* logits_out, float* probs, hipStream_t s) {
+  // 32 experts: the f32 weight image (96-128 KB) leaves room for ONE workgroup per CU; 512 threads put 8 waves behind it
+  // instead of 4 (the f32 pass only: the f64 redo pass would spill at that size and handles a handful of tokens)
+  constexpr int NTH = EB > 16 ? 512 : R16_THREADS;
   const size_t smem = router16_smem<NJ, LN, EB, 0>();
-  const int64_t tok_per_block = (R16_THREADS / 64) * 4;
+  const int64_t tok_per_block = (NTH / 64) * 4;
   int64_t need = (T + tok_per_block - 1) / tok_per_block;
   // <= 768 workgroups (3 resident per CU; 512 = 2 per CU for the 16-expert image: the LDS weight image is loaded once
   // per workgroup), every workgroup the same number of 16-token groups
@@ -103,11 +106,12 @@ int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, 
   const int64_t iters = (need + max_wg - 1) / max_wg;
   const int grid = (int)(need < 1 ? 1 : (need + iters - 1) / (iters < 1 ? 1 : iters));
   if (smem > 64 * 1024) {  // 16 experts x d 1024 (+ LayerNorm vectors): above the default dynamic-LDS limit
-    SMOE_ENSURE_SMEM(router16_kernel<XT, NJ, 0, LN, NT, EB>);
-    SMOE_ENSURE_SMEM(router16_kernel<XT, NJ, 1, LN, NT, EB>);
+    SMOE_ENSURE_SMEM(router16_kernel<XT, NJ, 0, LN, NT, EB, 0, NTH>);
+    SMOE_ENSURE_SMEM(router16_kernel<XT, NJ, 1, LN, NT, EB, 0, R16_THREADS>);
   }
 #define R16_LAUNCH(MODE, GRID, RC, RL)                                                                               \
-  hipLaunchKernelGGL((router16_kernel<XT, NJ, MODE, LN, NT, EB>), dim3(GRID), dim3(R16_THREADS), smem, s, (const XT*)x,  \
+  hipLaunchKernelGGL((router16_kernel<XT, NJ, MODE, LN, NT, EB, 0, (MODE == 0 ? NTH : R16_THREADS)>), dim3(GRID),       \
+                     dim3(MODE == 0 ? NTH : R16_THREADS), smem, s, (const XT*)x,                                      \
                      ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, noise, T, d, E, k, gate_kind, RC, RL, idx,   \
                      score, logits_out, probs, SkipGateArgs{})
   if (force_f64 && !LN) {

@@ -72,12 +72,14 @@ template <typename NT> __device__ __forceinline__ void store4_16(NT* dst, const 
   }
 }
 
+// NTH = threads per workgroup: 256, or 512 for the 16- / 32-expert images (their f32 weight image fills most of the LDS, so
+// only one or two workgroups fit a CU: twice the waves behind the same image doubles what is in flight per CU).
 // LN = fused LayerNorm in front (models/vision_transformer.py:321 `mlp(norm2(x))`, resMoE.py:126 / 137): the row is
 // normalised in registers (two-pass mean / variance over the 16-lane row, f32), written once as the 16-bit
 // operand image the GEMMs read (xn16) and optionally as f32 (xn32), and routed / gated on its f32 value.
 // The f64 redo pass recomputes the same normalisation with the same lane layout, hence bit-identical inputs.
-template <typename XT, int NJ, int MODE, bool LN, typename NT, int EB, int GATE = 0>
-__global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3 : 4) : (EB <= 16 ? 2 : 1)) : (EB <= 16 ? 2 : 1))) void router16_kernel(
+template <typename XT, int NJ, int MODE, bool LN, typename NT, int EB, int GATE = 0, int NTH = R16_THREADS>
+__global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3 : 4) : (EB <= 16 ? 2 : 1)) : (EB <= 16 ? 2 : 1))) void router16_kernel(
     const XT* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
     NT* __restrict__ xn16, float* __restrict__ xn32, const float* __restrict__ wg, const float* __restrict__ bg,
     const float* __restrict__ noise, int64_t T, int d, int E, int k, int gate_kind,
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3
     n_items = *redo_count;
     n_items = n_items < 0 ? 0 : (n_items > T ? T : n_items);
   }
-  const int64_t slot_gid = ((int64_t)blockIdx.x * (R16_THREADS / 64) + wave) * 4 + q;
-  const int64_t slot_stride = (int64_t)gridDim.x * (R16_THREADS / 64) * 4;
+  const int64_t slot_gid = ((int64_t)blockIdx.x * (NTH / 64) + wave) * 4 + q;
+  const int64_t slot_stride = (int64_t)gridDim.x * (NTH / 64) * 4;
   // The row of the NEXT item is fetched as soon as the current one's registers are free -- the first one before
   // the weight staging below, so the HBM latency of the first rows runs under the prologue.  Dead slots of the
   // last group re-read the last item (no predication on the loads; only stores are guarded).
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3
   if (it0 < n_items) fetch(it0);
 
   if constexpr (ROUTE) {
-    for (int i = tid * 4; i < EB * d; i += R16_THREADS * 4) {
+    for (int i = tid * 4; i < EB * d; i += NTH * 4) {
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (i / d < E) v = *reinterpret_cast<const f32x4*>(wg + i);
       *reinterpret_cast<f32x4*>(lds_w + i) = v;
@@ -137,17 +139,17 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3
     if (tid < EB) lds_bias[tid] = (bg && tid < E) ? bg[tid] : 0.f;
   }
   if (LN) {
-    for (int i = tid; i < d; i += R16_THREADS) {
+    for (int i = tid; i < d; i += NTH) {
       lds_g[i] = ln_g ? ln_g[i] : 1.f;
       lds_be[i] = ln_b ? ln_b[i] : 0.f;
     }
   }
   if constexpr (GATE != 0) {
-    for (int i = tid; i < d; i += R16_THREADS) lds_gw[i] = ga.w[i];
+    for (int i = tid; i < d; i += NTH) lds_gw[i] = ga.w[i];
   }
   __syncthreads();
   if constexpr (ROUTE) {
-    for (int e = wave; MODE == 0 && e < EB; e += R16_THREADS / 64) {  // squared row norms, one wave per expert row
+    for (int e = wave; MODE == 0 && e < EB; e += NTH / 64) {  // squared row norms, one wave per expert row
       float s = 0.f;
       for (int c = lane; c < d; c += 64) s = fmaf(lds_w[e * d + c], lds_w[e * d + c], s);
 #pragma unroll
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(R16_THREADS, (MODE == 0 ? (EB <= 8 ? (GATE != 0 ? 3
     }
   }
   if constexpr (GATE != 0) {
-    if (wave == R16_THREADS / 64 - 1) {  // the last wave: |gate_w|^2, logit(threshold), bias
+    if (wave == NTH / 64 - 1) {  // the last wave: |gate_w|^2, logit(threshold), bias
       float s = 0.f;
       for (int c = lane; c < d; c += 64) s = fmaf(lds_gw[c], lds_gw[c], s);
 #pragma unroll
