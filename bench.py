@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--gemm-variant", type=int, default=None,
                     help="grouped-GEMM kernel (default: ops.DEFAULT_GEMM_VARIANT = 9, the persistent kernel; 4 = one "
                          "workgroup per tile, bit-identical results)")
+    ap.add_argument("--compute-streams", type=int, default=1, choices=[1, 2],
+                    help="2 = the two halves of the batch on two compute streams (VisionTransformer.compute_streams; "
+                         "opt-in, single rank only)")
     ap.add_argument("--force-ep", action="store_true",
                     help="diagnostic: drive the expert-parallel code path on one GPU (world of one rank)")
     return ap.parse_args()
@@ -85,6 +88,7 @@ def build_model(args, world, rank, device):
             # the head is zero-initialised in the reference (vision_transformer.py:859-861); give it signal
         torch.nn.init.trunc_normal_(model.head.weight, std=0.02, a=-2, b=2, generator=g)
     model.ep_micro_batches = max(1, args.ep_micro_batches)
+    model.compute_streams = args.compute_streams if world == 1 else 1
     sd_cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -342,7 +346,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"ViT-B/16 Switch-MoE E={args.experts} top-1, 224^2, batch {args.batch}/GPU, "
                                    f"full eval forward (12 blocks: attention + MoE MLP), fp16 autocast",
-                       "global_batch": args.batch * world, "tokens_per_image": 197,
+                       "global_batch": args.batch * world, "tokens_per_image": 197, "compute_streams": args.compute_streams,
                        "parallelism": ("single" if not args.force_ep else f"single (EP code path forced, {args.ep_micro_batches} interleaved micro-batches)") if world == 1 else f"ep{world} (experts/{world} per rank, all-to-all, {args.ep_micro_batches} interleaved micro-batches)"},
             "roofline": roofline,
             "kernels": kernels,
