@@ -95,6 +95,26 @@ def build_model(args, world, rank, device):
     return model.to(device).eval(), sd_cpu
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the cgroup quota when there is one (a GPU box hands a container a share of the
+    host, e.g. 16 of 256 logical CPUs -- running 128 torch threads on that share is slower than running 16), else the
+    affinity mask / os.cpu_count()."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(sd, images, seconds):
     """The CPU oracle (oracle/moe_oracle.py: 'port' of the path, fp32 torch on ALL host cores torch sees) on a bounded
     sample of the same workload: one warm-up forward, then >= 5 timed forwards of the same batch (3 if a forward takes
@@ -102,11 +122,13 @@ def cpu_baseline(sd, images, seconds):
     from oracle import moe_oracle as mo
 
     n = images.shape[0]
+    threads = min(torch.get_num_threads(), host_cpu_share())
+    torch.set_num_threads(threads)
     with torch.no_grad():
         t0 = time.perf_counter()
         logits = mo.vit_forward(images, sd, depth=12, num_heads=12, k=1, residual_moe=False)
         first = time.perf_counter() - t0
-        iters = 5 if first * 5 <= 2.0 * seconds else 3
+        iters = 5 if first * 5 <= 2.0 * seconds else (3 if first * 3 <= 2.0 * seconds else 2)
         times = []
         for _ in range(iters):
             t0 = time.perf_counter()
@@ -114,7 +136,7 @@ def cpu_baseline(sd, images, seconds):
             times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return n / med, logits, {"iters": iters, "first_call_s": round(first, 3), "median_s": round(med, 3),
+    return n / med, logits, {"iters": iters, "threads": threads, "first_call_s": round(first, 3), "median_s": round(med, 3),
                              "min_s": round(times[0], 3), "max_s": round(times[-1], 3)}
 
 
@@ -360,10 +382,10 @@ def main():
             out["expert_parallel"] = ep_info
         if world == 1 and sd_cpu is not None:
             ips, cpu_logits, info = cpu_baseline(sd_cpu, images_cpu[: args.cpu_batch], args.cpu_seconds)
-            out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+            out["cpu_baseline"] = {"value": round(ips, 3), "unit": "images/s", "cores": info["threads"],
                                    "kind": "port",
-                                   "sample": f"oracle vit_forward (fp32 torch CPU, torch.get_num_threads() = "
-                                             f"{torch.get_num_threads()} of os.cpu_count() = {os.cpu_count()}), same model, "
+                                   "sample": f"oracle vit_forward (fp32 torch CPU, {info['threads']} threads = this "
+                                             f"container's CPU share of os.cpu_count() = {os.cpu_count()}), same model, "
                                              f"batch {args.cpu_batch}, median of {info['iters']} forwards "
                                              f"({info['median_s']} s; min {info['min_s']}, max {info['max_s']})"}
             out["speedup_vs_cpu"] = round(out["value"] / ips, 1)
