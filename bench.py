@@ -43,7 +43,7 @@ def parse():
                          "count read-backs and all-to-alls of one run under the other's compute (1 = off; 0 = time "
                          "1, 2 and 3 during warm-up and keep the fastest -- the right depth depends on the link rate)")
     ap.add_argument("--cpu-batch", type=int, default=128, help="images in the CPU-oracle sample")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU budget: 5 timed forwards if they fit ~2x this, else 3")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget: 5 timed forwards if they fit ~2x this, else 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=None,
                     help="grouped-GEMM kernel (default: ops.DEFAULT_GEMM_VARIANT = 9, the persistent kernel; 4 = one "
