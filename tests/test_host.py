@@ -167,3 +167,52 @@ def test_expert_parameters_are_tagged_and_kept_out_of_ddp():
     assert set(names) <= set(m._ddp_params_and_buffers_to_ignore)
     single = sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=5, depth=1)
     assert sm.ddp_ignore_expert_parameters(single) == []            # single rank: ordinary data parallelism is right
+
+
+def test_adamw_and_native_scaler_cpu_composition_matches_torch():
+    """optim.AdamW / optim.NativeScaler on CPU tensors take the torch composition (the HIP kernels need the GPU): same
+    numbers as torch.optim.AdamW stepped through unscale -> clip_grad_norm_ -> step -> update, a non-finite step is
+    skipped and backs the scale off, the state dict has GradScaler's keys."""
+    torch.manual_seed(0)
+    a = torch.nn.Linear(7, 5)
+    b = torch.nn.Linear(7, 5)
+    b.load_state_dict(a.state_dict())
+    oa = sm.AdamW(a.parameters(), lr=1e-2, weight_decay=0.05)
+    ob = torch.optim.AdamW(b.parameters(), lr=1e-2, weight_decay=0.05)
+    sc = sm.NativeScaler(init_scale=256.0, growth_interval=2)
+    g = torch.Generator().manual_seed(1)
+    scales = []
+    for it in range(5):
+        x = torch.randn(16, 7, generator=g) * 3
+        la = a(x).square().mean()
+        if it == 2:
+            la = la * float("inf")
+        oa.zero_grad()
+        sc(la, oa, clip_grad=0.3, parameters=a.parameters())
+        scales.append(sc.get_scale())
+        if it == 2:
+            continue
+        ob.zero_grad()
+        b(x).square().mean().backward()
+        torch.nn.utils.clip_grad_norm_(b.parameters(), 0.3)
+        ob.step()
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(p, q, rtol=0, atol=1e-6)
+    assert scales == [256.0, 512.0, 256.0, 256.0, 512.0], scales
+    assert set(sc.state_dict()) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+
+
+def test_gate_threshold_schedule_and_counters_on_cpu():
+    """Gate.step anneals `_threshold` towards `threshold` (main.py:812-815 calls it every iteration), never below it;
+    the CPU composition counts skipped tokens; masks are exactly 0 / 1 and sum to 1."""
+    gate = sm.Gate(16, 1.0, target_threshold=0.7, starting_threshold=0.9)
+    for _ in range(5):
+        gate.step(torch.tensor(0.06))
+    assert abs(float(gate._threshold) - 0.7) < 1e-6
+    gate.eval()
+    x = torch.randn(2, 9, 16, generator=torch.Generator().manual_seed(0)) * 4
+    m = gate(x)
+    assert m.shape == (2, 9, 2) and torch.all((m == 0) | (m == 1)) and torch.all(m.sum(-1) == 1)
+    assert gate._total_tokens == 18 and gate._skipped_tokens == float(m[..., 0].sum())
+    gate._skipped_tokens = 0
+    assert gate._skipped_tokens == 0
