@@ -460,33 +460,42 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       PP_BARRIER();
       if (p == 0) PS_STAMP(6);
       if (p == NPASS - 1) PS_STAMP(10);
-      // (3) whole-row-segment stores (combine scale and residual / gelu' fused); a row's residual segments are fetched
-      //     right here, per row: holding a whole pass of them across (2) costs registers the 320-row tile does not have
+      // (3) whole-row-segment stores (combine scale and residual / gelu' fused).  Residual segments are fetched one row
+      //     iteration ahead, and every use of a row's segments comes BEFORE that row's first store: with LDS-DMA in flight
+      //     hipcc waits vmcnt(0) at any use of an ordinary load, so a use behind a store would wait for that store's
+      //     acknowledgement (that was 4.2 k cycles per row iteration; the loads of row it + 1 now travel under the stores of it)
+      auto res_fetch = [&](int it, u32x4 (&dst)[CPT]) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
+          dst[j] = u32x4{0u, 0u, 0u, 0u};
+          if (residual && orow[it] >= 0 && ncol < N)
+            dst[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + ((int64_t)orow[it] * N + ncol) * OB);
+        }
+      };
+      u32x4 resv[CPT], resn[CPT];
+      res_fetch(0, resv);
 #pragma unroll
       for (int it = 0; it < ITS; ++it) {
+        const int r = trow + it * ROWS_PER_IT;
+        const int64_t rbase = (int64_t)orow[it] * N;
+        u32x4 v[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          v[j] = *reinterpret_cast<const u32x4*>(cst + r * C_STRIDE + (tcol + j * TPR) * 16);
+          if (row_map && row_scale) v[j] = scale16<OT>(v[j], oscale[it]);
+          if (residual) v[j] = fuse_aux<OT>(epilogue, resv[j], v[j]);
+        }
+        if (it + 1 < ITS) res_fetch(it + 1, resn);
         if (orow[it] >= 0) {
-          const int r = trow + it * ROWS_PER_IT;
-          const int64_t rbase = (int64_t)orow[it] * N;
-          u32x4 resv[CPT];
 #pragma unroll
           for (int j = 0; j < CPT; ++j) {
             const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
-            resv[j] = u32x4{0u, 0u, 0u, 0u};
-            if (residual && ncol < N)
-              resv[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + (rbase + ncol) * OB);
-          }
-#pragma unroll
-          for (int j = 0; j < CPT; ++j) {
-            const int ch = tcol + j * TPR;
-            const int ncol = cn0 + ch * (16 / OB);
-            if (ncol < N) {
-              u32x4 v = *reinterpret_cast<const u32x4*>(cst + r * C_STRIDE + ch * 16);
-              if (row_map && row_scale) v = scale16<OT>(v, oscale[it]);
-              if (residual) v = fuse_aux<OT>(epilogue, resv[j], v);
-              *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (rbase + ncol) * OB) = v;
-            }
+            if (ncol < N) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (rbase + ncol) * OB) = v[j];
           }
         }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) resv[j] = resn[j];
       }
       // the staging reads above are complete when their stores have issued; the next pass (or the next tile's K-tile 1)
       // may overwrite the region once every wave is here
