@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fused LayerNorm + router driver for timing / rocprofv3 (ViT-B shape: T = 256 x 197, d 768, E 8, k 1).
-usage: lnrouter_prof.py [iters] [images]; SMOE_LIB=<path> selects an alternative build of the library."""
+usage: lnrouter_prof.py [iters] [images] [d] [E] [tokens per image]; SMOE_LIB=<path> selects an alternative build of the library."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +10,9 @@ if os.environ.get("SMOE_LIB"):
     _lib.LIB_PATH = os.environ["SMOE_LIB"]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 images = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-T, d, E = images * 197, 768, 8
+d = int(sys.argv[3]) if len(sys.argv) > 3 else 768
+E = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+T = images * (int(sys.argv[5]) if len(sys.argv) > 5 else 197)
 g = torch.Generator().manual_seed(0)
 x = torch.randn(T, d, generator=g).cuda()
 gamma = (1 + 0.1 * torch.randn(d, generator=g)).cuda(); beta = (0.1 * torch.randn(d, generator=g)).cuda()
