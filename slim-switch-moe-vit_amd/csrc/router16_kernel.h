@@ -131,10 +131,22 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
   if (it0 < n_items) fetch(it0);
 
   if constexpr (ROUTE) {
-    for (int i = tid * 4; i < EB * d; i += NTH * 4) {
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i / d < E) v = *reinterpret_cast<const f32x4*>(wg + i);
-      *reinterpret_cast<f32x4*>(lds_w + i) = v;
+    // weight image -> LDS, eight 16-byte loads in flight per thread (one load per trip made the staging a chain of
+    // dependent L2 round trips: 16 of them for the 32-expert image of a 512-thread workgroup)
+    constexpr int WU = 8;
+    for (int base = tid * 4; base < EB * d; base += NTH * 4 * WU) {
+      f32x4 v[WU];
+#pragma unroll
+      for (int q8 = 0; q8 < WU; ++q8) {
+        const int i = base + q8 * NTH * 4;
+        v[q8] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < EB * d && i / d < E) v[q8] = *reinterpret_cast<const f32x4*>(wg + i);
+      }
+#pragma unroll
+      for (int q8 = 0; q8 < WU; ++q8) {
+        const int i = base + q8 * NTH * 4;
+        if (i < EB * d) *reinterpret_cast<f32x4*>(lds_w + i) = v[q8];
+      }
     }
     if (tid < EB) lds_bias[tid] = (bg && tid < E) ? bg[tid] : 0.f;
   }
