@@ -39,6 +39,19 @@ int smoe_kernel_ensure(SmoeKernelEntry& e) {
   if (bit) e.done.fetch_or(bit, std::memory_order_release);
   return 0;
 }
+namespace {
+__global__ void zero_words_kernel(uint32_t* p, int64_t words) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+}  // namespace
+
+hipError_t smoe_zero_words(void* p, int64_t words, hipStream_t s) {
+  if (words <= 0) return hipSuccess;
+  const int64_t blocks = (words + 255) / 256;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, s, (uint32_t*)p, words);
+  return hipGetLastError();
+}
+
 int smoe_num_cus() {
   static std::atomic<int> cached[32];
   int dev = 0;

@@ -382,8 +382,8 @@ extern "C" int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int6
   SMOE_REQUIRE(out && E >= 1 && E <= GW_MAX_E && C > 0 && C % 4 == 0 && n_rows >= 0, "smoe_gate_wgrad: bad arguments (E <= %d, C %% 4 == 0)", GW_MAX_E);
   hipStream_t s = (hipStream_t)stream;
   if (n_rows == 0) {
-    hipError_t me = hipMemsetAsync(out, 0, (size_t)E * C * 4, s);
-    SMOE_REQUIRE(me == hipSuccess, "smoe_gate_wgrad: memset failed");
+    hipError_t me = smoe_zero_words(out, (int64_t)E * C, s);
+    SMOE_REQUIRE(me == hipSuccess, "smoe_gate_wgrad: counter clear failed");
     return 0;
   }
   SMOE_REQUIRE(dl && x, "smoe_gate_wgrad: null pointer");

@@ -23,9 +23,9 @@ int launch_gate(const float* x, const GLnArgs& ln, const SkipGateArgs& ga, const
   constexpr int64_t max_wg = 768;
   const int64_t iters = (need + max_wg - 1) / max_wg;
   const int grid = (int)(need < 1 ? 1 : (need + iters - 1) / (iters < 1 ? 1 : iters));
-  hipError_t me = hipMemsetAsync(rc, 0, 16, s);
+  hipError_t me = smoe_zero_words(rc, 4, s);
   if (me != hipSuccess) {
-    smoe_set_error("smoe_gate_ln_router: memset failed: %s", hipGetErrorString(me));
+    smoe_set_error("smoe_gate_ln_router: counter clear failed: %s", hipGetErrorString(me));
     return (int)me;
   }
   if (smem > 64 * 1024) {

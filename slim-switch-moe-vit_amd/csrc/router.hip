@@ -256,7 +256,7 @@ __global__ __launch_bounds__(ROUTER_THREADS, (MODE == 0 ? 4 : 2)) void router_ke
 #pragma unroll
       for (int r = 0; r < ROUTER_MAX_K; ++r)
         if (r + 1 < kc) ambiguous |= !((chosen_val[r] - chosen_val[r + 1]) > bound);
-      if (ambiguous && lane == 0) redo_list[atomicAdd(redo_count, 1)] = (int32_t)t;  // wave-uniform condition
+      if (ambiguous && lane == 0) list_push(redo_count, redo_list, T, t);  // wave-uniform condition
     } else {
       logits_f64();
       __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -321,9 +321,9 @@ int launch_router(const void* x, const float* wg, const float* bg, const float* 
     SMOE_CHECK_LAUNCH("smoe_router_topk/f64");
     return 0;
   }
-  hipError_t me = hipMemsetAsync(redo_count, 0, 16, stream);
+  hipError_t me = smoe_zero_words(redo_count, 4, stream);
   if (me != hipSuccess) {
-    smoe_set_error("smoe_router_topk: memset failed: %s", hipGetErrorString(me));
+    smoe_set_error("smoe_router_topk: counter clear failed: %s", hipGetErrorString(me));
     return (int)me;
   }
   if (w_lds) ROUTER_LAUNCH(true, 0, grid, redo_count, redo_list);

@@ -119,9 +119,9 @@ int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, 
     SMOE_CHECK_LAUNCH("smoe_router_topk/f64");
     return 0;
   }
-  hipError_t me = hipMemsetAsync(rc, 0, 16, s);
+  hipError_t me = smoe_zero_words(rc, 4, s);
   if (me != hipSuccess) {
-    smoe_set_error("smoe_router_topk: memset failed: %s", hipGetErrorString(me));
+    smoe_set_error("smoe_router_topk: counter clear failed: %s", hipGetErrorString(me));
     return (int)me;
   }
   if (force_f64 && LN) {  // f64 mode still needs the normalised rows written: run the f32 pass for its stores first

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
       // gate only: bookkeeping, then the next row
       it0 += slot_stride;
       const bool redo = (MODE == 0) && gate_ambiguous;
-      if (redo && live && u == 0) redo_list[atomicAdd(redo_count, 1)] = (int32_t)t;
+      if (redo && live && u == 0) list_push(redo_count, redo_list, T, t);
       if (live && u == 0 && ga.mask) {
         ga.mask[t * 2] = skip ? 1.f : 0.f;
         ga.mask[t * 2 + 1] = skip ? 0.f : 1.f;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
       // an all-zero row (a skipped token, or a genuinely zero input) has logits that ARE the biases -- no arithmetic, no
       // rounding: a tie between biases is resolved by the lowest id here exactly as the f64 pass would resolve it
       redo = (ambiguous && xs > 0.f) || gate_ambiguous;
-      if (redo && live && u == 0) redo_list[atomicAdd(redo_count, 1)] = (int32_t)t;
+      if (redo && live && u == 0) list_push(redo_count, redo_list, T, t);
     }
     if constexpr (GATE != 0) {
       if (live && u == 0 && ga.mask) {

@@ -123,6 +123,9 @@ struct SmoeKernelEntry {
 };
 int smoe_kernel_ensure(SmoeKernelEntry& e);  // api.hip
 int smoe_num_cus();                          // CU count of the current device (cached per device)
+// Zero `words` 32-bit words at p (4-byte aligned) with a kernel on stream s.  Used for the few device-side counters instead of
+// hipMemsetAsync: a plain kernel node orders like every other launch when the caller captures the stream into a graph.
+hipError_t smoe_zero_words(void* p, int64_t words, hipStream_t s);  // api.hip
 template <auto KERN> struct SmoeKernelReg { static SmoeKernelEntry entry; };
 template <auto KERN> SmoeKernelEntry SmoeKernelReg<KERN>::entry{reinterpret_cast<const void*>(KERN)};
 #define SMOE_ENSURE_SMEM(...)                                                \
@@ -133,3 +136,10 @@ template <auto KERN> SmoeKernelEntry SmoeKernelReg<KERN>::entry{reinterpret_cast
 
 static inline int smoe_dtype_size(int code) { return code == SMOE_F32 ? 4 : 2; }
 static inline bool smoe_dtype_ok(int code) { return code == SMOE_F32 || code == SMOE_F16 || code == SMOE_BF16; }
+
+// Append token t to a device-side list behind an atomic counter.  The list holds `cap` entries; a slot outside it (a counter
+// that was not zeroed, or corrupted) is dropped instead of becoming a wild store.
+__device__ __forceinline__ void list_push(int32_t* count, int32_t* list, int64_t cap, int64_t t) {
+  const int32_t slot = atomicAdd(count, 1);
+  if (slot >= 0 && (int64_t)slot < cap) list[slot] = (int32_t)t;
+}

@@ -343,3 +343,53 @@ def test_two_compute_streams_reproduce_the_single_stream_forward():
     res = q.get(timeout=10)
     print("two compute streams:", res)
     assert res["repeat_err"] == 0.0 and res["vs_single_stream"] == 0.0, res
+
+
+def _graph_worker(q):
+    """Capture the eval forward into a HIP graph and replay it: include/slimmoe.h promises launch functions that neither
+    allocate nor synchronise, i.e. capturable ones."""
+    torch.manual_seed(0)
+    model = _init(sm.create_model("moe_base_patch16_224_expert8_top1", num_classes=100, depth=3), 23).eval().to(DEV)
+    images = torch.randn(16, 3, 224, 224, generator=torch.Generator().manual_seed(24)).to(DEV)
+
+    def step():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return model(images)
+
+    eager = step().float().clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = step()
+    worst = 0.0
+    for _ in range(6):   # back to back: every replay after the first finds the previous one's bytes in its buffers
+        g.replay()
+    torch.cuda.synchronize()
+    worst = float((out.float() - eager).abs().max())
+    images.copy_(torch.randn(16, 3, 224, 224, generator=torch.Generator().manual_seed(25)).to(DEV))
+    g.replay()
+    torch.cuda.synchronize()
+    other = float((out.float() - step().float()).abs().max())
+    q.put({"replay_vs_eager": worst, "new_input_vs_eager": other})
+
+
+def test_eval_forward_captured_in_a_hip_graph_replays_bit_exact():
+    """The first capture of this forward faulted on its SECOND replay: the router's redo counter was cleared with
+    hipMemsetAsync, whose graph node did not order against the kernels around it, so the f32 pass appended to its redo
+    list at whatever the counter's bytes held from the previous replay.  The counters are now cleared by a kernel
+    (smoe_zero_words) and every list append is bounds-checked (list_push).  Child process, finite timeout."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_graph_worker, args=(q,))
+    p.start()
+    _join_or_kill([p], 240)
+    res = q.get(timeout=10)
+    print("graph replay:", res)
+    assert res["replay_vs_eager"] == 0.0 and res["new_input_vs_eager"] == 0.0, res
