@@ -189,6 +189,10 @@ int smoe_rowdot(const void* dout, int dout_dtype, const void* y, int y_dtype, co
 int smoe_pad_offsets(const int32_t* offsets, int E, int32_t* offsets_pad, void* stream);
 int smoe_transpose_pad(const void* src, int dtype, const int32_t* offsets, const int32_t* offsets_pad, int E,
                        int64_t n_rows, int C, int Lp, void* dst, void* stream);
+/* smoe_transpose_cast: dst[b][c][r] = (dst_dtype) src[b][r][c] for b < B; R % 64 == 0, C % 64 == 0.  The backward pass reads every
+ * expert weight [E, out, in] a second time as [E, in, out] (FastMoE: `MOELinear.backward` -> fmoe_cuda.linear_backward contracts
+ * grad_out with the weight over `out`); this makes that 16-bit image straight from the f32 master in one pass.               */
+int smoe_transpose_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int B, int R, int C, void* stream);
 int smoe_grouped_wgrad(const void* PT, const void* QT, int ab_dtype, const int32_t* offsets_pad, int E, int R1,
                        int R2, int Lp, float* out, void* stream);
 /* smoe_grouped_wgrad_rows: the same weight gradients as smoe_grouped_wgrad, straight from the token-major operands

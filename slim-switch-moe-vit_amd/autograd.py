@@ -128,7 +128,7 @@ class _GroupFFN(torch.autograd.Function):
         G = offsets.numel() - 1
         n = rows.shape[0]
         dY = dY.contiguous()
-        w2t = ex.h4toh.weight_as(cd).transpose(1, 2).contiguous()                        # [E, h, d]  (N = h, K = d)
+        w2t = ex.h4toh.weight_t_as(cd)                                                   # [E, h, d]  (N = h, K = d)
         # dH = (dY W2) * gelu'(H) [* dropout mask]: gelu' rides in the dgrad GEMM's epilogue; the (elementwise, commuting)
         # dropout mask of the rare drop > 0 training configuration is one multiply behind it
         dH = ops.grouped_gemm(dY, w2t, None, offsets, ops.EPI_GELU_GRAD, cd, variant=mod.gemm_variant,
@@ -147,7 +147,7 @@ class _GroupFFN(torch.autograd.Function):
             db1 = db1.view(-1, E_local, db1.shape[1]).sum(0) if db1 is not None else None
         drows = None
         if ctx.needs_input_grad[0]:
-            w1t = ex.htoh4.weight_as(cd).transpose(1, 2).contiguous()                    # [E, d, h]  (N = d, K = h)
+            w1t = ex.htoh4.weight_t_as(cd)                                               # [E, d, h]  (N = d, K = h)
             drows = ops.grouped_gemm(dH, w1t, None, offsets, ops.EPI_NONE, cd, variant=mod.gemm_variant,
                                      group_expert=gexp)
         return drows, dW1, db1, dW2, db2, None, None, None, None

@@ -667,21 +667,19 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   const AB* w_src[SLOTS];
   // per K-tile advance of the source pointers (elements): 64 k-columns, or 64 token rows in MODE 2
   const int64_t a_step = (MODE == 2) ? (int64_t)64 * m_rows : 64, w_step = (MODE == 2) ? (int64_t)64 * N : 64;
-  int t_row[ASLOTS];  // MODE 2: token row (inside the K-tile) this lane stages in slot s
+  // MODE 2: 32-bit ELEMENT offsets from A / W instead of per-lane pointers (the launcher keeps both operands under 2^32
+  // elements), and ONE running row offset + first column per operand -- slot s reads 64 s columns further, clamped at the
+  // matrix edge when its piece is issued: the 320-row tile has no registers to spare for nine 64-bit running pointers
+  uint32_t a_rowoff = 0, w_rowoff = 0;
+  int a_col0 = 0, w_col0 = 0;
+  const int t_row = 8 * wave + l_row;  // MODE 2: token row (inside the K-tile) this lane stages, the same in every slot
   if constexpr (MODE == 2) {
-    static_assert(MODE != 2 || AFR == 4, "token-major wgrad is written for the 256-row tile");
-#pragma unroll
-    for (int s = 0; s < ASLOTS; ++s) {
-      const int pc = s * NW + wave;             // 1-KiB piece: slab pc / 8 (64 output columns), token rows 8 (pc % 8) ..
-      const int row = 8 * (pc & 7) + l_row;
-      const int ch = (((l_pos >> 1) ^ ((row >> 1) & 3)) << 1) | (l_pos & 1);   // 32-byte segment swizzle (source side)
-      int ca = m0 + 64 * (pc >> 3) + ch * 8, cw = n0 + 64 * (pc >> 3) + ch * 8;
-      if (ca > m_rows - 8) ca = m_rows - 8;     // columns past the matrix: any valid address (those outputs are not stored)
-      if (cw > N - 8) cw = N - 8;
-      t_row[s] = row;
-      a_src[s] = A + (int64_t)(k_base + row) * m_rows + ca;
-      w_src[s] = W + (int64_t)(k_base + row) * N + cw;
-    }
+    // 1-KiB piece (s, wave): slab s (64 output columns), token rows 8 wave .. 8 wave + 7 of the K-tile
+    const int ch = (((l_pos >> 1) ^ ((t_row >> 1) & 3)) << 1) | (l_pos & 1);   // 32-byte segment swizzle (source side)
+    a_col0 = m0 + ch * 8;
+    w_col0 = n0 + ch * 8;
+    a_rowoff = (uint32_t)((int64_t)(k_base + t_row) * m_rows);
+    w_rowoff = (uint32_t)((int64_t)(k_base + t_row) * N);
   }
 #pragma unroll
   for (int s = 0; s < ASLOTS && MODE != 2; ++s) {
@@ -702,14 +700,17 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   // MODE 2: source of A piece s of K-tile kt -- the zero page once the token row is past the expert's range
   // (only the last K-tile of an expert can hold such rows: a wave-uniform test keeps the per-lane selects out of the
   // steady state)
-  // MODE 2 keeps running pointers: every slot's pieces are requested for K-tiles 0, 1, 2, ... in order (prologue: 0 and 1,
-  // then one per loop iteration), so the 64-row advance is an add instead of a 64-bit multiply per DMA
+  // (kt is wave-uniform: the K-tile advance is one scalar multiply and one vector add per DMA)
   auto a_ptr = [&](int s, int kt) -> const AB* {
-    const AB* ptr = a_src[s] + (MODE == 2 ? 0 : kt * a_step);
+    const AB* ptr = nullptr;
+    if constexpr (MODE != 2) ptr = a_src[s] + kt * a_step;
     if constexpr (MODE == 2) {
-      a_src[s] += a_step;
+      // columns past the matrix: any valid address (those outputs are not stored)
+      int ca = a_col0 + 64 * s;
+      ca = ca > m_rows - 8 ? m_rows - 8 : ca;
+      ptr = A + (a_rowoff + (uint32_t)kt * (uint32_t)a_step + (uint32_t)ca);
       if (kt == nk - 1) {
-        const uint64_t keep = (k_base + kt * 64 + t_row[s] < k_hi) ? ~0ull : 0ull;
+        const uint64_t keep = (k_base + kt * 64 + t_row < k_hi) ? ~0ull : 0ull;
         ptr = reinterpret_cast<const AB*>((reinterpret_cast<uint64_t>(ptr) & keep) | (reinterpret_cast<uint64_t>(residual) & ~keep));
       }
     }
@@ -719,11 +720,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   // whatever bytes an arbitrary valid address happens to hold
   const AB* const w_safe = (MODE == 2) ? reinterpret_cast<const AB*>(residual) : W;
   auto w_ptr = [&](int s, int kt) -> const AB* {
-    const AB* ptr = w_src[s] + (MODE == 2 ? 0 : kt * w_step);
+    const AB* ptr = nullptr;
+    if constexpr (MODE != 2) ptr = w_src[s] + kt * w_step;
     if constexpr (MODE == 2) {
-      w_src[s] += w_step;
+      int cw = w_col0 + 64 * s;
+      cw = cw > N - 8 ? N - 8 : cw;
+      ptr = W + (w_rowoff + (uint32_t)kt * (uint32_t)w_step + (uint32_t)cw);
       if (kt == nk - 1) {
-        const uint64_t keep = (k_base + kt * 64 + t_row[s] < k_hi) ? ~0ull : 0ull;
+        const uint64_t keep = (k_base + kt * 64 + t_row < k_hi) ? ~0ull : 0ull;
         ptr = reinterpret_cast<const AB*>((reinterpret_cast<uint64_t>(ptr) & keep) | (reinterpret_cast<uint64_t>(w_safe) & ~keep));
       }
     }
@@ -849,26 +853,35 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   // transposing reads (it cannot tell them from the LDS-DMA destinations in flight), which drains the operand pipeline
   // three times per K-tile (486 us per launch instead of ~330).  The price: the compiler does not count these reads
   // either, so the MFMA cluster that consumes them waits lgkmcnt(0) explicitly (PP_MFMA, MODE 2).
-  auto read_tr = [&](const char* slab, int seg, int kk) -> u32x4 {
-    const int tq = fr >> 2, tp = fr & 3;
-    const int r0 = 32 * kk + 4 * fq + tq, r1 = r0 + 16;
-    const uint32_t a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(slab + r0 * 128 + ((seg ^ ((r0 >> 1) & 3)) << 5) + tp * 8);
-    const uint32_t a1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(slab + r1 * 128 + ((seg ^ ((r1 >> 1) & 3)) << 5) + tp * 8);
-    s16x4 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
-    s16x8 v;
+  // One address register per 16-column block: the four reads of a fragment pair (kk = 0 / 1, token rows r0 / r0 + 16) differ
+  // by immediates (4096 kk + 2048), and the block's swizzle is an XOR into two otherwise unused address bits -- the lane part
+  // is a single register, re-derived behind an opaque copy at every use so that the compiler does not keep one address per
+  // (buffer, half, fragment, kk) alive through the main loop (the 320-row tile has no registers for that).
+  const uint32_t tr_lane = (uint32_t)((4 * fq + (fr >> 2)) * 128 + (fr & 3) * 8) | ((uint32_t)(((4 * fq + (fr >> 2)) >> 1) & 3) << 5);
+  auto read_tr2 = [&](uint32_t region, int seg, u32x4& k0, u32x4& k1) {   // region = LDS byte address of the slab
+    uint32_t ln = tr_lane;
+    asm volatile("" : "+v"(ln));
+    const uint32_t a = region + (ln ^ ((uint32_t)seg << 5));
+    s16x4 lo0, hi0, lo1, hi1;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo0) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi0) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(lo1) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(hi1) : "v"(a));
+    s16x8 v0, v1;
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) { v[q4] = lo[q4]; v[4 + q4] = hi[q4]; }
-    return __builtin_bit_cast(u32x4, v);
+    for (int q4 = 0; q4 < 4; ++q4) { v0[q4] = lo0[q4]; v0[4 + q4] = hi0[q4]; v1[q4] = lo1[q4]; v1[4 + q4] = hi1[q4]; }
+    k0 = __builtin_bit_cast(u32x4, v0);
+    k1 = __builtin_bit_cast(u32x4, v1);
   };
+  const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
   auto read_a = [&](int buf, int half) {
     if constexpr (MODE == 2) {
-      const char* slab = smem + buf * STAGE + (wr * 2 + half) * 8192;   // 64 output rows = one [64 tokens][64 columns] slab
+      // 64 output rows = one [64 tokens][64 columns] slab; this wave's 16-row fragment i of the half is fragment
+      // (2 wr + half) AFR + i of the tile: slab = that / 4, 16-column block = that % 4 (320-row tile: a half spans 1.25 slabs)
+      const int f0 = (wr * 2 + half) * AFR;
 #pragma unroll
       for (int i = 0; i < AFR; ++i)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) ar[i][kk] = read_tr(slab, i, kk);
+        read_tr2(smem_lds + (uint32_t)(buf * STAGE + ((f0 + i) >> 2) * 8192), (f0 + i) & 3, ar[i][0], ar[i][1]);
       return;
     }
     if (ABL & 2) { asm volatile("" : "+v"(ar[0][0]), "+v"(ar[1][1])); return; }
@@ -880,11 +893,9 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
   };
   auto read_b = [&](int buf, int half) {
     if constexpr (MODE == 2) {
-      const char* slab = smem + buf * STAGE + TBM * BK_BYTES + wc * 8192;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) br[i][kk] = read_tr(slab, half * 2 + i, kk);
+        read_tr2(smem_lds + (uint32_t)(buf * STAGE + TBM * BK_BYTES + wc * 8192), half * 2 + i, br[i][0], br[i][1]);
       return;
     }
     if (ABL & 2) { asm volatile("" : "+v"(br[0][0]), "+v"(br[1][1])); return; }
@@ -1209,15 +1220,28 @@ int launch_wgrad(const void* PT, const void* QT, const int32_t* offsets_pad, int
 template <typename AB>
 int launch_wgrad_rows(const void* P, const void* Q, const int32_t* offsets, int E, int R1, int R2, const void* zero16,
                       float* out, hipStream_t s) {
-  constexpr int TBM = 256, TBN = 256;
-  const int tm = (R1 + TBM - 1) / TBM, tn = (R2 + TBN - 1) / TBN;
-  const int grid = E * tm * tn;
-  const size_t smem = 2 * (size_t)(TBM + TBN) * BK_BYTES;
-  auto kern = grouped_gemm_pp256<AB, float, 0, 2>;
-  SMOE_ENSURE_SMEM(grouped_gemm_pp256<AB, float, 0, 2>);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, (const AB*)P, (const AB*)Q, (const float*)nullptr, offsets,
-                     (const int32_t*)nullptr, E, 0, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
-                     (const float*)zero16, out, tn, tm, R1, (const int64_t*)nullptr, 1);
+  // Tile height 256 or 320 output rows, whichever needs fewer cost-weighted rounds of workgroups: the static grid has E x
+  // tm x tn equal tiles, e.g. ViT-B's dW1 [3072, 768] x 8 experts = 288 tiles of 256 rows (two rounds on 256 CUs, the
+  // second one an eighth full) or 240 of 320 rows (one round).
+  constexpr int TBN = 256;
+  const int tn = (R2 + TBN - 1) / TBN, tm4 = (R1 + 255) / 256, tm5 = (R1 + 319) / 320;
+  const int64_t cus = smoe_num_cus();
+  const double c4 = (double)(((int64_t)E * tm4 * tn + cus - 1) / cus), c5 = 1.25 * (double)(((int64_t)E * tm5 * tn + cus - 1) / cus);
+  if (c5 < c4) {
+    const size_t smem = 2 * (size_t)(320 + TBN) * BK_BYTES;
+    auto kern = grouped_gemm_pp256<AB, float, 0, 2, 5>;
+    SMOE_ENSURE_SMEM(grouped_gemm_pp256<AB, float, 0, 2, 5>);
+    hipLaunchKernelGGL(kern, dim3(E * tm5 * tn), dim3(512), smem, s, (const AB*)P, (const AB*)Q, (const float*)nullptr, offsets,
+                       (const int32_t*)nullptr, E, 0, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
+                       (const float*)zero16, out, tn, tm5, R1, (const int64_t*)nullptr, 1);
+  } else {
+    const size_t smem = 2 * (size_t)(256 + TBN) * BK_BYTES;
+    auto kern = grouped_gemm_pp256<AB, float, 0, 2>;
+    SMOE_ENSURE_SMEM(grouped_gemm_pp256<AB, float, 0, 2>);
+    hipLaunchKernelGGL(kern, dim3(E * tm4 * tn), dim3(512), smem, s, (const AB*)P, (const AB*)Q, (const float*)nullptr, offsets,
+                       (const int32_t*)nullptr, E, 0, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
+                       (const float*)zero16, out, tn, tm4, R1, (const int64_t*)nullptr, 1);
+  }
   SMOE_CHECK_LAUNCH("smoe_grouped_wgrad_rows");
   return 0;
 }

@@ -56,6 +56,16 @@ class FMoELinear(nn.Module):
             return w.detach()
         return self._shadow.get((dtype, w.device), param_version(w), lambda: ops.cast(w.detach().contiguous(), dtype))
 
+    def weight_t_as(self, dtype: torch.dtype) -> torch.Tensor:
+        """``weight.transpose(1, 2)`` as a contiguous [E, in, out] tensor in ``dtype`` -- the operand of the dgrad GEMM
+        (it contracts over ``out``); cached like ``weight_as``, made from the master weight in one HIP pass."""
+        w = self.weight
+        if w.is_cuda and w.shape[1] % 64 == 0 and w.shape[2] % 64 == 0:
+            make = lambda: ops.transpose_cast(w.detach().contiguous(), dtype)
+        else:
+            make = lambda: w.detach().transpose(1, 2).to(dtype).contiguous()
+        return self._shadow.get(("t", dtype, w.device), param_version(w), make)
+
     def extra_repr(self):
         return f"num_expert={self.num_expert}, in_features={self.in_feat}, out_features={self.out_feat}"
 

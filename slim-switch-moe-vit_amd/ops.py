@@ -417,6 +417,19 @@ def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return dst
 
 
+def transpose_cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """``src [B, R, C] -> [B, C, R]`` in ``dtype`` (R, C multiples of 64): the second, transposed operand image of an expert
+    weight that the dgrad GEMMs read, made in one pass from the master weight."""
+    _chk(src, "src")
+    if src.dim() != 3 or src.shape[1] % 64 or src.shape[2] % 64:
+        raise ValueError(f"transpose_cast: [B, R, C] with R, C multiples of 64, got {tuple(src.shape)}")
+    B, R, C = src.shape
+    dst = torch.empty((B, C, R), dtype=dtype, device=src.device)
+    rc = _lib.load().smoe_transpose_cast(_ptr(src), dtype_code(src.dtype), _ptr(dst), dtype_code(dtype), B, R, C, _stream(src))
+    _lib.check(rc, "smoe_transpose_cast")
+    return dst
+
+
 # ------------------------------------------------------------------------------------------ backward pieces
 def gelu(src: torch.Tensor) -> torch.Tensor:
     _chk(src, "src")
@@ -487,14 +500,29 @@ def _zero16(device) -> torch.Tensor:
     return _zero_pages.get(str(device), 0, lambda: torch.zeros(64, dtype=torch.uint8, device=device))
 
 
-def grouped_wgrad_rows(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
-    """out[e] (f32 [R1, R2]) = P[rows of e]^T @ Q[rows of e] from the token-major operands (no transposed copies)."""
+def _wgrad_rounds(E: int, R1: int, R2: int, cus: int) -> float:
+    """Cost-weighted rounds of workgroups of smoe_grouped_wgrad_rows (256- or 320-row tiles; csrc/gemm.hip launch_wgrad_rows)."""
+    tn = -(-R2 // 256)
+    c4 = -(-(E * -(-R1 // 256) * tn) // cus)
+    c5 = 1.25 * -(-(E * -(-R1 // 320) * tn) // cus)
+    return min(c4, c5)
+
+
+def grouped_wgrad_rows(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor, allow_swap: bool = True) -> torch.Tensor:
+    """out[e] (f32 [R1, R2]) = P[rows of e]^T @ Q[rows of e] from the token-major operands (no transposed copies).
+    The kernel's tile is taller (256 / 320 output rows) than wide along R1 only, so when the transposed problem needs fewer
+    rounds of workgroups (ViT-B's dW2 [768, 3072]: 288 tiles = two rounds on 256 CUs; as [3072, 768]: 240 taller tiles = one)
+    it is computed as Q^T P and transposed back by smoe_transpose_cast (one pass over the f32 result)."""
     _chk(P, "P", ndim=2)
     _chk(Q, "Q", ndim=2)
     if P.dtype != Q.dtype or P.dtype not in (torch.float16, torch.bfloat16) or P.shape[0] != Q.shape[0]:
         raise RuntimeError("grouped_wgrad_rows: P and Q must be f16 / bf16 with the same row count")
     E = offsets.numel() - 1
     R1, R2 = P.shape[1], Q.shape[1]
+    if allow_swap and R1 % 64 == 0 and R2 % 64 == 0:
+        cus = torch.cuda.get_device_properties(P.device).multi_processor_count
+        if _wgrad_rounds(E, R2, R1, cus) + 0.15 < _wgrad_rounds(E, R1, R2, cus):
+            return transpose_cast(grouped_wgrad_rows(Q, P, offsets, allow_swap=False), torch.float32)
     out = torch.empty((E, R1, R2), dtype=torch.float32, device=P.device)
     rc = _lib.load().smoe_grouped_wgrad_rows(_ptr(P), _ptr(Q), dtype_code(P.dtype), _ptr(offsets), E, R1, R2,
                                               _ptr(_zero16(P.device)), _ptr(out), _stream(P))

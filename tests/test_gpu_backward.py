@@ -291,7 +291,13 @@ def test_gate_wgrad_matches_matmul(T, E, d, dtype):
 
 
 @pytest.mark.parametrize("counts,R1,R2", [([64, 128], 256, 256), ([100, 0, 37, 64, 1], 72, 136), ([300, 5, 777], 768, 256),
-                                          ([1000, 900, 1100, 950], 768, 3072)])
+                                          ([1000, 900, 1100, 950], 768, 3072),
+                                          # eight experts at ViT-B's weight shapes: 320-row tiles (240 tiles = one round of
+                                          # workgroups instead of 288 = two), the last one 192 rows; then dW2's shape, which
+                                          # ops computes transposed; then 320-row tiles with ragged row AND column tails
+                                          ([250, 0, 300, 310, 280, 333, 64, 201], 3072, 768),
+                                          ([250, 0, 300, 310, 280, 333, 64, 201], 768, 3072),
+                                          ([130, 70, 0, 65, 129, 64, 1, 200], 3064, 760)])
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
 def test_grouped_wgrad_rows_matches_per_expert_matmul(counts, R1, R2, dtype, tol):
     """Token-major wgrad (transposed LDS reads, no transposed operand copies): ragged and empty experts, row counts
@@ -334,3 +340,17 @@ def test_grouped_wgrad_rows_tail_rows_never_meet_foreign_bytes():
         ref = P[o[e]:o[e + 1]].double().t() @ Q[o[e]:o[e + 1]].double()
         assert torch.isfinite(got[e]).all(), e
         assert (got[e] - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item()), e
+
+
+@pytest.mark.parametrize("shape", [(3, 128, 192), (8, 768, 3072), (1, 64, 64)])
+@pytest.mark.parametrize("src,dst", [(torch.float32, torch.float16), (torch.float32, torch.bfloat16), (torch.float16, torch.float16),
+                                     (torch.float32, torch.float32), (torch.bfloat16, torch.float32)])
+def test_transpose_cast_is_the_transposed_rounded_copy(shape, src, dst):
+    """smoe_transpose_cast == .transpose(1, 2).to(dst) bit for bit (the dgrad GEMMs' weight operand, and the way back of the
+    weight gradient that is computed transposed)."""
+    w = (torch.randn(shape, generator=_gen(sum(shape))) * 0.3).to(src).to(DEV)
+    got = ops.transpose_cast(w, dst)
+    assert got.shape == (shape[0], shape[2], shape[1]) and got.is_contiguous()
+    assert torch.equal(got, w.transpose(1, 2).to(dst).contiguous())
+    with pytest.raises(ValueError):
+        ops.transpose_cast(w[:, :, :-8].contiguous(), dst)

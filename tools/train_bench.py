@@ -1,56 +1,84 @@
 #!/usr/bin/env python3
-"""fwd + bwd timing of ONE MoE layer at BASELINE cfg-5 per-GPU size (ViT-B/16, E=8, SwitchGate, capacity_factor 1.0,
-aux loss; T = 256 x 197 tokens), single rank.  Prints one JSON line."""
-import json
-import os
-import sys
-
-import torch
-
+"""BASELINE cfg 5 timing: forward + backward (+ AdamW step through NativeScaler) with the SwitchGate, capacity_factor 1.0 and the
+aux loss, (a) for ONE MoE layer at ViT-B dims (T = images x 197 rows) and (b) for the whole ViT-B/16 E=8 model.
+usage: train_bench.py [layer|model] [images] [iters]      (run under rocprofv3 --kernel-trace --stats for the per-kernel table)"""
+import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import slim_switch_moe_vit_amd as sm  # noqa: E402
-from slim_switch_moe_vit_amd import _lib  # noqa: E402
-if os.environ.get("SMOE_LIB"):
-    _lib.LIB_PATH = os.environ["SMOE_LIB"]
+import slim_switch_moe_vit_amd as sm
+from slim_switch_moe_vit_amd import optim as smo
+
+what = sys.argv[1] if len(sys.argv) > 1 else "layer"
+images = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+g = torch.Generator().manual_seed(5)
 
 
-def main():
-    dev = "cuda:0"
-    torch.manual_seed(0)
-    d, h, E, T = 768, 3072, 8, 256 * 197
-    mod = sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=1, gate="switch", capacity_factor=1.0).to(dev).train()
+def timed(fn, n):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+if what == "layer":
+    d, h, E = 768, 3072, 8
+    T = images * 197
+    mod = sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=1, gate="switch", capacity_factor=1.0).to(dev)
     with torch.no_grad():
-        for p in mod.experts.parameters():
-            if p.dim() == 3:
-                p.copy_(torch.randn_like(p) * 0.02)
-    x = torch.randn(T, d, device=dev, requires_grad=True)
-    gout = torch.randn(T, d, device=dev) * 1e-2
+        for p in mod.parameters():
+            if p.dim() > 1:
+                p.copy_((torch.randn(p.shape, generator=g) * 0.02).to(dev))
+    mod.train()
+    x = torch.randn(T, d, generator=g).to(dev).requires_grad_(True)
+    gout = (torch.randn(T, d, generator=g) * 0.01).to(dev)
 
-    def step():
-        out = mod(x)
-        loss = (out * gout).sum() + 0.01 * mod.gate.get_loss()
-        loss.backward()
+    def fwd():
+        with torch.autocast("cuda", dtype=torch.float16):
+            return mod(x)
+
+    def fwd_bwd():
         for p in mod.parameters():
             p.grad = None
         x.grad = None
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = mod(x)
+            loss = (out.float() * gout).sum() + 0.01 * mod.gate.get_loss()
+        loss.backward()
 
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 10
-    s.record()
-    for _ in range(n):
-        step()
-    e.record()
-    torch.cuda.synchronize()
-    ms = s.elapsed_time(e) / n
-    kept = int(mod.last_plan[3][-1])
-    flops = 3 * 4.0 * kept * d * h  # fwd (2 GEMMs) + dgrad (2) + wgrad (2)
-    print(json.dumps({"what": "MoE layer fwd+bwd, cfg-5 size, 1 GPU", "ms": round(ms, 3), "kept_tokens": kept,
-                      "dropped": T - kept, "gemm_tflops": round(flops / ms / 1e9, 1)}))
+    with torch.no_grad():
+        t_f = timed(fwd, iters)
+    t_fb = timed(fwd_bwd, iters)
+    fl = 4.0 * T * d * h          # forward expert-GEMM FLOPs (kept rows <= T); backward = 2x that
+    print(f"MoE layer cfg 5 (T {T}, d {d}, h {h}, E {E}, switch gate, cf 1.0): forward {t_f:.3f} ms, forward+backward "
+          f"{t_fb:.3f} ms  ({3 * fl / (t_fb * 1e-3) / 1e12:.0f} TFLOP/s over the 3 x 4Tdh expert-GEMM FLOPs)", flush=True)
+else:
+    model = sm.create_model("moe_base_patch16_224_expert8_top1", num_classes=1000, gate="switch", capacity_factor=1.0).to(dev)
+    model.train()
+    opt = smo.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
+    scaler = smo.NativeScaler()
+    crit = torch.nn.CrossEntropyLoss()
+    x = torch.randn(images, 3, 224, 224, generator=g).to(dev)
+    y = torch.randint(0, 1000, (images,), generator=g).to(dev)
+    moes = [m for m in model.modules() if isinstance(m, sm.FMoETransformerMLP)]
 
+    def train_step():
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = model(x)
+            loss = crit(out, y)
+            for m in moes:
+                loss = loss + 0.01 * m.gate.get_loss()
+        opt.zero_grad()
+        scaler(loss, opt, clip_grad=1.0, parameters=model.parameters())
 
-if __name__ == "__main__":
-    main()
+    t = timed(train_step, iters)
+    print(f"ViT-B/16 E=8 switch cf 1.0 train step (fwd + bwd + clip + AdamW), batch {images}: {t:.2f} ms = {images / t * 1e3:.0f} images/s",
+          flush=True)
