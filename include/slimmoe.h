@@ -259,6 +259,16 @@ int smoe_grad_sumsq(const void* g, int g_dtype, int64_t n, const float* inv_scal
 int smoe_adamw_step(float* p, const void* g, int g_dtype, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, const float* step, const float* grad_mult, const float* found_inf,
                     void* stream);
+/* Multi-tensor forms of the two passes: ONE launch for every gradient / parameter of the step (torch's `foreach` / fused
+ * AdamW play this role upstream).  tab = int64 [5][n_tensors] in device memory: rows p, g, exp_avg, exp_avg_sq (addresses) and
+ * n (elements); the sumsq form reads rows g and n only.  hyp = f32 [2][n_tensors]: lr, weight_decay.  blk = int32 [2][n_blocks]:
+ * the tensor of workgroup b and the 16,384-element block inside it, blocks in tensor order; partial[b] receives block b's sum.
+ * Same arithmetic and the same partial sums as the single-tensor forms.                                                      */
+int smoe_grad_sumsq_multi(const int64_t* tab, int n_tensors, const int32_t* blk, int64_t n_blocks, int g_dtype,
+                          const float* inv_scale, float* partial, float* found_inf, void* stream);
+int smoe_adamw_step_multi(const int64_t* tab, const float* hyp, int n_tensors, const int32_t* blk, int64_t n_blocks,
+                          int g_dtype, float beta1, float beta2, float eps, const float* step, const float* grad_mult,
+                          const float* found_inf, void* stream);
 int smoe_amp_update(float* scale, float* growth_tracker, const float* found_inf, float growth_factor, float backoff_factor,
                     int growth_interval, void* stream);
 int smoe_step_advance(float* step, const float* found_inf, void* stream);

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: the library resolves libamd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -59,6 +59,9 @@ SIGNATURES = {
     "smoe_grad_sumsq": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_adamw_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,
                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "smoe_grad_sumsq_multi": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "smoe_adamw_step_multi": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, ctypes.c_float, ctypes.c_float,
+                                      ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_amp_update": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
     "smoe_step_advance": (c_int, [c_void_p, c_void_p, c_void_p]),
     "smoe_unique_id_bytes": (c_int, []),

@@ -16,13 +16,12 @@ namespace {
 constexpr int OPT_THREADS = 256;
 constexpr int SUMSQ_BLOCK = 16384;  // elements per workgroup of the norm pass
 
+// one 16K-element block of one gradient: sum of squares of (g * mul) -> partial[slot]; non-finite -> *found_inf = 1
 template <typename GT>
-__global__ __launch_bounds__(OPT_THREADS) void grad_sumsq_kernel(const GT* __restrict__ g, int64_t n,
-                                                                 const float* __restrict__ inv_scale,
-                                                                 float* __restrict__ partial, float* __restrict__ found_inf) {
+__device__ __forceinline__ void sumsq_block(const GT* __restrict__ g, int64_t n, int64_t block, float mul, float* __restrict__ partial_slot,
+                                            float* __restrict__ found_inf) {
   __shared__ float red[OPT_THREADS / 64];
-  const float mul = inv_scale ? *inv_scale : 1.0f;
-  const int64_t base = (int64_t)blockIdx.x * SUMSQ_BLOCK;
+  const int64_t base = block * SUMSQ_BLOCK;
   float acc = 0.f;
   bool bad = false;
   for (int i = threadIdx.x * 8; i < SUMSQ_BLOCK; i += OPT_THREADS * 8) {
@@ -52,21 +51,39 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_sumsq_kernel(const GT* __res
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   if (__ballot(bad) && (threadIdx.x & 63) == 0 && found_inf) *found_inf = 1.0f;
   __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) *partial_slot = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 template <typename GT>
-__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ p, const GT* __restrict__ g,
-                                                            float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
-                                                            float b1, float b2, float eps, float wd,
-                                                            const float* __restrict__ step, const float* __restrict__ grad_mult,
-                                                            const float* __restrict__ found_inf) {
-  if (found_inf && *found_inf != 0.f) return;   // GradScaler.step: a non-finite gradient skips the whole update
-  const float t = *step;                        // already advanced for this update
+__global__ __launch_bounds__(OPT_THREADS) void grad_sumsq_kernel(const GT* __restrict__ g, int64_t n,
+                                                                 const float* __restrict__ inv_scale,
+                                                                 float* __restrict__ partial, float* __restrict__ found_inf) {
+  sumsq_block<GT>(g, n, blockIdx.x, inv_scale ? *inv_scale : 1.0f, partial + blockIdx.x, found_inf);
+}
+
+// MULTI-TENSOR forms: one launch for every gradient / parameter of the step (a ViT-B/16 MoE has ~180 parameter tensors; one
+// launch each left the optimizer step bound by launch overhead).  tab = int64 [5][n_t]: rows p, g, m, v (addresses) and n;
+// blk = int32 [2][n_blocks]: tensor of workgroup b, 16K-element block inside it.  Same blocks, same arithmetic, same order of
+// the partial sums as the single-tensor forms.
+template <typename GT>
+__global__ __launch_bounds__(OPT_THREADS) void grad_sumsq_multi_kernel(const int64_t* __restrict__ tab, int n_t,
+                                                                       const int32_t* __restrict__ blk, int64_t n_blocks,
+                                                                       const float* __restrict__ inv_scale,
+                                                                       float* __restrict__ partial, float* __restrict__ found_inf) {
+  const int t = blk[blockIdx.x];
+  if (t < 0 || t >= n_t) return;   // the table is caller data
+  sumsq_block<GT>(reinterpret_cast<const GT*>(tab[(int64_t)n_t + t]), tab[4ll * n_t + t], blk[n_blocks + blockIdx.x],
+                  inv_scale ? *inv_scale : 1.0f, partial + blockIdx.x, found_inf);
+}
+
+// elements [begin, end) of one parameter, `stride` apart per pass (begin = this thread's first element, a multiple of 4)
+template <typename GT>
+__device__ __forceinline__ void adamw_range(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
+                                            float* __restrict__ v, int64_t begin, int64_t end, int64_t stride, int64_t n, float lr,
+                                            float b1, float b2, float eps, float wd, float t, float gm) {
   const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
-  const float step_size = lr / bc1, decay = 1.0f - lr * wd, gm = grad_mult ? *grad_mult : 1.0f;
-  const int64_t stride = (int64_t)gridDim.x * OPT_THREADS * 4;
-  for (int64_t i = ((int64_t)blockIdx.x * OPT_THREADS + threadIdx.x) * 4; i < n; i += stride) {
+  const float step_size = lr / bc1, decay = 1.0f - lr * wd;
+  for (int64_t i = begin; i < end; i += stride) {
     if (i + 4 <= n) {
       float gv[4];
       load4(g + i, gv);
@@ -96,6 +113,37 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ 
       }
     }
   }
+}
+
+template <typename GT>
+__global__ __launch_bounds__(OPT_THREADS) void adamw_kernel(float* __restrict__ p, const GT* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                            float b1, float b2, float eps, float wd,
+                                                            const float* __restrict__ step, const float* __restrict__ grad_mult,
+                                                            const float* __restrict__ found_inf) {
+  if (found_inf && *found_inf != 0.f) return;   // GradScaler.step: a non-finite gradient skips the whole update
+  // *step: already advanced for this update
+  adamw_range<GT>(p, g, m, v, ((int64_t)blockIdx.x * OPT_THREADS + threadIdx.x) * 4, n, (int64_t)gridDim.x * OPT_THREADS * 4, n,
+                  lr, b1, b2, eps, wd, *step, grad_mult ? *grad_mult : 1.0f);
+}
+
+// hyp = f32 [2][n_t]: lr, weight decay per tensor (parameter groups differ in both)
+template <typename GT>
+__global__ __launch_bounds__(OPT_THREADS) void adamw_multi_kernel(const int64_t* __restrict__ tab, const float* __restrict__ hyp,
+                                                                  int n_t, const int32_t* __restrict__ blk, int64_t n_blocks,
+                                                                  float b1, float b2, float eps, const float* __restrict__ step,
+                                                                  const float* __restrict__ grad_mult,
+                                                                  const float* __restrict__ found_inf) {
+  if (found_inf && *found_inf != 0.f) return;
+  const int t = blk[blockIdx.x];
+  if (t < 0 || t >= n_t) return;
+  const int64_t n = tab[4ll * n_t + t];
+  const int64_t base = (int64_t)blk[n_blocks + blockIdx.x] * SUMSQ_BLOCK;
+  const int64_t end = base + SUMSQ_BLOCK < n ? base + SUMSQ_BLOCK : n;
+  adamw_range<GT>(reinterpret_cast<float*>(tab[t]), reinterpret_cast<const GT*>(tab[(int64_t)n_t + t]),
+                  reinterpret_cast<float*>(tab[2ll * n_t + t]), reinterpret_cast<float*>(tab[3ll * n_t + t]),
+                  base + threadIdx.x * 4, end, OPT_THREADS * 4, n, hyp[t], b1, b2, eps, hyp[n_t + t], *step,
+                  grad_mult ? *grad_mult : 1.0f);
 }
 
 __global__ void amp_update_kernel(float* scale, float* growth_tracker, const float* found_inf, float growth, float backoff,
@@ -170,5 +218,38 @@ extern "C" int smoe_step_advance(float* step, const float* found_inf, void* stre
   SMOE_REQUIRE(step, "smoe_step_advance: null pointer");
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, found_inf);
   SMOE_CHECK_LAUNCH("smoe_step_advance");
+  return 0;
+}
+
+extern "C" int smoe_grad_sumsq_multi(const int64_t* tab, int n_tensors, const int32_t* blk, int64_t n_blocks, int g_dtype,
+                                     const float* inv_scale, float* partial, float* found_inf, void* stream) {
+  SMOE_REQUIRE(n_tensors >= 0 && n_blocks >= 0 && n_blocks < (1ll << 31) && smoe_dtype_ok(g_dtype), "smoe_grad_sumsq_multi: bad arguments");
+  if (n_blocks == 0) return 0;
+  SMOE_REQUIRE(tab && blk && partial, "smoe_grad_sumsq_multi: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)n_blocks), block(OPT_THREADS);
+  switch (g_dtype) {
+    case SMOE_F32: hipLaunchKernelGGL(grad_sumsq_multi_kernel<float>, grid, block, 0, s, tab, n_tensors, blk, n_blocks, inv_scale, partial, found_inf); break;
+    case SMOE_F16: hipLaunchKernelGGL(grad_sumsq_multi_kernel<f16>, grid, block, 0, s, tab, n_tensors, blk, n_blocks, inv_scale, partial, found_inf); break;
+    default: hipLaunchKernelGGL(grad_sumsq_multi_kernel<bf16_bits>, grid, block, 0, s, tab, n_tensors, blk, n_blocks, inv_scale, partial, found_inf); break;
+  }
+  SMOE_CHECK_LAUNCH("smoe_grad_sumsq_multi");
+  return 0;
+}
+
+extern "C" int smoe_adamw_step_multi(const int64_t* tab, const float* hyp, int n_tensors, const int32_t* blk, int64_t n_blocks,
+                                     int g_dtype, float beta1, float beta2, float eps, const float* step, const float* grad_mult,
+                                     const float* found_inf, void* stream) {
+  SMOE_REQUIRE(n_tensors >= 0 && n_blocks >= 0 && n_blocks < (1ll << 31) && smoe_dtype_ok(g_dtype), "smoe_adamw_step_multi: bad arguments");
+  if (n_blocks == 0) return 0;
+  SMOE_REQUIRE(tab && hyp && blk && step, "smoe_adamw_step_multi: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)n_blocks), block(OPT_THREADS);
+  switch (g_dtype) {
+    case SMOE_F32: hipLaunchKernelGGL(adamw_multi_kernel<float>, grid, block, 0, s, tab, hyp, n_tensors, blk, n_blocks, beta1, beta2, eps, step, grad_mult, found_inf); break;
+    case SMOE_F16: hipLaunchKernelGGL(adamw_multi_kernel<f16>, grid, block, 0, s, tab, hyp, n_tensors, blk, n_blocks, beta1, beta2, eps, step, grad_mult, found_inf); break;
+    default: hipLaunchKernelGGL(adamw_multi_kernel<bf16_bits>, grid, block, 0, s, tab, hyp, n_tensors, blk, n_blocks, beta1, beta2, eps, step, grad_mult, found_inf); break;
+  }
+  SMOE_CHECK_LAUNCH("smoe_adamw_step_multi");
   return 0;
 }

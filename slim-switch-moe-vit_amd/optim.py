@@ -29,6 +29,33 @@ def _hip_ok(p: torch.Tensor) -> bool:
     return p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
 
 
+SUMSQ_BLOCK = 16384   # elements per workgroup of the multi-tensor kernels (csrc/optim.hip)
+_blk_cache = {}       # (device, numels) -> (blk int32 [2, n_blocks] on the device, blocks per tensor)
+
+
+def _block_table(numels, device):
+    """Workgroup -> (tensor, 16K-element block) map of the multi-tensor kernels; depends on the tensor sizes only, cached."""
+    key = (str(device), tuple(numels))
+    hit = _blk_cache.get(key)
+    if hit is None:
+        import numpy as np
+        nb = [(n + SUMSQ_BLOCK - 1) // SUMSQ_BLOCK for n in numels]
+        tens = np.repeat(np.arange(len(numels), dtype=np.int32), nb)
+        first = np.cumsum([0] + nb[:-1]) if nb else np.zeros(0, dtype=np.int64)
+        index = (np.arange(int(sum(nb)), dtype=np.int64) - np.repeat(first, nb)).astype(np.int32)
+        blk = torch.from_numpy(np.stack([tens, index]) if len(tens) else np.zeros((2, 0), dtype=np.int32)).to(device)
+        if len(_blk_cache) > 16:
+            _blk_cache.clear()
+        hit = _blk_cache[key] = (blk.contiguous(), nb)
+    return hit
+
+
+def _pointer_table(rows, device):
+    """int64 [len(rows), n_t] on the device (addresses and element counts: they change with every backward, so this is one
+    small host-to-device copy per step)."""
+    return torch.tensor(rows, dtype=torch.int64, device=device)
+
+
 class AdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW(params, lr, betas, eps, weight_decay)`` (no amsgrad / maximize) with a fused HIP step.
 
@@ -58,6 +85,7 @@ class AdamW(torch.optim.Optimizer):
                 loss = closure()
         lib = None
         advanced = set()
+        batches = {}   # (device, grad dtype, betas, eps) -> [(p, g, exp_avg, exp_avg_sq, lr, wd)]: one launch each
         for group in self.param_groups:
             lr, (b1, b2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
             for p in group["params"]:
@@ -70,19 +98,8 @@ class AdamW(torch.optim.Optimizer):
                     st["step"] = 0
                 g = p.grad
                 if _hip_ok(p) and g.is_cuda and g.is_contiguous() and g.dtype in ops._DT:
-                    if lib is None:
-                        lib = _lib.load()
-                    dev = p.device
-                    step_t = self._step_counter(dev)
-                    if dev not in advanced:   # one counter per device: every parameter of a step sees the same t
-                        _lib.check(lib.smoe_step_advance(step_t.data_ptr(), ops._ptr(found_inf), ops._stream(p)),
-                                   "smoe_step_advance")
-                        advanced.add(dev)
-                    rc = lib.smoe_adamw_step(p.data_ptr(), g.data_ptr(), ops.dtype_code(g.dtype), st["exp_avg"].data_ptr(),
-                                             st["exp_avg_sq"].data_ptr(), p.numel(), float(lr), float(b1), float(b2),
-                                             float(eps), float(wd), step_t.data_ptr(), ops._ptr(grad_mult),
-                                             ops._ptr(found_inf), ops._stream(p))
-                    _lib.check(rc, "smoe_adamw_step")
+                    batches.setdefault((p.device, g.dtype, float(b1), float(b2), float(eps)), []).append(
+                        (p, g, st["exp_avg"], st["exp_avg_sq"], float(lr), float(wd)))
                     st["step"] += 1   # host-side count of step() calls (the device counter skips non-finite steps)
                 else:                 # torch composition (CPU tensors, other dtypes): same arithmetic
                     if found_inf is not None and float(found_inf) != 0.0:
@@ -95,6 +112,29 @@ class AdamW(torch.optim.Optimizer):
                     st["exp_avg_sq"].mul_(b2).addcmul_(gg, gg, value=1 - b2)
                     denom = (st["exp_avg_sq"].sqrt() / (1 - b2 ** t) ** 0.5).add_(eps)
                     p.addcdiv_(st["exp_avg"], denom, value=-lr / (1 - b1 ** t))
+        for (dev, gdt, b1, b2, eps), items in batches.items():
+            if lib is None:
+                lib = _lib.load()
+            step_t = self._step_counter(dev)
+            stream = ops._stream(items[0][0])
+            if dev not in advanced:   # one counter per device: every parameter of a step sees the same t
+                _lib.check(lib.smoe_step_advance(step_t.data_ptr(), ops._ptr(found_inf), stream), "smoe_step_advance")
+                advanced.add(dev)
+            if len(items) == 1:
+                p, g, m, v, lr, wd = items[0]
+                rc = lib.smoe_adamw_step(p.data_ptr(), g.data_ptr(), ops.dtype_code(gdt), m.data_ptr(), v.data_ptr(), p.numel(),
+                                         lr, b1, b2, eps, wd, step_t.data_ptr(), ops._ptr(grad_mult), ops._ptr(found_inf), stream)
+                _lib.check(rc, "smoe_adamw_step")
+                continue
+            # every tensor of the batch in ONE launch (a ViT-B/16 MoE has ~180 parameter tensors)
+            blk, nb = _block_table([it[0].numel() for it in items], dev)
+            tab = _pointer_table([[it[0].data_ptr() for it in items], [it[1].data_ptr() for it in items],
+                                  [it[2].data_ptr() for it in items], [it[3].data_ptr() for it in items],
+                                  [it[0].numel() for it in items]], dev)
+            hyp = torch.tensor([[it[4] for it in items], [it[5] for it in items]], dtype=torch.float32, device=dev)
+            rc = lib.smoe_adamw_step_multi(tab.data_ptr(), hyp.data_ptr(), len(items), blk.data_ptr(), sum(nb), ops.dtype_code(gdt),
+                                           b1, b2, eps, step_t.data_ptr(), ops._ptr(grad_mult), ops._ptr(found_inf), stream)
+            _lib.check(rc, "smoe_adamw_step_multi")
         return loss
 
 
@@ -178,21 +218,30 @@ class NativeScaler:
         # pass 1 over every gradient the optimizer will use: non-finite check (+ the norm's partial sums where clipped)
         grads = [p.grad for p in params]
         clip_ids = {id(p) for p in clip_over if p.grad is not None} if clip_over is not None else set()
-        n_blocks = [int(lib.smoe_grad_sumsq_blocks(g.numel())) for g in grads]
-        partial = torch.zeros(max(1, sum(n_blocks)), dtype=torch.float32, device=dev)
-        clip_mask = torch.zeros(max(1, sum(n_blocks)), dtype=torch.bool)
-        at = 0
-        for p, g, nb in zip(params, grads, n_blocks):
-            if nb:
-                rc = lib.smoe_grad_sumsq(g.data_ptr(), ops.dtype_code(g.dtype), g.numel(), inv_scale.data_ptr(),
-                                         partial[at:].data_ptr(), found_inf.data_ptr(), ops._stream(g))
-                _lib.check(rc, "smoe_grad_sumsq")
-                if id(p) in clip_ids:
-                    clip_mask[at:at + nb] = True
-            at += nb
+        # one launch per gradient dtype over every gradient (partials in parameter order, 16K-element blocks)
+        by_dtype = {}
+        for p, g in zip(params, grads):
+            if g.numel():
+                by_dtype.setdefault(g.dtype, []).append((p, g))
+        partials, masks = [], []
+        for gdt, items in by_dtype.items():
+            blk, nb = _block_table([g.numel() for _, g in items], dev)
+            zeros = [0] * len(items)
+            tab = _pointer_table([zeros, [g.data_ptr() for _, g in items], zeros, zeros, [g.numel() for _, g in items]], dev)
+            part = torch.empty(sum(nb), dtype=torch.float32, device=dev)
+            rc = lib.smoe_grad_sumsq_multi(tab.data_ptr(), len(items), blk.data_ptr(), sum(nb), ops.dtype_code(gdt),
+                                           inv_scale.data_ptr(), part.data_ptr(), found_inf.data_ptr(), ops._stream(part))
+            _lib.check(rc, "smoe_grad_sumsq_multi")
+            partials.append(part)
+            if clip_grad is not None:
+                masks.append(self._clip_mask([id(p) in clip_ids for p, _ in items], nb, dev))
         mult = inv_scale
         if clip_grad is not None:
-            total = partial[clip_mask.to(dev)].sum().sqrt() if bool(clip_mask.any()) else partial.new_zeros(())
+            total = torch.zeros((), dtype=torch.float32, device=dev)
+            for part, mask in zip(partials, masks):
+                if mask is not None:
+                    total = total + torch.where(mask, part, part.new_zeros(())).sum()
+            total = total.sqrt()
             self.last_grad_norm = total.reshape(1)
             coef = (float(clip_grad) / (total + 1e-6)).clamp(max=1.0)      # torch.nn.utils.clip_grad_norm_
             mult = inv_scale * coef
@@ -202,6 +251,20 @@ class NativeScaler:
                                  float(self.growth_factor), float(self.backoff_factor), int(self.growth_interval),
                                  ops._stream(self._scale))
         _lib.check(rc, "smoe_amp_update")
+
+    def _clip_mask(self, clipped, nb, dev):
+        """bool [n_blocks]: True for the partial sums of gradients that count towards the clipped norm (cached: the pattern
+        only changes with the parameter list); None when nothing is clipped."""
+        if not any(clipped):
+            return None
+        key = (str(dev), tuple(clipped), tuple(nb))
+        cache = self.__dict__.setdefault("_mask_cache", {})
+        m = cache.get(key)
+        if m is None:
+            if len(cache) > 8:
+                cache.clear()
+            m = cache[key] = torch.repeat_interleave(torch.tensor(clipped, dtype=torch.bool), torch.tensor(nb)).to(dev)
+        return m
 
     def _stock_step(self, optimizer, params, clip_grad, parameters):
         """GradScaler's sequence for optimizers that know nothing of device scalars (and for CPU tensors)."""

@@ -43,6 +43,31 @@ def test_adamw_kernel_matches_torch_adamw(gdt):
     assert float(a._step_counter(torch.device(DEV))) == 12.0
 
 
+def test_adamw_multi_tensor_launch_equals_per_tensor_launches_bitwise():
+    """One launch over every tensor of the step (two parameter groups with their own lr / weight decay) == one launch per
+    tensor, bit for bit, and == torch.optim.AdamW with the same groups."""
+    init = _params(5, SHAPES)
+    multi = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    single = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().double()) for t in init]
+    groups = lambda ps: [dict(params=ps[:3], lr=2e-3, weight_decay=0.05), dict(params=ps[3:], lr=5e-4, weight_decay=0.0)]
+    a = sm.AdamW(groups(multi), betas=(0.9, 0.999))
+    singles = [sm.AdamW([p], lr=(2e-3 if i < 3 else 5e-4), weight_decay=(0.05 if i < 3 else 0.0), betas=(0.9, 0.999))
+               for i, p in enumerate(single)]
+    b = torch.optim.AdamW(groups(ref), betas=(0.9, 0.999))
+    for it in range(5):
+        grads = _params(200 + it, SHAPES)
+        for p, q, r, g in zip(multi, single, ref, grads):
+            p.grad, q.grad, r.grad = g.to(DEV), g.to(DEV), g.double()
+        a.step()
+        for o in singles:
+            o.step()
+        b.step()
+    for p, q, r in zip(multi, single, ref):
+        assert torch.equal(p.detach(), q.detach())
+        assert (p.detach().cpu().double() - r.detach()).abs().max().item() <= 2e-6 * max(1.0, float(r.abs().max()))
+
+
 def test_native_scaler_step_matches_the_stock_sequence_and_skips_on_inf():
     """scale -> backward -> (unscale, clip, step, update) on device scalars == the stock sequence on a float64 twin:
     clipping engages (norm > max_norm), a step with an inf gradient is skipped (parameters, Adam moments AND the step
