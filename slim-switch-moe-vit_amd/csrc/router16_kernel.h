@@ -314,15 +314,41 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
       f32x2 acc[EB];
 #pragma unroll
       for (int e = 0; e < EB; ++e) acc[e] = f32x2{0.f, 0.f};
+      if constexpr (EB <= 8) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-        for (int e = 0; e < EB; ++e) {
-          const f32x4 w = *reinterpret_cast<const f32x4*>(lds_w + ub + (e * d + 64 * j));
-          acc[e] = __builtin_elementwise_fma(lo2(xv[j]), lo2(w), acc[e]);
-          acc[e] = __builtin_elementwise_fma(hi2(xv[j]), hi2(w), acc[e]);
+          for (int e = 0; e < EB; ++e) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(lds_w + ub + (e * d + 64 * j));
+            acc[e] = __builtin_elementwise_fma(lo2(xv[j]), lo2(w), acc[e]);
+            acc[e] = __builtin_elementwise_fma(hi2(xv[j]), hi2(w), acc[e]);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one chunk's weight reads next to their FMAs (else: e-major reorder + spills)
         }
-        __builtin_amdgcn_sched_barrier(0);  // one chunk's weight reads next to their FMAs (else: e-major reorder + spills)
+      } else {
+        // 16 / 32 experts: only one or two waves per SIMD fit (the weight image fills the LDS), so a chunk's reads followed by
+        // its FMAs left both pipes idle most of the time (E = 32: LDS 25 % busy, VALU 28 %, waves waiting 66 % of their cycles).
+        // Software pipeline over groups of 8 experts: the next group's eight 16-byte reads are in flight under the current
+        // group's sixteen packed FMAs (two register sets of 8 x 4).
+        constexpr int G = 8, GPJ = EB / G, NSTEP = NJ * GPJ;
+        f32x4 wq[2][G];
+        auto ldw = [&](int step, f32x4 (&dst)[G]) {
+          const int j = step / GPJ, e0 = (step % GPJ) * G;
+#pragma unroll
+          for (int g8 = 0; g8 < G; ++g8) dst[g8] = *reinterpret_cast<const f32x4*>(lds_w + ub + ((e0 + g8) * d + 64 * j));
+        };
+        ldw(0, wq[0]);
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+          const int j = step / GPJ, e0 = (step % GPJ) * G;
+          if (step + 1 < NSTEP) ldw(step + 1, wq[(step + 1) & 1]);
+#pragma unroll
+          for (int g8 = 0; g8 < G; ++g8) {
+            acc[e0 + g8] = __builtin_elementwise_fma(lo2(xv[j]), lo2(wq[step & 1][g8]), acc[e0 + g8]);
+            acc[e0 + g8] = __builtin_elementwise_fma(hi2(xv[j]), hi2(wq[step & 1][g8]), acc[e0 + g8]);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // keep the steps in order: reads of step + 1, then the FMAs of step
+        }
       }
 #pragma unroll
       for (int e = 0; e < EB; ++e) lg[e] = row16_sum(acc[e][0] + acc[e][1]) + lds_bias[e];
