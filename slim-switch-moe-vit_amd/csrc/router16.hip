@@ -2,6 +2,8 @@
 // path of smoe_router_topk, the fused LayerNorm + router, and the LayerNorm kernel.  The kernel template lives in
 // router16_kernel.h (shared with gate.hip, which instantiates the token-skip-gate variants).
 #include "router16_kernel.h"
+#include "router_mt_kernel.h"
+#include <cstdlib>
 
 namespace {
 using namespace r16;
@@ -139,10 +141,72 @@ int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, 
   return 0;
 }
 
+// 16 / 32 experts on the f32 matrix cores (router_mt_kernel.h); SMOE_ROUTER_MT=0 keeps the 16-lanes-per-token kernel (A/B)
+static bool use_router_mt() {
+  static const bool on = [] { const char* v = getenv("SMOE_ROUTER_MT"); return !(v && v[0] == '0'); }();
+  return on;
+}
+
+template <typename XT, int MP, bool LN, typename NT, int EB>
+int launch_mt(const void* x, const LnArgs& ln, const float* wg, const float* bg, const float* noise, int64_t T, int E, int k,
+              int gate_kind, int force_f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score, float* logits_out,
+              float* probs, hipStream_t s) {
+  using namespace rmt;
+  constexpr size_t smem = router_mt_smem<MP, LN, EB>();
+  static_assert(smem <= 160 * 1024, "router_mt: LDS image too large");
+  const int64_t n_tiles = (T + 15) / 16;
+  const int per_cu = (int)((160 * 1024) / smem) < 1 ? 1 : (int)((160 * 1024) / smem);
+  const int64_t max_wg = (int64_t)smoe_num_cus() * (per_cu > 2 ? 2 : per_cu);
+  // every workgroup the same number of tiles (the weight image is staged once per workgroup)
+  const int64_t iters = (n_tiles + max_wg - 1) / max_wg;
+  const int grid = (int)(n_tiles < 1 ? 1 : (n_tiles + iters - 1) / (iters < 1 ? 1 : iters));
+  SMOE_ENSURE_SMEM(router_mt_kernel<XT, MP, 0, LN, NT, EB>);
+  SMOE_ENSURE_SMEM(router_mt_kernel<XT, MP, 1, LN, NT, EB>);
+#define MT_LAUNCH(MODE, GRID, RC, RL)                                                                                  \
+  hipLaunchKernelGGL((router_mt_kernel<XT, MP, MODE, LN, NT, EB>), dim3(GRID), dim3(MT_THREADS), smem, s, (const XT*)x, \
+                     ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, noise, T, E, k, gate_kind, RC, RL, idx, score,  \
+                     logits_out, probs)
+  if (force_f64 && !LN) {
+    MT_LAUNCH(1, grid, nullptr, nullptr);
+    SMOE_CHECK_LAUNCH("smoe_router_topk/mt f64");
+    return 0;
+  }
+  hipError_t me = smoe_zero_words(rc, 4, s);
+  if (me != hipSuccess) {
+    smoe_set_error("smoe_router_topk: counter clear failed: %s", hipGetErrorString(me));
+    return (int)me;
+  }
+  MT_LAUNCH(0, grid, rc, rl);
+  SMOE_CHECK_LAUNCH("smoe_router_topk/mt f32");
+  if (force_f64) {   // f64 mode with LayerNorm: the f32 pass above wrote the normalised rows
+    MT_LAUNCH(1, grid, nullptr, nullptr);
+    SMOE_CHECK_LAUNCH("smoe_router_topk/mt f64");
+    return 0;
+  }
+  MT_LAUNCH(1, (grid < 16 ? grid : 16), rc, rl);
+  SMOE_CHECK_LAUNCH("smoe_router_topk/mt redo");
+#undef MT_LAUNCH
+  return 0;
+}
+
 template <typename XT, bool LN, typename NT>
 int dispatch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, const float* noise, int64_t T, int d,
                int E, int k, int gate_kind, int f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score, float* lo,
                float* pr, hipStream_t s) {
+  if (E > 8 && use_router_mt()) {
+    if (E > 16) {
+      switch (d) {
+        case 768: return launch_mt<XT, 6, LN, NT, 32>(x, ln, wg, bg, noise, T, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+        case 1024: return launch_mt<XT, 8, LN, NT, 32>(x, ln, wg, bg, noise, T, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+      }
+    } else {
+      switch (d) {
+        case 768: return launch_mt<XT, 6, LN, NT, 16>(x, ln, wg, bg, noise, T, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+        case 1024: return launch_mt<XT, 8, LN, NT, 16>(x, ln, wg, bg, noise, T, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);
+      }
+    }
+    return -1;
+  }
   if (E > 16) {  // 32 experts per lane (one workgroup per CU: the f32 weight image is 96-128 KB); ViT-B / ViT-L widths
     switch (d) {
       case 768: return launch16<XT, 12, LN, NT, 32>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, f64, rc, rl, idx, score, lo, pr, s);

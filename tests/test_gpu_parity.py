@@ -71,6 +71,25 @@ def test_router_naive_matches_oracle(T, d, E, k, dtype, force_f64):
         assert torch.all(score == 1.0)
 
 
+@pytest.mark.parametrize("d,E,scale", [(1024, 32, 1.0), (768, 16, 1.0), (1024, 20, 40.0), (768, 32, 1e-3)])
+def test_router_matrix_core_logits_stay_inside_the_error_bound(d, E, scale):
+    """The 16- / 32-expert router accumulates its logits on the f32 matrix cores (csrc/router_mt_kernel.h), whose internal
+    summation order is not documented.  Its redo list is only as rigorous as its bound: the f32 logits must sit well
+    inside `4 (d / 16 + 6) 2^-24 |row| max|w_e|` of the f64 values (observed <= a quarter of it leaves the factor-4 margin)."""
+    T = 4096
+    g = _gen(d + E)
+    x = (torch.randn(T, d, generator=g) * scale)
+    wg = torch.randn(E, d, generator=g) * 0.05
+    bg = torch.randn(E, generator=g) * 0.1
+    _, _, logits, _ = ops.router_topk(x.to(DEV), wg.to(DEV), bg.to(DEV), 1, ops.GATE_NAIVE, want_logits=True)
+    ref = x.double() @ wg.double().t() + bg.double()
+    err = (logits.cpu().double() - ref).abs().max(dim=1).values
+    bound = 4.0 * (d / 16 + 6) * 2.0 ** -24 * x.double().norm(dim=1) * wg.double().norm(dim=1).max()
+    ratio = float((err / bound).max())
+    print(f"d {d} E {E}: max |f32 - f64| / bound = {ratio:.4f}")
+    assert ratio <= 0.25, ratio
+
+
 def test_router_zero_rows_route_by_bias_with_lowest_id_tie_break():
     x = torch.zeros(300, 192)
     wg = torch.randn(8, 192, generator=_gen(0))
