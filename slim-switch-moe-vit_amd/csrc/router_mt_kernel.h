@@ -76,7 +76,7 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
   constexpr int d = 128 * MP, dq = 32 * MP, WP = d + 16, NTL = EB / 16, PS = EB + 4, NACC = 4;
   static_assert(EB == 16 || EB == 32, "16 or 32 expert rows");
   float* lds_w = reinterpret_cast<float*>(smem);   // [EB][WP = d + 16] (the 64-byte row pad and the XOR below make the fragment reads
-                                                   // conflict-free), rows >= E zero; 16-byte slot s of a 128-byte group of row e sits at s ^ (e & 7)
+                                                   // conflict-free), rows >= E repeat row E - 1 (masked by every consumer); 16-byte slot s of a 128-byte group of row e sits at s ^ (e & 7)
   float* lds_wn2 = lds_w + EB * WP;                // [EB]
   float* lds_bias = lds_wn2 + EB;                  // [EB]
   float* lds_g = lds_bias + EB;                    // [d] LayerNorm weight, [d] bias (LN only)
@@ -122,24 +122,20 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
   };
   if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x, xv);   // the first rows travel under the weight staging
 
-  {  // weight image -> LDS (swizzled), eight 16-byte loads in flight per thread
-    constexpr int WU = 8;
-    for (int base = tid * 4; base < EB * d; base += MT_THREADS * 4 * WU) {
-      f32x4 v[WU];
-#pragma unroll
-      for (int q8 = 0; q8 < WU; ++q8) {
-        const int i = base + q8 * MT_THREADS * 4;
-        v[q8] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < EB * d && i / d < E) v[q8] = *reinterpret_cast<const f32x4*>(wg + i);
-      }
-#pragma unroll
-      for (int q8 = 0; q8 < WU; ++q8) {
-        const int i = base + q8 * MT_THREADS * 4;
-        if (i < EB * d) {
-          const int e = i / d, c = i - e * d;
-          *reinterpret_cast<f32x4*>(lds_w + e * WP + (c ^ ((e & 7) << 2))) = v[q8];
-        }
-      }
+  {  // weight image -> LDS by LDS-DMA (no registers, every piece in flight at once: staging through VGPRs was four dependent
+     // rounds of loads, ~8 us per launch).  A wave-instruction fills 1 KiB of LDS linearly, so the SOURCE address carries the
+     // layout: 16-byte unit L of the image = row e = L / (WP / 4), slot s; slot s holds source slot s ^ (e & 7) of its 8-slot
+     // group.  Pad slots read any valid address (never read back); rows >= E repeat row E - 1 (every consumer masks e >= E).
+    constexpr int UNITS_PER_ROW = WP / 4, N_KIB = EB * WP * 4 / 1024;
+    static_assert(EB * WP * 4 % 1024 == 0, "whole 1-KiB pieces");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // the DMA's LDS base is wave-uniform (M0)
+    for (int pc = wave_u; pc < N_KIB; pc += MT_THREADS / 64) {
+      const int L = pc * 64 + lane;
+      const int e = L / UNITS_PER_ROW, sl = L - e * UNITS_PER_ROW;
+      const int ec = e < E ? e : E - 1;
+      const int src_slot = sl < d / 4 ? ((sl & ~7) | ((sl & 7) ^ (e & 7))) : 0;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + (int64_t)ec * d + 4 * src_slot),
+                                       (__attribute__((address_space(3))) void*)(smem + pc * 1024), 16, 0, 0);
     }
     if (tid < EB) lds_bias[tid] = (bg && tid < E) ? bg[tid] : 0.f;
     if (LN) {
@@ -149,6 +145,7 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces (and the first rows) have landed
   __syncthreads();
   for (int e = wave; MODE == 0 && e < EB; e += MT_THREADS / 64) {  // squared row norms (any column order): 16-byte reads, all in flight
     f32x4 q4 = f32x4{0.f, 0.f, 0.f, 0.f};
