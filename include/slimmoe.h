@@ -174,6 +174,14 @@ int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int
                       const void* residual, const int64_t* a_gather, int a_div,
                       void* out, int out_dtype, int variant, void* stream);
 
+/* smoe_grouped_gemm_gelu_keep: the first expert linear of the TRAINING forward (fmoe_cuda.linear_forward + the activation, whose
+ * input autograd keeps): pre_out = A W^T + bias and out = gelu(pre_out), both [m_rows, N] in the operand dtype (f16 / bf16), from one
+ * epilogue.  Returns -1 (no error set) for shapes outside the persistent kernel's reach (K % 64 != 0, operands >= 4 GiB, G > 63):
+ * use smoe_grouped_gemm(SMOE_EPI_NONE) + smoe_gelu then.                                                                        */
+int smoe_grouped_gemm_gelu_keep(const void* A, const void* W, const float* bias, const int32_t* offsets,
+                                const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
+                                int ab_dtype, void* pre_out, void* out, void* stream);
+
 /* ---- backward pieces (fmoe_cuda.linear_backward and the adjoints of scatter / gather) ---------
  * smoe_gelu:            dst = gelu_erf(src), n % 8 == 0 (training forward keeps the pre-activations)
  * smoe_rowdot:          dscore[i] = <dout[i / k, :], y[inv_pos[i], :]>, 0 for dropped entries (i < n = T*k)

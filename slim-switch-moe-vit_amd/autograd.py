@@ -102,9 +102,8 @@ class _GroupFFN(torch.autograd.Function):
         cd = rows.dtype
         ex = mod.experts
         w1c, w2c = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
-        Hp = ops.grouped_gemm(rows, w1c, b1.detach().float() if b1 is not None else None, offsets, ops.EPI_NONE, cd,
-                              variant=mod.gemm_variant, group_expert=group_expert)
-        A = ops.gelu(Hp)
+        Hp, A = ops.grouped_gemm_gelu_keep(rows, w1c, b1.detach().float() if b1 is not None else None, offsets,
+                                           group_expert=group_expert, variant=mod.gemm_variant)
         if drop_mask is not None:
             A = A * drop_mask
         Y = ops.grouped_gemm(A, w2c, b2.detach().float() if b2 is not None else None, offsets, ops.EPI_NONE, cd,

@@ -1379,6 +1379,25 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   return 1;
 }
 
+// First expert linear of the TRAINING forward: pre_out = A W^T + bias (kept for gelu' in the backward) and out = gelu(pre_out),
+// both in the operand dtype, from one epilogue of the persistent kernel.  Returns -1 when the shape is outside that kernel's
+// reach (K % 64, operands of 4 GiB and more, more than 63 row groups): the caller then runs SMOE_EPI_NONE + smoe_gelu.
+extern "C" int smoe_grouped_gemm_gelu_keep(const void* A, const void* W, const float* bias, const int32_t* offsets,
+                                           const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
+                                           int ab_dtype, void* pre_out, void* out, void* stream) {
+  SMOE_REQUIRE(offsets && G >= 1 && n_experts >= 1 && (group_expert || n_experts == G), "smoe_grouped_gemm_gelu_keep: bad groups");
+  SMOE_REQUIRE(m_rows_max >= 0 && m_rows_max < (1ll << 31) && K > 0 && N > 0 && N % 8 == 0, "smoe_grouped_gemm_gelu_keep: bad sizes");
+  SMOE_REQUIRE(ab_dtype == SMOE_F16 || ab_dtype == SMOE_BF16, "smoe_grouped_gemm_gelu_keep: 16-bit operands only");
+  if (m_rows_max == 0) return 0;
+  SMOE_REQUIRE(A && W && pre_out && out, "smoe_grouped_gemm_gelu_keep: null pointer");
+  const uint64_t a_bytes = (uint64_t)m_rows_max * (uint64_t)K * 2u, w_bytes = (uint64_t)n_experts * (uint64_t)N * (uint64_t)K * 2u;
+  if (K % 64 != 0 || G > 63 || a_bytes >= (1ull << 32) || w_bytes >= (1ull << 32)) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  if (ab_dtype == SMOE_F16)
+    return launch_ps<f16, f16, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1);
+  return launch_ps<bf16_bits, bf16_bits, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1);
+}
+
 // Weight gradients of a grouped linear (fmoe_cuda.linear_backward's grad_W):
 //   out[e] (f32 [R1,R2]) = PT[:, offsets_pad[e]:offsets_pad[e+1]] @ QT[:, same]^T
 // PT [R1,Lp], QT [R2,Lp] are the K-major, 64-padded images made by smoe_transpose_pad (e.g. PT = dY^T, QT = A^T

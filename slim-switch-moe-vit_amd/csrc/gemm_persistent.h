@@ -30,7 +30,11 @@ __device__ unsigned long long smoe_diag_stamps[256 * 12 * 16];
 #define PS_STAMP(i) do {} while (0)
 #endif
 
-template <typename AB, typename OT, int AFR, bool DEEP>
+// KEEP (training forward of the first expert linear): the epilogue stores BOTH the pre-activation H = A W^T + b and gelu(H) --
+// the backward needs H for gelu' and gelu(H) as the operand of the second linear's weight gradient; a separate GELU pass over
+// H was 620 MB of HBM traffic (110 us at ViT-B).  `residual` carries the address that RECEIVES H; no row map / residual fusion.
+// Its own instantiation (320-row tile, 5 staging passes of 2 x 64 rows): the inference kernels' registers are untouched.
+template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false>
 __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
@@ -247,9 +251,10 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   constexpr int BIAS_BYTES = 2048;        // two 1-KiB bias tiles (256 f32) at the top of the LDS, alternating per tile
   constexpr int ROWBUF_BYTES = TBM * 4;   // below them: the next tile's gathered row numbers (i32), prefetched by DMA
   constexpr int EPI_BYTES = LDS_TOTAL - STAGE - BIAS_BYTES - ROWBUF_BYTES;
-  constexpr int NPASS = (TBM * C_STRIDE <= EPI_BYTES) ? 1 : ((TBM / 2) * C_STRIDE <= EPI_BYTES ? 2 : (AFR == 4 ? 4 : 5));
+  static_assert(!KEEP || (AFR == 5 && !DEEP && OB == 2), "the two-output epilogue is instantiated for the 320-row tile, 16-bit outputs");
+  constexpr int NPASS = KEEP ? 5 : ((TBM * C_STRIDE <= EPI_BYTES) ? 1 : ((TBM / 2) * C_STRIDE <= EPI_BYTES ? 2 : (AFR == 4 ? 4 : 5)));
   constexpr int RP = TBM / NPASS;
-  static_assert(RP * C_STRIDE <= EPI_BYTES, "epilogue pass does not fit behind buffer 0");
+  static_assert((KEEP ? 2 : 1) * RP * C_STRIDE <= EPI_BYTES, "epilogue pass does not fit behind buffer 0");
   constexpr int CHUNKS = TBN * OB / 16;   // 16-B chunks per tile row
   constexpr int TPR = 16;                 // threads per output row: 16 consecutive threads = 256 contiguous bytes
   constexpr int CPT = CHUNKS / TPR;       // chunks per thread per row (strided by 256 B)
@@ -260,6 +265,9 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   constexpr int MPP = HALF / 16;
   static_assert(HALF % 16 == 0 && MPP * NPASS == MI, "epilogue pass split");
   char* const cst = smem + STAGE;         // output staging
+  char* const cst2 = cst + RP * C_STRIDE; // KEEP: the pre-activations of the same rows
+  const OT* const resid = KEEP ? nullptr : residual;
+  OT* const pre_out = KEEP ? const_cast<OT*>(residual) : nullptr;
   // The tile's bias row reaches the epilogue through LDS by DMA (one 1-KiB piece, wave 0), issued with the tile's first
   // operand pieces: an ordinary load in the epilogue would make hipcc drain the whole vector-memory queue -- the next
   // tile's operand DMAs included -- at its first use (cdna_hip_programming.md section 5, "Pipelining across barriers").
@@ -444,8 +452,9 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           f32x4 v = acc[mi][ni] + bv[ni];
-          if (epilogue == SMOE_EPI_GELU) v = gelu_fast4(v);
           const int nl = wc * TN + ni * 16 + fq * 4;
+          if constexpr (KEEP) OutPack<OT>::write4(cst2 + (wr * HALF + mm * 16 + fr) * C_STRIDE + nl * OB, v);
+          if (KEEP || epilogue == SMOE_EPI_GELU) v = gelu_fast4(v);
           OutPack<OT>::write4(cst + (wr * HALF + mm * 16 + fr) * C_STRIDE + nl * OB, v);
         }
       }
@@ -469,8 +478,8 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
         for (int j = 0; j < CPT; ++j) {
           const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
           dst[j] = u32x4{0u, 0u, 0u, 0u};
-          if (residual && orow[it] >= 0 && ncol < N)
-            dst[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(residual) + ((int64_t)orow[it] * N + ncol) * OB);
+          if (resid && orow[it] >= 0 && ncol < N)
+            dst[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(resid) + ((int64_t)orow[it] * N + ncol) * OB);
         }
       };
       u32x4 resv[CPT], resn[CPT];
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
         for (int j = 0; j < CPT; ++j) {
           v[j] = *reinterpret_cast<const u32x4*>(cst + r * C_STRIDE + (tcol + j * TPR) * 16);
           if (row_map && row_scale) v[j] = scale16<OT>(v[j], oscale[it]);
-          if (residual) v[j] = fuse_aux<OT>(epilogue, resv[j], v[j]);
+          if (resid) v[j] = fuse_aux<OT>(epilogue, resv[j], v[j]);
         }
         if (it + 1 < ITS) res_fetch(it + 1, resn);
         if (orow[it] >= 0) {
@@ -492,6 +501,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
           for (int j = 0; j < CPT; ++j) {
             const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
             if (ncol < N) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + (rbase + ncol) * OB) = v[j];
+          }
+          if constexpr (KEEP) {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+              const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
+              const u32x4 h2 = *reinterpret_cast<const u32x4*>(cst2 + r * C_STRIDE + (tcol + j * TPR) * 16);
+              if (ncol < N) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(pre_out) + (rbase + ncol) * OB) = h2;
+            }
           }
         }
 #pragma unroll
@@ -512,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
 #undef PS_DMA
 }
 
-template <typename AB, typename OT, int AFR, bool DEEP>
+template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false>
 int launch_ps(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert, int E,
               int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
               const void* residual, void* out, int group_m, hipStream_t s, const int64_t* a_gather, int a_div) {
@@ -525,8 +542,8 @@ int launch_ps(const void* A, const void* W, const float* bias, const int32_t* of
 #ifdef SMOE_DIAG
   if (const char* gcap = getenv("SMOE_PS_GRID")) grid = atoi(gcap) & ~7;   // diagnostic: fewer CUs (is a phase chip- or CU-bound?)
 #endif
-  SMOE_ENSURE_SMEM(grouped_gemm_ps<AB, OT, AFR, DEEP>);
-  hipLaunchKernelGGL((grouped_gemm_ps<AB, OT, AFR, DEEP>), dim3(grid), dim3(512), 160 * 1024, s, (const AB*)A, (const AB*)W,
+  SMOE_ENSURE_SMEM(grouped_gemm_ps<AB, OT, AFR, DEEP, KEEP>);
+  hipLaunchKernelGGL((grouped_gemm_ps<AB, OT, AFR, DEEP, KEEP>), dim3(grid), dim3(512), 160 * 1024, s, (const AB*)A, (const AB*)W,
                      bias, offsets, group_expert, E, K, N, epilogue, row_map, row_scale, (const OT*)residual, (OT*)out,
                      n_tiles_n, group_m, a_gather, a_div, (int)m_rows_max);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm/persistent");

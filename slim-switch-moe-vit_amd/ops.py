@@ -408,6 +408,34 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+def grouped_gemm_gelu_keep(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], offsets: torch.Tensor,
+                           group_expert: Optional[torch.Tensor] = None, variant: int = DEFAULT_GEMM_VARIANT):
+    """(H, gelu(H)) with H = A W[e]^T + bias[e] per row group -- the first expert linear of the training forward, which keeps
+    both (gelu' needs H, the second linear's weight gradient needs gelu(H)): one epilogue with two stores where the kernel
+    has it, else the GEMM followed by the GELU pass."""
+    _chk(A, "A", ndim=2)
+    _chk(W, "W", A.dtype, 3)
+    _chk(offsets, "offsets", torch.int32, 1)
+    M, K = A.shape
+    E, N, _ = W.shape
+    G = offsets.numel() - 1
+    if A.dtype in (torch.float16, torch.bfloat16) and W.shape[2] == K and (group_expert is not None or G == E):
+        if bias is not None:
+            _chk(bias, "bias", torch.float32, 2)
+        if group_expert is not None:
+            _chk(group_expert, "group_expert", torch.int32, 1)
+        pre = torch.empty((M, N), dtype=A.dtype, device=A.device)
+        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+        rc = _lib.load().smoe_grouped_gemm_gelu_keep(_ptr(A), _ptr(W), _ptr(bias), _ptr(offsets), _ptr(group_expert), G, E, M, K, N,
+                                                     dtype_code(A.dtype), _ptr(pre), _ptr(out), _stream(A))
+        if rc == 0:
+            return pre, out
+        if rc != -1:
+            _lib.check(rc, "smoe_grouped_gemm_gelu_keep")
+    pre = grouped_gemm(A, W, bias, offsets, EPI_NONE, A.dtype, variant=variant, group_expert=group_expert)
+    return pre, gelu(pre)
+
+
 def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     _chk(src, "src")
     dst = torch.empty(src.shape, dtype=dtype, device=src.device)

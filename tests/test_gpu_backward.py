@@ -354,3 +354,26 @@ def test_transpose_cast_is_the_transposed_rounded_copy(shape, src, dst):
     assert torch.equal(got, w.transpose(1, 2).to(dst).contiguous())
     with pytest.raises(ValueError):
         ops.transpose_cast(w[:, :, :-8].contiguous(), dst)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("counts,K,N", [([300, 0, 517, 64], 128, 264), ([700, 650, 1, 900, 0, 320, 321, 1280], 768, 3072)])
+def test_grouped_gemm_gelu_keep_matches_the_two_step_form(counts, K, N, dtype):
+    """One epilogue, two stores (H and gelu(H)) == SMOE_EPI_NONE followed by smoe_gelu: H bit for bit (same accumulators, same
+    rounding), gelu(H) within the 16-bit rounding of the two GELU forms (the fused epilogue applies GELU to the f32 value, the
+    pass to the rounded H)."""
+    E = len(counts)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device=DEV)
+    n = sum(counts)
+    g = _gen(n + K)
+    A = (torch.randn(n, K, generator=g) * 0.5).to(dtype).to(DEV)
+    W = (torch.randn(E, N, K, generator=g) * 0.05).to(dtype).to(DEV)
+    b = (torch.randn(E, N, generator=g) * 0.1).to(DEV)
+    pre, act = ops.grouped_gemm_gelu_keep(A, W, b, offsets)
+    ref_pre = ops.grouped_gemm(A, W, b, offsets, ops.EPI_NONE, dtype, variant=10)
+    assert torch.equal(pre, ref_pre)
+    ref_act = torch.nn.functional.gelu(ref_pre.float()).to(dtype)
+    tol = 2 ** -10 if dtype == torch.float16 else 2 ** -7
+    assert (act.float() - ref_act.float()).abs().max().item() <= tol * max(1.0, float(ref_act.float().abs().max()))
+    fused = ops.grouped_gemm(A, W, b, offsets, ops.EPI_GELU, dtype, variant=10)
+    assert torch.equal(act, fused)   # the same epilogue arithmetic as the inference kernel's
