@@ -197,6 +197,12 @@ int smoe_rowdot(const void* dout, int dout_dtype, const void* y, int y_dtype, co
 int smoe_pad_offsets(const int32_t* offsets, int E, int32_t* offsets_pad, void* stream);
 int smoe_transpose_pad(const void* src, int dtype, const int32_t* offsets, const int32_t* offsets_pad, int E,
                        int64_t n_rows, int C, int Lp, void* dst, void* stream);
+/* smoe_switch_gate_bwd: gradient of the SwitchGate's score and load-balance loss w.r.t. the router logits (fmoe.gates.SwitchGate:
+ * score = softmax(logits)[idx], aux = E sum_e frac_e prob_e), one pass over [T, E]:  g[t,e] = coef[e] + (e == idx[t] ? dscore[t] : 0),
+ * dlogits[t,e] = probs[t,e] (g[t,e] - sum_j probs[t,j] g[t,j]).  coef [E] f32 (device; = daux * E * frac_e / kept) or NULL,
+ * dscore [T] f32 or NULL, idx [T] int64 (entries outside [0, E) select nothing).                                               */
+int smoe_switch_gate_bwd(const float* probs, const int64_t* idx, const float* dscore, const float* coef, int64_t T, int E,
+                         float* dlogits, void* stream);
 /* smoe_transpose_cast: dst[b][c][r] = (dst_dtype) src[b][r][c] for b < B; R % 64 == 0, C % 64 == 0.  The backward pass reads every
  * expert weight [E, out, in] a second time as [E, in, out] (FastMoE: `MOELinear.backward` -> fmoe_cuda.linear_backward contracts
  * grad_out with the weight over `out`); this makes that 16-bit image straight from the f32 master in one pass.               */

@@ -178,6 +178,28 @@ class _GateLogits(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _SwitchScoreAux(torch.autograd.Function):
+    """SwitchGate's differentiable outputs from what the HIP router already computed: score = softmax(logits + noise)[idx] and
+    the load-balance loss aux = E sum_e frac_e prob_e (fmoe.gates.SwitchGate).  Forward: the router's probabilities
+    and score, an [E]-sized reduction for aux.  Backward: ONE pass over [T, E] (smoe_switch_gate_bwd) instead of the ~25 small
+    autograd kernels of softmax / gather / bincount / where."""
+
+    @staticmethod
+    def forward(ctx, logits, probs, score, idx, counts, E):
+        kept = counts.sum().clamp(min=1).to(torch.float32)
+        frac = counts.to(torch.float32) / kept                      # share of kept tokens per expert (dropped ones count nowhere)
+        aux = E * (frac * (probs.sum(0) / kept)).sum()
+        ctx.save_for_backward(probs, idx, (E * frac / kept).contiguous())   # d aux / d p[t, e], the same for every t
+        return score.clone(), aux
+
+    @staticmethod
+    def backward(ctx, dscore, daux):
+        probs, idx, cbase = ctx.saved_tensors
+        coef = (cbase * daux.to(cbase.dtype)).contiguous() if daux is not None else None
+        ds = dscore.reshape(-1).to(torch.float32).contiguous() if dscore is not None else None
+        return ops.switch_gate_bwd(probs, idx.reshape(-1), ds, coef), None, None, None, None, None
+
+
 def _route_train(mod, x):
     """HIP routing + the differentiable gate score; returns (idx, score, plan tensors)."""
     from .fmoe import SwitchGate
@@ -191,18 +213,16 @@ def _route_train(mod, x):
     gb = g.gate.bias.detach().float() if g.gate.bias is not None else None
     need_grad = is_switch or k > 1
     with torch.no_grad():
-        idx, score_c, logits_r, _ = ops.router_topk(x.detach(), gw, gb, k, g.kind, noise, want_logits=need_grad)
+        idx, score_c, logits_r, probs_r = ops.router_topk(x.detach(), gw, gb, k, g.kind, noise, want_logits=need_grad,
+                                                          want_probs=is_switch)
         cap = g.capacity(T)
         counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, g.tot_expert, cap)
     mod.last_plan = (idx, score_c, counts, offsets, pos, inv_pos)
     if need_grad:  # tiny [T,E] work -- the routing itself stays the HIP router's
         logits = _GateLogits.apply(x, g.gate.weight, g.gate.bias, logits_r)
-        if is_switch:
-            if noise is not None:
-                logits = logits + noise
-            probs = torch.softmax(logits, dim=-1)
-            score = probs.gather(1, idx)
-            g.set_loss(switch_aux_loss(pruned if pruned is not None else idx, probs, g.tot_expert))
+        if is_switch:   # probs_r = softmax(logits + noise) and score_c = probs_r[idx] are the router's own
+            score, aux = _SwitchScoreAux.apply(logits, probs_r, score_c, idx, counts, g.tot_expert)
+            g.set_loss(aux)
         else:
             score = torch.softmax(logits.gather(1, idx), dim=-1)
     else:

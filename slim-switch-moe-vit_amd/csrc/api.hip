@@ -75,5 +75,5 @@ extern "C" int smoe_init(void) {
   return 0;
 }
 
-extern "C" int smoe_abi_version(void) { return 17; }
+extern "C" int smoe_abi_version(void) { return 18; }
 extern "C" const char* smoe_last_error(void) { return g_err; }

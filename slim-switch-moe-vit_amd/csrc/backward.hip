@@ -144,6 +144,24 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const ST* __restric
   }
 }
 
+// SwitchGate backward in one pass over [T, E] (fmoe.gates.SwitchGate: score = softmax(logits)[idx], aux = E sum_e frac_e prob_e):
+//   g[t, e] = coef[e] + (e == idx[t] ? dscore[t] : 0)          coef[e] = d aux / d p[t, e] = daux * E * frac_e / kept (any t)
+//   dlogits[t, e] = p[t, e] * (g[t, e] - sum_j p[t, j] g[t, j])                                     (softmax backward)
+// One thread per token; the row (E <= 64 floats) is read twice from L1.
+__global__ __launch_bounds__(256) void switch_gate_bwd_kernel(const float* __restrict__ probs, const int64_t* __restrict__ idx,
+                                                              const float* __restrict__ dscore, const float* __restrict__ coef,
+                                                              int64_t T, int E, float* __restrict__ dlogits) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const float* p = probs + t * E;
+  const int64_t sel = idx[t];
+  const float ds = dscore ? dscore[t] : 0.f;
+  float dot = 0.f;
+  for (int e = 0; e < E; ++e) dot = fmaf(p[e], (coef ? coef[e] : 0.f) + (e == sel ? ds : 0.f), dot);
+  float* o = dlogits + t * E;
+  for (int e = 0; e < E; ++e) o[e] = p[e] * ((coef ? coef[e] : 0.f) + (e == sel ? ds : 0.f) - dot);
+}
+
 // Bias gradients, two deterministic passes.  Pass 1: one workgroup per (512-row chunk of one expert, 256-column slab);
 // wave w sums the chunk's rows w, w+4, ... (a row of the slab is 256 contiguous elements = one 8-byte load per lane),
 // the four waves meet in LDS and the workgroup stores one f32 partial row.  The grid is an upper bound (the row
@@ -470,4 +488,15 @@ extern "C" int smoe_transpose_cast(const void* src, int src_dtype, void* dst, in
     case SMOE_F16: return transpose_cast_launch<f16>(src, dst, dst_dtype, B, R, C, s);
     default: return transpose_cast_launch<bf16_bits>(src, dst, dst_dtype, B, R, C, s);
   }
+}
+
+extern "C" int smoe_switch_gate_bwd(const float* probs, const int64_t* idx, const float* dscore, const float* coef, int64_t T, int E,
+                                    float* dlogits, void* stream) {
+  SMOE_REQUIRE(T >= 0 && E >= 1 && E <= 4096, "smoe_switch_gate_bwd: bad sizes T=%lld E=%d", (long long)T, E);
+  if (T == 0) return 0;
+  SMOE_REQUIRE(probs && idx && dlogits, "smoe_switch_gate_bwd: null pointer");
+  hipLaunchKernelGGL(switch_gate_bwd_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, probs, idx, dscore,
+                     coef, T, E, dlogits);
+  SMOE_CHECK_LAUNCH("smoe_switch_gate_bwd");
+  return 0;
 }

@@ -480,6 +480,24 @@ def rowdot(dout: torch.Tensor, y: torch.Tensor, inv_pos: torch.Tensor, k: int) -
     return out
 
 
+def switch_gate_bwd(probs: torch.Tensor, idx: torch.Tensor, dscore: Optional[torch.Tensor], coef: Optional[torch.Tensor]) -> torch.Tensor:
+    """dlogits [T, E] of the SwitchGate's score (= probs[t, idx[t]]) and load-balance loss in one pass (softmax backward of
+    g[t, e] = coef[e] + (e == idx[t]) dscore[t])."""
+    _chk(probs, "probs", torch.float32, 2, align=4)
+    T, E = probs.shape
+    _chk(idx, "idx", torch.int64, align=8)
+    if idx.numel() != T:
+        raise RuntimeError("switch_gate_bwd: one index per token")
+    if dscore is not None:
+        _chk(dscore, "dscore", torch.float32, align=4)
+    if coef is not None:
+        _chk(coef, "coef", torch.float32, 1, align=4)
+    out = torch.empty_like(probs)
+    rc = _lib.load().smoe_switch_gate_bwd(_ptr(probs), _ptr(idx), _ptr(dscore), _ptr(coef), T, E, _ptr(out), _stream(probs))
+    _lib.check(rc, "smoe_switch_gate_bwd")
+    return out
+
+
 def pad_offsets(offsets: torch.Tensor) -> torch.Tensor:
     _chk(offsets, "offsets", torch.int32, 1)
     out = torch.empty_like(offsets)
