@@ -90,6 +90,53 @@ def test_router_matrix_core_logits_stay_inside_the_error_bound(d, E, scale):
     assert ratio <= 0.25, ratio
 
 
+@pytest.mark.parametrize("T", [1, 3, 16, 17, 33])
+@pytest.mark.parametrize("d,E,k", [(768, 16, 2), (1024, 32, 1), (768, 27, 4)])
+def test_router_matrix_core_partial_tiles_and_edges(T, d, E, k):
+    """The 16-token tiles of the matrix-core router with fewer live tokens than slots, an expert count that is not a
+    multiple of 16 (rows past E repeat the last expert's weights and must be masked everywhere), up to 4 choices; logits,
+    probabilities and scores of every token against the oracle."""
+    g = _gen(1000 * T + E)
+    x = torch.randn(T, d, generator=g)
+    wg = torch.randn(E, d, generator=g) * 0.05
+    bg = torch.randn(E, generator=g) * 0.1
+    idx, score, logits, _ = ops.router_topk(x.to(DEV), wg.to(DEV), bg.to(DEV), k, ops.GATE_NAIVE, want_logits=True)
+    o_idx, o_score, _ = mo.naive_gate(x, wg, bg, k)
+    assert torch.equal(idx.cpu(), o_idx)
+    assert torch.allclose(score.cpu(), o_score, rtol=0, atol=5e-6)
+    ref = x.double() @ wg.double().t() + bg.double()
+    assert (logits.cpu().double() - ref).abs().max().item() <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("d,E", [(768, 16), (1024, 32)])
+def test_router_matrix_core_zero_rows_near_ties_and_switch_probabilities(d, E):
+    """(a) all-zero rows route by the biases, ties to the lowest id, without visiting the redo pass' arithmetic; (b) exact and
+    near ties between experts in different 16-expert blocks and different lanes of the row go through the f64 matrix-core
+    pass and come out as the oracle orders them; (c) the switch gate's probabilities, scores and noise handling."""
+    g = _gen(31 + E)
+    T = 2000
+    x = torch.randn(T, d, generator=g)
+    x[::7] = 0.0
+    wg = torch.randn(E, d, generator=g) * 0.03
+    wg[E - 1] = wg[2]                          # exact tie across blocks / lanes
+    wg[9] = wg[1]; wg[9, 33] += 2e-9           # near ties far below the f32 accumulation error
+    wg[E - 3] = wg[1]; wg[E - 3, d - 5] -= 4e-9
+    bg = torch.zeros(E)
+    bg[4] = bg[E - 2] = 0.5                    # zero rows: experts 4 and E - 2 tie on the bias -> 4 first
+    for k in (1, 2, 3):
+        idx, score, _, _ = ops.router_topk(x.to(DEV), wg.to(DEV), bg.to(DEV), k, ops.GATE_NAIVE)
+        o_idx, o_score, _ = mo.naive_gate(x, wg, bg, k)
+        assert torch.equal(idx.cpu(), o_idx), k
+        assert torch.allclose(score.cpu(), o_score, rtol=0, atol=5e-6)
+        assert torch.all(idx[::7, 0].cpu() == 4)
+    noise = torch.rand(T, E, generator=g) * 0.2 + 0.9
+    idx, score, _, probs = ops.router_topk(x.to(DEV), wg.to(DEV), bg.to(DEV), 1, ops.GATE_SWITCH, noise.to(DEV), want_probs=True)
+    o_idx, o_score, o_p = mo.switch_gate(x, wg, bg, noise)
+    assert torch.equal(idx.cpu(), o_idx)
+    assert torch.allclose(score.cpu(), o_score, rtol=0, atol=5e-6)
+    assert torch.allclose(probs.cpu(), o_p, rtol=0, atol=5e-6)
+
+
 def test_router_zero_rows_route_by_bias_with_lowest_id_tie_break():
     x = torch.zeros(300, 192)
     wg = torch.randn(8, 192, generator=_gen(0))
