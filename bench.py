@@ -392,7 +392,13 @@ def main():
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                 gl = model(images[: args.cpu_batch]).float().cpu()
             out["parity"] = hot_path_parity(model, sd_cpu, device)
-            out["parity"]["model_logits_max_abs_diff_vs_cpu_fp32"] = float((gl - cpu_logits).abs().max())
+            # whole model, fp16 autocast on the GPU against the fp32 CPU oracle: NOT a parity bar -- a top-1 router turns a
+            # last-bit difference in a near-tied token into a different expert, and that image's logits then differ visibly
+            # (tests/test_gpu_model.py attributes every such flip to a logit gap below the fp16 perturbation).  Per image:
+            per_img = (gl - cpu_logits).abs().amax(dim=1)
+            out["parity"]["model_logits_max_abs_diff_vs_cpu_fp32"] = float(per_img.max())
+            out["parity"]["model_logits_per_image_median_max_abs_diff"] = float(per_img.median())
+            out["parity"]["model_images_within_2e-2_of_cpu_fp32"] = f"{int((per_img <= 2e-2).sum())} / {per_img.numel()}"
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_ep:
         dist.destroy_process_group()
