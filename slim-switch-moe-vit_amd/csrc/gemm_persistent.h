@@ -266,6 +266,12 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   static_assert(HALF % 16 == 0 && MPP * NPASS == MI, "epilogue pass split");
   char* const cst = smem + STAGE;         // output staging
   char* const cst2 = cst + RP * C_STRIDE; // KEEP: the pre-activations of the same rows
+  // Row-mapped stores (the fused combine): the tile's output rows and combine scales are resolved ONCE per tile into LDS behind
+  // the staging rows, where there is room for them -- resolved per pass, the chain row_map -> row_scale -> residual put two
+  // exposed global-load latencies in front of every pass's stores.
+  constexpr bool OMAP = (KEEP ? 2 : 1) * RP * C_STRIDE + 2 * TBM * 4 <= EPI_BYTES;
+  int* const omap = reinterpret_cast<int*>(cst + (KEEP ? 2 : 1) * RP * C_STRIDE);
+  float* const oscl = reinterpret_cast<float*>(omap + TBM);
   const OT* const resid = KEEP ? nullptr : residual;
   OT* const pre_out = KEEP ? const_cast<OT*>(residual) : nullptr;
   // The tile's bias row reaches the epilogue through LDS by DMA (one 1-KiB piece, wave 0), issued with the tile's first
@@ -429,22 +435,59 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       if (bias) bv[ni] = *reinterpret_cast<const f32x4*>(bias_lds + bias_par * 1024 + nl * 4);
     }
     bias_par ^= 1;
+    const bool use_omap = OMAP && row_map != nullptr;   // workgroup-uniform
+    if (use_omap && tid_e < TBM) {   // tile row tid_e -> (output row, scale); visible to everybody after pass 0's barrier
+      const int m = cm0 + tid_e;
+      int o = -1;
+      float sc = 1.f;
+      if (m < cm_end) {
+        o = (int)row_map[m];
+        if (row_scale) sc = row_scale[o];
+      }
+      omap[tid_e] = o;
+      oscl[tid_e] = sc;
+    }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       // (1) resolve this pass's output rows (32-bit: a row index, not an address) and their combine scales
       int orow[ITS];
       float oscale[ITS];
+      if (!use_omap) {
 #pragma unroll
-      for (int it = 0; it < ITS; ++it) {
-        const int r = trow + it * ROWS_PER_IT;
-        const int m = cm0 + (r / HALF) * TM + p * HALF + (r % HALF);
-        orow[it] = -1;
-        oscale[it] = 1.f;
-        if (m < cm_end) {
-          orow[it] = row_map ? (int)row_map[m] : m;
-          if (row_map && row_scale) oscale[it] = row_scale[orow[it]];
+        for (int it = 0; it < ITS; ++it) {
+          const int r = trow + it * ROWS_PER_IT;
+          const int m = cm0 + (r / HALF) * TM + p * HALF + (r % HALF);
+          orow[it] = -1;
+          oscale[it] = 1.f;
+          if (m < cm_end) {
+            orow[it] = row_map ? (int)row_map[m] : m;
+            if (row_map && row_scale) oscale[it] = row_scale[orow[it]];
+          }
         }
       }
+      if (use_omap && p > 0) {   // the table is visible since pass 0's barrier
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int r = trow + it * ROWS_PER_IT;
+          const int tr = (r / HALF) * TM + p * HALF + (r % HALF);
+          orow[it] = omap[tr];
+          oscale[it] = oscl[tr];
+        }
+      }
+      auto res_fetch = [&](int it, u32x4 (&dst)[CPT]) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+          const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
+          dst[j] = u32x4{0u, 0u, 0u, 0u};
+          if (resid && orow[it] >= 0 && ncol < N)
+            dst[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(resid) + ((int64_t)orow[it] * N + ncol) * OB);
+        }
+      };
+      u32x4 resv[CPT], resn[CPT];
+      // passes after the first know their rows before staging (and the accumulators of the passes already stored are dead, so
+      // there are registers for it): the first residual segments travel under the staging arithmetic instead of behind the barrier
+      const bool early_res = p > 0 && (use_omap || !row_map);
+      if (early_res) res_fetch(0, resv);
       // (2) bias (+GELU), convert, stage this pass's fragments in LDS
 #pragma unroll
       for (int mm = 0; mm < MPP; ++mm) {
@@ -468,22 +511,21 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       if (p == NPASS - 1) PS_STAMP(9);
       PP_BARRIER();
       if (p == 0) PS_STAMP(6);
+      if (use_omap && p == 0) {
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int r = trow + it * ROWS_PER_IT;
+          const int tr = (r / HALF) * TM + p * HALF + (r % HALF);
+          orow[it] = omap[tr];
+          oscale[it] = oscl[tr];
+        }
+      }
       if (p == NPASS - 1) PS_STAMP(10);
       // (3) whole-row-segment stores (combine scale and residual / gelu' fused).  Residual segments are fetched one row
       //     iteration ahead, and every use of a row's segments comes BEFORE that row's first store: with LDS-DMA in flight
       //     hipcc waits vmcnt(0) at any use of an ordinary load, so a use behind a store would wait for that store's
       //     acknowledgement (that was 4.2 k cycles per row iteration; the loads of row it + 1 now travel under the stores of it)
-      auto res_fetch = [&](int it, u32x4 (&dst)[CPT]) {
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-          const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
-          dst[j] = u32x4{0u, 0u, 0u, 0u};
-          if (resid && orow[it] >= 0 && ncol < N)
-            dst[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(resid) + ((int64_t)orow[it] * N + ncol) * OB);
-        }
-      };
-      u32x4 resv[CPT], resn[CPT];
-      res_fetch(0, resv);
+      if (!early_res) res_fetch(0, resv);
 #pragma unroll
       for (int it = 0; it < ITS; ++it) {
         const int r = trow + it * ROWS_PER_IT;
