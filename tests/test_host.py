@@ -216,3 +216,27 @@ def test_gate_threshold_schedule_and_counters_on_cpu():
     assert gate._total_tokens == 18 and gate._skipped_tokens == float(m[..., 0].sum())
     gate._skipped_tokens = 0
     assert gate._skipped_tokens == 0
+
+
+def test_multi_tensor_block_table_and_wgrad_round_model():
+    """Host-side tables of the round's launch-count work: the workgroup -> (tensor, 16K block) map of the multi-tensor optimizer
+    kernels, and the cost model that picks the weight-gradient tile height / orientation."""
+    import numpy as np
+    from slim_switch_moe_vit_amd import optim as smo
+    from slim_switch_moe_vit_amd import ops
+
+    blk, nb = smo._block_table([5, 16384, 16385, 40000], "cpu")
+    assert nb == [1, 1, 2, 3]
+    assert blk.shape == (2, 7) and blk.dtype == torch.int32
+    assert blk[0].tolist() == [0, 1, 2, 2, 3, 3, 3]      # tensor of each workgroup
+    assert blk[1].tolist() == [0, 0, 0, 1, 0, 1, 2]      # 16K-element block inside it
+    blk2, _ = smo._block_table([5, 16384, 16385, 40000], "cpu")
+    assert blk2 is blk                                    # cached by the size tuple
+    empty, nb0 = smo._block_table([], "cpu")
+    assert nb0 == [] and empty.shape == (2, 0)
+    # ViT-B expert weights on 256 CUs: dW1 [3072, 768] x 8 experts = 240 tiles of 320 rows (one round, weighted 1.25) against
+    # 288 tiles of 256 rows (two rounds); dW2 [768, 3072] gains nothing from the taller tile as it stands, so ops swaps it
+    assert ops._wgrad_rounds(8, 3072, 768, 256) == 1.25
+    assert ops._wgrad_rounds(8, 768, 3072, 256) == 2
+    assert ops._wgrad_rounds(4, 768, 3072, 256) == 1      # 144 tiles: one round either way
+    assert np.isclose(ops._wgrad_rounds(1, 256, 256, 256), 1.0)
