@@ -377,3 +377,29 @@ def test_grouped_gemm_gelu_keep_matches_the_two_step_form(counts, K, N, dtype):
     assert (act.float() - ref_act.float()).abs().max().item() <= tol * max(1.0, float(ref_act.float().abs().max()))
     fused = ops.grouped_gemm(A, W, b, offsets, ops.EPI_GELU, dtype, variant=10)
     assert torch.equal(act, fused)   # the same epilogue arithmetic as the inference kernel's
+
+
+@pytest.mark.parametrize("T,E", [(1, 8), (1000, 8), (4097, 16), (333, 27)])
+def test_switch_gate_bwd_matches_autograd_of_softmax_gather_and_linear_aux(T, E):
+    """smoe_switch_gate_bwd == d/dlogits of  sum_t dscore[t] softmax(logits)[t, idx[t]] + sum_{t,e} coef[e] softmax(logits)[t, e]
+    (float64 autograd), with and without either term; entries with idx = -1 select nothing."""
+    g = _gen(T * 31 + E)
+    logits = torch.randn(T, E, generator=g) * 2
+    idx = torch.randint(0, E, (T,), generator=g)
+    if T > 10:
+        idx[::9] = -1
+    dscore = torch.randn(T, generator=g)
+    coef = torch.randn(E, generator=g) * 0.1
+    probs = torch.softmax(logits, -1)
+    for use_ds, use_cf in ((True, True), (True, False), (False, True)):
+        l64 = logits.double().requires_grad_(True)
+        p64 = torch.softmax(l64, -1)
+        obj = torch.zeros((), dtype=torch.float64)
+        if use_ds:
+            sel = idx >= 0
+            obj = obj + (dscore.double()[sel] * p64[sel, idx[sel]]).sum()
+        if use_cf:
+            obj = obj + (p64 * coef.double()).sum()
+        obj.backward()
+        got = ops.switch_gate_bwd(probs.to(DEV), idx.to(DEV), dscore.to(DEV) if use_ds else None, coef.to(DEV) if use_cf else None)
+        assert (got.cpu().double() - l64.grad).abs().max().item() <= 2e-6 * max(1.0, float(l64.grad.abs().max()))
