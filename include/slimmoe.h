@@ -38,6 +38,9 @@ enum { SMOE_EPI_NONE = 0, SMOE_EPI_GELU = 1, SMOE_EPI_GELU_GRAD = 2 };
 
 /* library ABI version (bumped on any signature change) */
 int smoe_abi_version(void);
+/* first 16 hex digits of the sha256 over the sources this binary was built from (csrc/Makefile HASHED): lets the loader
+ * refuse, and build() replace, a shipped binary that does not belong to the shipped sources */
+const char* smoe_build_id(void);
 /* raise the dynamic-LDS limit of every kernel of the library on the current device (see Conventions); idempotent */
 int smoe_init(void);
 /* message for the last non-zero return on this thread */
@@ -229,10 +232,14 @@ int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E,
  * Replaces fmoe_cuda.ensure_nccl / expert_exchange / global_scatter / global_gather (reached from
  * models/resMoE.py:27-29 when world_size > 1).  A context owns ONE RCCL communicator (built from a unique-id blob that
  * rank 0 creates with smoe_unique_id and the caller distributes by whatever means it has -- MPI, a file, torch's store),
- * ONE communication stream and two events.  Every exchange is enqueued on the context's stream behind an event recorded
- * on the caller's `stream` (so it sees the send buffer the compute stream produced) and ends with an event the caller's
- * stream waits on: immediately when wait != 0, or later through smoe_a2a_wait -- in between the compute stream is free
- * to run other work (the expert GEMMs of another micro-batch) while rows move over xGMI.  All peers' transfers of one
+ * ONE communication stream and a ring of completion events.  Every exchange is enqueued on the context's stream behind an
+ * event recorded on the caller's `stream` (so it sees the send buffer the compute stream produced) and ends with an event
+ * the caller's stream waits on: immediately when wait != 0, or later -- in between the compute stream is free to run other
+ * work (the expert GEMMs of another micro-batch) while rows move over xGMI.  Every exchange has a ticket (1, 2, ...:
+ * smoe_a2a_last_ticket right after posting it); smoe_a2a_wait_ticket waits for THAT exchange (the ring holds the last 16;
+ * an older ticket waits for the exchange that re-used its slot, which is later on the same in-order stream), so exchanges
+ * of several micro-batches in flight can be waited for in any order; smoe_a2a_wait = the latest one.  Arguments are
+ * checked before the RCCL group opens and a failing call inside the group closes it before returning.  All peers' transfers of one
  * call are posted as one RCCL group: on the point-to-point xGMI mesh every link then carries its pair's rows concurrently.
  * RCCL is resolved at run time from the librccl.so already in the process (or the system's): no link-time dependency.
  *   smoe_a2a_counts : send_counts[w*E_local + e] = rows this rank routes to rank w's local expert e  ->  recv_counts[w*E_local
@@ -253,6 +260,8 @@ int smoe_a2a_counts(smoe_ctx* ctx, const int32_t* send_counts, int32_t* recv_cou
 int smoe_a2a_tokens(smoe_ctx* ctx, const void* send, const int64_t* send_rows, void* recv, const int64_t* recv_rows, int d,
                     int dtype, void* stream, int wait);
 int smoe_a2a_wait(smoe_ctx* ctx, void* stream);
+int64_t smoe_a2a_last_ticket(smoe_ctx* ctx);
+int smoe_a2a_wait_ticket(smoe_ctx* ctx, int64_t ticket, void* stream);
 
 /* ---- optimizer side of the training step (engine.py:68-74: timm NativeScaler around torch.optim.AdamW; SURVEY.md 8f
  * rank 3).  Everything stays on the device -- loss scale, non-finite flag, clip coefficient, step count -- so a step has

@@ -11,13 +11,14 @@ import torch  # noqa: F401  (must be imported first: the library resolves libamd
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
 # name -> (restype, argtypes); mirrors include/slimmoe.h one to one
 SIGNATURES = {
     "smoe_abi_version": (c_int, []),
+    "smoe_build_id": (ctypes.c_char_p, []),
     "smoe_init": (c_int, []),
     "smoe_last_error": (ctypes.c_char_p, []),
     "smoe_router_workspace_bytes": (c_size_t, [c_int64]),
@@ -77,14 +78,40 @@ SIGNATURES = {
     "smoe_a2a_counts": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "smoe_a2a_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int]),
     "smoe_a2a_wait": (c_int, [c_void_p, c_void_p]),
+    "smoe_a2a_last_ticket": (c_int64, [c_void_p]),
+    "smoe_a2a_wait_ticket": (c_int, [c_void_p, c_int64, c_void_p]),
     "smoe_zero_row_output": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None
 
+# what csrc/Makefile hashes into smoe_build_id(): the same names, sorted as strings, relative to csrc/
+_HASHED = ["api.hip", "router.hip", "router16.hip", "gate.hip", "dispatch.hip", "gemm.hip", "backward.hip", "attention.hip",
+           "optim.hip", "comm.hip", "smoe_common.h", "router16_kernel.h", "router_mt_kernel.h", "gemm_persistent.h",
+           "../../include/slimmoe.h", "Makefile"]
+
 
 class SlimMoEError(RuntimeError):
     pass
+
+
+def source_build_id() -> str:
+    """sha256 (first 16 hex digits) over the library's sources as they lie in the tree -- what ``smoe_build_id()`` of a
+    binary built from them returns.  None if the sources are not there (a binary-only install)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    try:
+        for name in sorted(_HASHED):   # GNU make's $(sort) and Python's sorted() agree on these ASCII names
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
+def binary_build_id() -> str:
+    return load().smoe_build_id().decode()
 
 
 def load():

@@ -68,7 +68,8 @@ class ExchangeContext:
     def all_to_all_rows(self, rows: torch.Tensor, send_rows: List[int], recv_rows: List[int], wait: bool = True,
                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """all-to-all-v of whole rows (``rows[:sum(send_rows)]`` split by destination rank); returns the receive buffer.
-        With ``wait=False`` the caller's stream does NOT wait for the exchange: call ``wait_stream()`` before reading it."""
+        With ``wait=False`` the caller's stream does NOT wait for the exchange: call ``wait_stream(ref, ticket)`` with
+        ``last_ticket()`` taken right after this call (or ``wait_stream(ref)`` = the latest exchange) before reading it."""
         ops._chk(rows, "rows", ndim=2, align=4)
         W = self.world_size
         if len(send_rows) != W or len(recv_rows) != W:
@@ -100,6 +101,15 @@ class ExchangeContext:
             return ops.F16
         raise TypeError(f"all_to_all_rows: element size {t.element_size()} not supported (2 or 4 bytes)")
 
-    def wait_stream(self, ref: torch.Tensor):
-        """Make torch's current stream (on ``ref``'s device) wait for the context's last exchange."""
-        _lib.check(_lib.load().smoe_a2a_wait(self._h, ops._stream(ref)), "smoe_a2a_wait")
+    def last_ticket(self) -> int:
+        """Ticket of the exchange posted last on this context (0 before the first one)."""
+        return int(_lib.load().smoe_a2a_last_ticket(self._h))
+
+    def wait_stream(self, ref: torch.Tensor, ticket: Optional[int] = None):
+        """Make torch's current stream (on ``ref``'s device) wait for exchange ``ticket`` of this context (default: the
+        latest).  Waiting for an older exchange does not wait for the ones posted after it."""
+        lib = _lib.load()
+        if ticket is None:
+            _lib.check(lib.smoe_a2a_wait(self._h, ops._stream(ref)), "smoe_a2a_wait")
+        else:
+            _lib.check(lib.smoe_a2a_wait_ticket(self._h, int(ticket), ops._stream(ref)), "smoe_a2a_wait_ticket")

@@ -44,41 +44,81 @@ def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: to
     return {"loss": loss_sum / n, "acc1": a1 / n, "acc5": a5 / n, "images_per_sec": n / dt}
 
 
+def _criterion_takes_inputs(criterion) -> bool:
+    """The reference's criterion is ``DistillationLoss.forward(inputs, outputs, labels)`` (losses.py:28; called as
+    ``criterion(samples, outputs, targets)`` at engine.py:54); a plain ``nn.CrossEntropyLoss`` takes (outputs, targets)."""
+    import inspect
+    fn = getattr(criterion, "forward", criterion)
+    try:
+        params = [p for p in inspect.signature(fn).parameters.values()
+                  if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD) and p.default is p.empty]
+    except (TypeError, ValueError):
+        return False
+    return len(params) >= 3
+
+
 def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]],
-                    optimizer: torch.optim.Optimizer, device, epoch: int, loss_scaler, max_norm=None,
-                    aux_loss_weight: float = 0.0, gate_delta=None, autocast: bool = True):
-    """The reference's training loop body (engine.py:21-84) around the HIP path: autocast forward, criterion,
-    ``loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters())`` (optim.NativeScaler keeps the
-    whole step on the device), then the token-skip gates' threshold schedule (``Gate.step(delta)`` for every gate, as
-    main.py:812-815 does after the epoch's steps).  ``criterion(outputs, targets)`` -- the reference's distillation
-    criterion also takes the inputs (losses.py, off the hot path).  ``aux_loss_weight`` adds the MoE gates' load-balance
-    losses (SwitchGate, BASELINE cfg 5).  Mixup, EMA and the metric logger are training-driver plumbing (out of scope).
-    Returns {"loss": mean loss, "steps": n}."""
+                    optimizer: torch.optim.Optimizer, device, epoch: int, loss_scaler, max_norm=None, model_ema=None,
+                    mixup_fn=None, set_training_mode=True, args=None, *, aux_loss_weight: float = 0.0, gate_delta=None,
+                    autocast: bool = True):
+    """The reference's training loop body (engine.py:22-85) around the HIP path, with the reference's positional
+    parameters in the reference's order (main.py:825-838 calls it positionally: ``model_ema`` and ``mixup_fn`` sit in
+    positions 9 and 10): autocast forward, criterion, ``loss_scaler(loss, optimizer, clip_grad=max_norm,
+    parameters=model.parameters())`` (optim.NativeScaler keeps the whole step on the device), ``model_ema.update(model)``
+    after every step and ``mixup_fn(samples, targets)`` before it when given, ``args.bce_loss`` as at engine.py:49-50.
+    ``max_norm=None`` = no clipping (what main.py passes by default, ``--clip-grad None``).  A criterion whose forward takes
+    three tensors is called like the reference's DistillationLoss, ``criterion(samples, outputs, targets)``.
+
+    Keyword-only extensions: ``aux_loss_weight`` adds the MoE gates' load-balance losses (SwitchGate, BASELINE cfg 5);
+    ``gate_delta`` runs the token-skip gates' threshold schedule (``Gate.step(delta)`` for every gate, as main.py:887-891
+    does after the epoch's steps); ``autocast``.
+
+    The reference aborts on a non-finite loss by reading ``loss.item()`` in every step (engine.py:56-60: one host sync per
+    step).  Here the check is a device-side count read ONCE at the end of the epoch: the same abort (``SystemExit(1)``
+    after the message), an epoch late at worst, and no step of it trains on garbage meanwhile when the scaler is an
+    ``optim.NativeScaler`` (a non-finite gradient skips the update).  The metric logger is driver plumbing (out of scope).
+    Returns {"loss": mean loss, "steps": n, "lr": first group's lr}."""
     from .fmoe import FMoETransformerMLP
     from .resmoe import Gate
 
-    model.train(True)
+    model.train(set_training_mode)
     dev = torch.device(device)
     moes = [m for m in model.modules() if isinstance(m, FMoETransformerMLP)]
-    loss_sum, n = torch.zeros((), device=dev), 0
+    with_inputs = _criterion_takes_inputs(criterion)
+    bce = bool(getattr(args, "bce_loss", False)) if args is not None else False
+    loss_sum, bad, n = torch.zeros((), device=dev), torch.zeros((), device=dev), 0
     for samples, targets in data_loader:
         samples = samples.to(dev, non_blocking=True)
         targets = targets.to(dev, non_blocking=True)
+        if mixup_fn is not None:
+            samples, targets = mixup_fn(samples, targets)
+        if bce:
+            targets = targets.gt(0.0).type(targets.dtype)
         with torch.autocast(device_type=dev.type, dtype=torch.float16, enabled=autocast and dev.type == "cuda"):
             outputs = model(samples)
-            loss = criterion(outputs, targets)
+            loss = criterion(samples, outputs, targets) if with_inputs else criterion(outputs, targets)
             if aux_loss_weight:
                 for m in moes:
                     aux = m.gate.get_loss()
                     if aux is not None:
                         loss = loss + aux_loss_weight * aux
         optimizer.zero_grad()
-        loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=False)
-        loss_sum += loss.detach().float()
+        is_second_order = hasattr(optimizer, "is_second_order") and optimizer.is_second_order
+        loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=is_second_order)
+        if model_ema is not None:
+            model_ema.update(model)
+        lv = loss.detach().float()
+        finite = torch.isfinite(lv)
+        loss_sum += torch.where(finite, lv, torch.zeros_like(lv))
+        bad += (~finite).to(bad.dtype)
         n += 1
     if gate_delta is not None:
         for m in model.modules():
             if isinstance(m, Gate):
                 m.step(gate_delta)
-    mean = float(loss_sum) / max(n, 1)   # the epoch's single host read
-    return {"loss": mean, "steps": n}
+    n_bad = int(bad)                          # the epoch's host read (with the mean below)
+    if n_bad:
+        print(f"Loss is non-finite in {n_bad} of {n} steps, stopping training")
+        raise SystemExit(1)
+    mean = float(loss_sum) / max(n, 1)
+    return {"loss": mean, "steps": n, "lr": optimizer.param_groups[0]["lr"]}

@@ -52,13 +52,14 @@ def _cabi_context(group, device):
 
 
 class _CtxWork:
-    """Work handle of an exchange on the library's communication stream: wait() fences torch's current stream."""
+    """Work handle of an exchange on the library's communication stream: wait() fences torch's current stream against
+    THIS exchange (its ticket), not against whatever the context posted since."""
 
     def __init__(self, ctx, ref):
-        self.ctx, self.ref = ctx, ref
+        self.ctx, self.ref, self.ticket = ctx, ref, ctx.last_ticket()
 
     def wait(self):
-        self.ctx.wait_stream(self.ref)
+        self.ctx.wait_stream(self.ref, self.ticket)
         return True
 
 

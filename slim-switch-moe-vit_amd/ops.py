@@ -565,6 +565,12 @@ def grouped_wgrad_rows(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor, 
         raise RuntimeError("grouped_wgrad_rows: P and Q must be f16 / bf16 with the same row count")
     E = offsets.numel() - 1
     R1, R2 = P.shape[1], Q.shape[1]
+    if P.numel() >= 2 ** 32 or Q.numel() >= 2 ** 32:
+        # the token-major kernel addresses its operands with 32-bit ELEMENT offsets (csrc/gemm.hip MODE 2): an operand of
+        # 2^32 elements or more takes the K-major path (64-padded transposed images, 64-bit row bases)
+        offs_pad = pad_offsets(offsets)
+        Lp = padded_len(P.shape[0], E)
+        return grouped_wgrad(transpose_pad(P, offsets, offs_pad, Lp), transpose_pad(Q, offsets, offs_pad, Lp), offs_pad)
     if allow_swap and R1 % 64 == 0 and R2 % 64 == 0:
         cus = torch.cuda.get_device_properties(P.device).multi_processor_count
         if _wgrad_rounds(E, R2, R1, cus) + 0.15 < _wgrad_rounds(E, R1, R2, cus):

@@ -67,15 +67,49 @@ class AdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("AdamW: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._step_dev = {}   # device -> f32[1] number of updates applied so far (advanced on the device)
+        self._step_dev = {}       # device -> f32[1] number of updates applied so far (advanced on the device)
+        self._step_restore = {}   # device -> count loaded from a checkpoint, applied when the counter is (re)created
 
     supports_device_scalars = True
 
     def _step_counter(self, device) -> torch.Tensor:
         t = self._step_dev.get(device)
         if t is None:
-            t = self._step_dev[device] = torch.zeros(1, dtype=torch.float32, device=device)
+            t = self._step_dev[device] = torch.full((1,), float(self._step_restore.pop(device, 0.0)), dtype=torch.float32,
+                                                    device=device)
         return t
+
+    def _on_hip_path(self, p) -> bool:
+        return _hip_ok(p)
+
+    # -- checkpoints (the reference saves / restores `optimizer.state_dict()`: main.py:898, 717) -------------------------------
+    def state_dict(self):
+        """torch.optim.AdamW's layout.  ``state[p]['step']`` is the number of updates APPLIED to p (the bias-correction
+        t): for parameters on the HIP path that is the device-side counter (steps skipped for non-finite gradients are
+        not counted), read back here -- a checkpoint is the one place where the host may ask."""
+        for dev, t in self._step_dev.items():
+            n = int(float(t))
+            for group in self.param_groups:
+                for p in group["params"]:
+                    st = self.state.get(p)
+                    if st and p.device == dev and self._on_hip_path(p):
+                        st["step"] = n
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """Restores exp_avg / exp_avg_sq AND the step count the kernels' bias correction uses (a ``torch.optim.AdamW``
+        checkpoint carries ``step`` as a tensor per parameter, this class's own as an int: both load)."""
+        super().load_state_dict(state_dict)
+        self._step_dev, self._step_restore = {}, {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if not st or "step" not in st:
+                    continue
+                n = float(st["step"])          # tensor or number
+                st["step"] = int(n)
+                if self._on_hip_path(p):       # one counter per device: every tensor of a step shares t
+                    self._step_restore[p.device] = max(self._step_restore.get(p.device, 0.0), n)
 
     @torch.no_grad()
     def step(self, closure=None, grad_mult: Optional[torch.Tensor] = None, found_inf: Optional[torch.Tensor] = None):
@@ -100,7 +134,6 @@ class AdamW(torch.optim.Optimizer):
                 if _hip_ok(p) and g.is_cuda and g.is_contiguous() and g.dtype in ops._DT:
                     batches.setdefault((p.device, g.dtype, float(b1), float(b2), float(eps)), []).append(
                         (p, g, st["exp_avg"], st["exp_avg_sq"], float(lr), float(wd)))
-                    st["step"] += 1   # host-side count of step() calls (the device counter skips non-finite steps)
                 else:                 # torch composition (CPU tensors, other dtypes): same arithmetic
                     if found_inf is not None and float(found_inf) != 0.0:
                         continue
@@ -135,6 +168,11 @@ class AdamW(torch.optim.Optimizer):
             rc = lib.smoe_adamw_step_multi(tab.data_ptr(), hyp.data_ptr(), len(items), blk.data_ptr(), sum(nb), ops.dtype_code(gdt),
                                            b1, b2, eps, step_t.data_ptr(), ops._ptr(grad_mult), ops._ptr(found_inf), stream)
             _lib.check(rc, "smoe_adamw_step_multi")
+        # The kernels wrote the parameters through raw pointers: autograd's version counters did not move, and every derived
+        # tensor keyed on them (the 16-bit weight shadows of the expert GEMMs and of the dense projections, the zero-row
+        # constants) would go on serving the OLD weights.  Bump the versions, as an in-place torch op would have.
+        for items in batches.values():
+            torch._C._increment_version([it[0] for it in items])
         return loss
 
 

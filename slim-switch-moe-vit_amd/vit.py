@@ -4,7 +4,10 @@ The reference builds its models from timm pieces that are absent on both boxes (
 ``PatchEmbed``, ``DropPath``, ``Mlp``, ``trunc_normal_`` and the model registry.  This file restates
 just enough of them -- with the reference's attribute names, so ``state_dict()`` keys match
 models/vision_transformer.py:642-848 / models/model.py:80-183 -- for the MoE factories in resmoe.py to
-patch.  It is the *caller* of the hot path, not the hot path: dense pieces run as ordinary torch ops.
+patch.  It is the *caller* of the hot path.  Under fp16-autocast inference its dense pieces run on the library's own kernels too
+(LayerNorm, qkv / projection / patch-embedding / head on the grouped MFMA GEMM with one row group, the attention kernel);
+a shape those kernels do not cover falls back to a torch op and SAYS SO (one ``SlimMoEFallbackWarning`` per shape and
+reason): a silent second backend would let a benchmark or a test run on vendor kernels unnoticed.
 """
 from __future__ import annotations
 
@@ -109,6 +112,16 @@ class _HalfCache(StreamCache):
     def get(self, p: torch.Tensor) -> torch.Tensor:  # noqa: D102
         return super().get(id(p), param_version(p), lambda: p.detach().half())
 
+    def get_padded(self, p: torch.Tensor, rows: int, dtype) -> torch.Tensor:
+        """``p`` (a weight [N, K] or a bias [N]) in ``dtype`` with zero rows appended up to ``rows`` (a classifier head whose
+        class count is not a multiple of 8 runs on the GEMM kernel with a padded N; the caller drops the extra columns)."""
+        def make():
+            t = p.detach().to(dtype).reshape(p.shape[0], -1)
+            out = torch.zeros((rows, t.shape[1]), dtype=dtype, device=p.device)
+            out[: t.shape[0]].copy_(t)
+            return out if p.dim() > 1 else out.reshape(rows)
+        return super().get(("pad", id(p), rows, dtype), param_version(p), make)
+
     def get_f32(self, p: torch.Tensor) -> torch.Tensor:
         """f32 view of a (bias) parameter: the parameter itself unless it is stored in another dtype."""
         if p.dtype == torch.float32:
@@ -127,18 +140,62 @@ def _half_cache(mod: nn.Module) -> "_HalfCache":
 DENSE_GEMM = os.environ.get("SLIMMOE_DENSE_GEMM", "own")   # "own": the grouped MFMA GEMM (one group); "blas": F.linear (A/B)
 
 
+class SlimMoEFallbackWarning(UserWarning):
+    """A dense piece of the eval forward left the hand-written kernels for a torch / vendor kernel."""
+
+
+_fallbacks_seen = set()
+
+
+def _warn_fallback(what: str, reason: str, shape) -> None:
+    """One warning per (piece, reason, shape): the BASELINE shapes raise none (tests/test_gpu_model.py checks that)."""
+    key = (what, reason, tuple(shape))
+    if key in _fallbacks_seen:
+        return
+    _fallbacks_seen.add(key)
+    import warnings
+    warnings.warn(f"{what}: shape {tuple(shape)} runs on a torch / vendor kernel, not on libslimmoe_hip ({reason})",
+                  SlimMoEFallbackWarning, stacklevel=3)
+
+
+def _linear16_reason(x16: torch.Tensor, weight: torch.Tensor):
+    """Why ``_linear16`` cannot take this GEMM (None = it can)."""
+    M, K = x16.shape
+    N = weight.shape[0]
+    if DENSE_GEMM != "own":
+        return f"SLIMMOE_DENSE_GEMM={DENSE_GEMM}"
+    if K % 64:
+        return "K % 64 != 0"
+    if not x16.is_contiguous():
+        return "rows not contiguous"
+    return None
+
+
 def _linear16(hc: "_HalfCache", x16: torch.Tensor, weight: torch.Tensor, bias, out_dtype=torch.float16, residual=None,
               name: str = "dense_gemm"):
     """``x16 @ weight^T + bias`` (+ residual) for fp16 rows ``x16 [M, K]`` on the hand-written grouped MFMA GEMM with a
     single row group -- the dense projections around the MoE (qkv, attention output, patch embedding, classifier head:
     models/vision_transformer.py:262-266, 276, 819, 847) -- returning ``[M, N]`` in ``out_dtype``.  Same arithmetic as
-    the fp16 GEMM autocast would run (f16 operands, f32 accumulate, one rounding).  Returns None when the shape is not
-    the kernel's (K % 64, N % 8), so the caller can fall back to ``F.linear``."""
+    the fp16 GEMM autocast would run (f16 operands, f32 accumulate, one rounding).  An N that is not a multiple of 8 (a
+    10-class head) is padded with zero weight rows and the extra columns dropped.  Returns None, after a
+    SlimMoEFallbackWarning, when the shape is not the kernel's (K % 64), so the caller can fall back to ``F.linear``."""
     from . import ops
     M, K = x16.shape
     N = weight.shape[0]
-    if DENSE_GEMM != "own" or K % 64 or N % 8 or M == 0 or not x16.is_contiguous():
+    if M == 0:
         return None
+    why = _linear16_reason(x16, weight)
+    if why is not None:
+        _warn_fallback(name, why, (M, K, N))
+        return None
+    if N % 8:
+        assert residual is None
+        Np = (N + 7) // 8 * 8
+        w = hc.get_padded(weight, Np, torch.float16)[None]
+        b = hc.get_padded(bias, Np, torch.float32)[None] if bias is not None else None
+        variant = 1 if M <= 1024 else ops.DEFAULT_GEMM_VARIANT
+        out = ops.grouped_gemm(x16, w, b, hc.offsets(M, x16.device), ops.EPI_NONE, out_dtype, variant=variant, prof_name=name)
+        return out[:, :N].contiguous()
     w = hc.get(weight).reshape(N, K)[None]
     b = hc.get_f32(bias)[None] if bias is not None else None
     # a handful of rows (the classifier head sees one row per image): 128 x 128 tiles spread the few output tiles over
@@ -178,6 +235,8 @@ class Attention(nn.Module):
                 # hand-written attention on the fused qkv layout [B,N,3,H,hd] (no q/k/v transposes)
                 o = ops.attention(qkv, B, N, self.num_heads, hd, self.scale).reshape(B * N, C)
             else:
+                _warn_fallback("attention", "kernel covers head_dim 64, N <= 640" if qkv.is_contiguous() else "qkv not contiguous",
+                               (N, hd))
                 q, k, v = qkv.reshape(B, N, 3, self.num_heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
                 o = F.scaled_dot_product_attention(q, k, v, scale=self.scale).transpose(1, 2).reshape(B * N, C)
             if residual is not None and C % 64 == 0 and residual.dtype == torch.float32 and residual.is_contiguous():
@@ -187,6 +246,8 @@ class Attention(nn.Module):
                                 residual=residual.reshape(B * N, C), name="attn_proj_gemm")
                 if out is not None:
                     return out.reshape(B, N, C), True
+            else:
+                _warn_fallback("attn_proj_gemm", "residual must be contiguous f32 and C % 64 == 0", (B * N, C, C))
             return F.linear(o, hc.get(self.proj.weight), hc.get(self.proj.bias)).reshape(B, N, C), False
         return self._forward(x), False
 

@@ -1,4 +1,4 @@
-"""Helpers for the multi-process tests."""
+"""Helpers shared by the test modules: child-process joins and THE float bar."""
 
 
 def join_or_kill(procs, timeout):
@@ -19,3 +19,14 @@ def join_or_kill(procs, timeout):
     assert not stuck, f"{len(stuck)} rank(s) still running after {timeout} s (terminated)"
     for p in procs:
         assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+
+
+def float_bar(got, ref, tol=1e-3):
+    """THE float bar of the operator tests (north_star: "fp tolerance <= 1e-3 on expert outputs"), stated once, in
+    the convention test_grouped_gemm_matches_fp64_reference uses: max |diff| <= tol * max(1, max |ref|) AND
+    relative L2 <= tol.  Returns the numbers so that a failure prints the scale it was judged at."""
+    diff = got.double() - ref.double()
+    scale = max(1.0, float(ref.abs().max()))
+    max_abs, rel_l2 = float(diff.abs().max()), float(diff.norm() / ref.double().norm().clamp(min=1e-30))
+    assert max_abs <= tol * scale and rel_l2 <= tol, dict(max_abs=max_abs, ref_abs_max=scale, rel_l2=rel_l2, tol=tol)
+    return max_abs, scale, rel_l2

@@ -134,3 +134,96 @@ def test_cfg5_training_step_through_the_harness():
         losses.append(st["loss"])
     assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
     assert float((model.blocks[0].mlp.experts.htoh4.weight.detach() - w0).abs().max()) > 0
+
+
+def test_fused_adamw_refreshes_the_16_bit_weight_shadows_autocast_training_matches_a_torch_adamw_twin():
+    """The fused step writes the f32 masters through raw pointers.  Every 16-bit shadow keyed on the parameter's version
+    (expert GEMM operands forward and backward, qkv / proj / head / patch-embed) must be rebuilt after it, or every step
+    after the first trains against the INITIAL fp16 weights (the reference's AMP configuration, engine.py:52-74).  Two
+    copies of one model take the same 5 autocast steps on the same batches: one through sm.AdamW (fused, device scalars),
+    one through torch.optim.AdamW behind the same scaler (torch in-place ops, which bump the versions by themselves).
+    Their parameters must stay together (with stale shadows they part by ~lr per element from the second step on), the
+    shadows must equal the casts of the masters, and a no_grad autocast eval must see the updated weights."""
+    import copy
+    torch.manual_seed(0)
+    a = sm.create_model("moe_tiny_patch16_224_expert8", num_classes=10, depth=2).to(DEV)   # E = 8, top-2
+    b = copy.deepcopy(a)
+    lr = 2e-3
+    oa = sm.AdamW(a.parameters(), lr=lr, weight_decay=0.05)
+    ob = torch.optim.AdamW(b.parameters(), lr=lr, weight_decay=0.05)
+    sa, sb = sm.NativeScaler(init_scale=1024.0), sm.NativeScaler(init_scale=1024.0)
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(8, 3, 224, 224, generator=g).to(DEV)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a.eval()
+        logits0 = a(images).float().clone()
+        a.train()
+    crit = torch.nn.CrossEntropyLoss()
+    for it in range(5):
+        batch = [(torch.randn(8, 3, 224, 224, generator=g), torch.randint(0, 10, (8,), generator=g))]
+        sm.train_one_epoch(a, crit, batch, oa, DEV, 0, sa, max_norm=1.0)
+        sm.train_one_epoch(b, crit, batch, ob, DEV, 0, sb, max_norm=1.0)
+    worst = 0.0
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        worst = max(worst, float((p.detach() - q.detach()).abs().max()))
+    print(f"fused vs torch AdamW after 5 autocast steps: max parameter difference {worst:.3e} (lr {lr})")
+    assert worst <= 0.1 * lr, worst     # stale shadows: O(lr) per step from the second step on
+    for blk in a.blocks:
+        for lin in (blk.mlp.experts.htoh4, blk.mlp.experts.h4toh):
+            assert torch.equal(lin.weight_as(torch.float16), lin.weight.detach().half())
+            assert torch.equal(lin.weight_t_as(torch.float16), lin.weight.detach().transpose(1, 2).half().contiguous())
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a.eval(); b.eval()
+        la, lb = a(images).float(), b(images).float()
+    assert float((la - lb).abs().max()) <= 2e-2, "eval after training must read the updated weights"
+    assert float((la - logits0).abs().max()) > 10 * float((la - lb).abs().max()), "the weights did move"
+
+
+def test_adamw_state_dict_round_trip_keeps_the_bias_correction_step():
+    """optimizer.load_state_dict(checkpoint['optimizer']) (main.py:717): exp_avg / exp_avg_sq AND the step count of the
+    bias correction survive a save / load -- into this class from its own checkpoint, from a torch.optim.AdamW checkpoint
+    (tensor 'step'), and back into torch.optim.AdamW -- so that the next step equals the uninterrupted run's."""
+    init = _params(7, SHAPES)
+    kw = dict(lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+
+    def run(opt_cls, params, its, start=0):
+        opt = opt_cls(params, **kw) if isinstance(opt_cls, type) else opt_cls
+        for it in range(start, start + its):
+            for p, gr in zip(params, _params(300 + it, SHAPES)):
+                p.grad = gr.to(p.device, p.dtype)
+            opt.step()
+        return opt
+
+    ref = [torch.nn.Parameter(t.clone().double()) for t in init]
+    run(torch.optim.AdamW, ref, 9)                                   # the uninterrupted run, float64
+    ours = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    o1 = run(sm.AdamW, ours, 5)
+    sd = o1.state_dict()
+    assert all(int(st["step"]) == 5 for st in sd["state"].values())
+    # (1) own checkpoint -> a fresh instance (through torch.save / torch.load, as the reference does)
+    import io
+    buf = io.BytesIO(); torch.save(sd, buf); buf.seek(0)
+    sd_l = torch.load(buf, weights_only=False)
+    resumed = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    o2 = sm.AdamW(resumed, **kw)
+    o2.load_state_dict(sd_l)
+    run(o2, resumed, 4, start=5)
+    assert float(o2._step_counter(torch.device(DEV))) == 9.0
+    for p, q in zip(resumed, ref):
+        assert (p.detach().cpu().double() - q.detach()).abs().max().item() <= 3e-6 * max(1.0, float(q.abs().max()))
+    # (2) a torch.optim.AdamW checkpoint (tensor 'step') -> this class
+    tp = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    to = run(torch.optim.AdamW, tp, 5)
+    resumed2 = [torch.nn.Parameter(p.detach().clone()) for p in tp]
+    o3 = sm.AdamW(resumed2, **kw)
+    o3.load_state_dict(to.state_dict())
+    run(o3, resumed2, 4, start=5)
+    for p, q in zip(resumed2, ref):
+        assert (p.detach().cpu().double() - q.detach()).abs().max().item() <= 3e-6 * max(1.0, float(q.abs().max()))
+    # (3) this class's checkpoint -> torch.optim.AdamW
+    resumed3 = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    o4 = torch.optim.AdamW(resumed3, **kw)
+    o4.load_state_dict(sd)
+    run(o4, resumed3, 4, start=5)
+    for p, q in zip(resumed3, ref):
+        assert (p.detach().cpu().double() - q.detach()).abs().max().item() <= 3e-6 * max(1.0, float(q.abs().max()))

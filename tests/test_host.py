@@ -33,6 +33,10 @@ def test_library_exports_every_declared_symbol():
 def test_library_loads_and_reports_abi():
     lib = _lib.load()
     assert lib.smoe_abi_version() == _lib.ABI_VERSION
+    # the binary that travels with the tree was built from the tree's sources (csrc/Makefile hashes them into the library)
+    assert _lib.source_build_id() is not None and len(_lib.binary_build_id()) == 16
+    assert _lib.binary_build_id() == _lib.source_build_id(), (
+        "libslimmoe_hip.so was not built from the sources in slim-switch-moe-vit_amd/csrc: run __graft_entry__.build()")
     assert lib.smoe_dispatch_plan_workspace_bytes(50432, 8) >= 2 * 50 * 8 * 4
 
 
@@ -240,3 +244,75 @@ def test_multi_tensor_block_table_and_wgrad_round_model():
     assert ops._wgrad_rounds(8, 768, 3072, 256) == 2
     assert ops._wgrad_rounds(4, 768, 3072, 256) == 1      # 144 tiles: one round either way
     assert np.isclose(ops._wgrad_rounds(1, 256, 256, 256), 1.0)
+
+
+def test_train_one_epoch_takes_the_reference_positional_arguments():
+    """main.py:825-838 calls ``train_one_epoch(model, criterion, loader, optimizer, device, epoch, loss_scaler, clip_grad,
+    model_ema, mixup_fn, set_training_mode=..., args=...)``: positions 9 and 10 are the EMA and the mixup function
+    (engine.py:22-35); the build's own extensions are keyword-only; a three-tensor criterion gets the inputs
+    (engine.py:54); a non-finite loss ends the run as engine.py:56-60 does."""
+    sig = inspect.signature(sm.train_one_epoch)
+    names = list(sig.parameters)
+    assert names[:12] == ["model", "criterion", "data_loader", "optimizer", "device", "epoch", "loss_scaler", "max_norm",
+                          "model_ema", "mixup_fn", "set_training_mode", "args"]
+    for extra in ("aux_loss_weight", "gate_delta", "autocast"):
+        assert sig.parameters[extra].kind is inspect.Parameter.KEYWORD_ONLY
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Flatten(), nn.Linear(12, 5))
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    calls = {"ema": 0, "mix": 0, "crit3": 0}
+
+    class Ema:
+        def update(self, m):
+            assert m is model
+            calls["ema"] += 1
+
+    def mix(x, y):
+        calls["mix"] += 1
+        return x, y
+
+    class Crit3(nn.Module):
+        def forward(self, inputs, outputs, labels):
+            calls["crit3"] += 1
+            assert inputs.shape[0] == outputs.shape[0]
+            return nn.functional.cross_entropy(outputs, labels)
+
+    data = [(torch.randn(4, 3, 2, 2), torch.randint(0, 5, (4,))) for _ in range(3)]
+    st = sm.train_one_epoch(model, Crit3(), data, opt, "cpu", 0, sm.NativeScaler(enabled=False), None, Ema(), mix, True, None)
+    assert calls == {"ema": 3, "mix": 3, "crit3": 3} and st["steps"] == 3 and st["lr"] == 0.1
+    st = sm.train_one_epoch(model, nn.CrossEntropyLoss(), data, opt, "cpu", 1, sm.NativeScaler(enabled=False))
+    assert st["steps"] == 3 and st["loss"] == st["loss"]
+    bad = [(torch.full((4, 3, 2, 2), float("nan")), torch.randint(0, 5, (4,)))]
+    with pytest.raises(SystemExit):
+        sm.train_one_epoch(model, nn.CrossEntropyLoss(), bad, opt, "cpu", 2, sm.NativeScaler(enabled=False))
+
+
+def test_adamw_state_dict_carries_the_step_count_on_cpu():
+    """The torch-composition path of optim.AdamW (CPU tensors): state_dict()['state'][i]['step'] = updates applied, loads
+    into torch.optim.AdamW and back (tensor step), and the resumed run equals the uninterrupted one."""
+    g = torch.Generator().manual_seed(0)
+    init = torch.randn(6, 5, generator=g)
+    grads = [torch.randn(6, 5, generator=g) for _ in range(6)]
+
+    def run(opt, p, gs):
+        for gr in gs:
+            p.grad = gr.clone()
+            opt.step()
+
+    ref = nn.Parameter(init.clone())
+    run(torch.optim.AdamW([ref], lr=1e-2, weight_decay=0.05), ref, grads)
+    a = nn.Parameter(init.clone())
+    oa = sm.AdamW([a], lr=1e-2, weight_decay=0.05)
+    run(oa, a, grads[:3])
+    sd = oa.state_dict()
+    assert int(sd["state"][0]["step"]) == 3
+    t = nn.Parameter(a.detach().clone())
+    ot = torch.optim.AdamW([t], lr=1e-2, weight_decay=0.05)
+    ot.load_state_dict(sd)
+    run(ot, t, grads[3:4])
+    b = nn.Parameter(t.detach().clone())
+    ob = sm.AdamW([b], lr=1e-2, weight_decay=0.05)
+    ob.load_state_dict(ot.state_dict())          # torch's tensor 'step'
+    assert ob.state_dict()["state"][0]["step"] == 4
+    run(ob, b, grads[4:])
+    assert torch.allclose(b.detach(), ref.detach(), rtol=0, atol=1e-6)
