@@ -8,8 +8,10 @@
 
 A step = one eval-mode forward of the whole model over one batch of synthetic images already resident in
 HBM (reference harness: engine.py:88-121 -- eval(), no_grad, fp16 autocast).  The MoE operator (router,
-dispatch plan, token scatter, grouped GEMMs, combine) runs on the hand-written HIP kernels; the dense shell
-around it (patch embed, attention, LayerNorm, head) is ordinary torch.  N > 1 = expert parallel: the 8
+dispatch plan, token scatter, grouped GEMMs, combine) runs on the hand-written HIP kernels, and so does the dense
+shell around it under fp16 autocast (patch embedding, qkv / projection / head on the grouped GEMM with one row group,
+the attention kernel, LayerNorm); what is left of torch are elementwise kernels of the embedding stage and the
+class-token LayerNorm.  N > 1 = expert parallel: the 8
 experts are partitioned over the ranks, every rank keeps 256 images (weak scaling) and tokens travel by
 RCCL all-to-all (slim_switch_moe_vit_amd/ep.py).
 """

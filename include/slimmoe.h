@@ -114,7 +114,14 @@ int smoe_layernorm(const void* x, int x_dtype, const float* gamma, const float* 
  * writes it; f16 / bf16.  Caller-side kernel, not part of the MoE operator.       */
 int smoe_attention_supported(int N, int head_dim);
 int smoe_attention_fwd(const void* qkv, void* out, int dtype, int B, int N, int H, int head_dim, float scale,
-                       void* stream);
+                       float* lse, void* stream);
+/* lse (may be NULL; N <= 256): [B, H, N] f32, log2 of the softmax normaliser in the scaled-score domain, p = exp2(s scale
+ * log2(e) - lse) -- what the backward recomputes the probabilities from.
+ * smoe_attention_bwd: dqkv [B,N,3,H,64] (same fused layout) from qkv, the forward's out and lse, and dout [B,N,H*64]:
+ * dV = P^T dO, dS = P (dO V^T - rowsum(dO O)) scale, dQ = dS K, dK = dS^T Q; scores recomputed per (image, head), N <= 256. */
+int smoe_attention_bwd_supported(int N, int head_dim);
+int smoe_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int dtype, int B, int N,
+                       int H, int head_dim, float scale, void* stream);
 
 /* ---- dispatch plan --------------------------------------------------------------------------------
  * Replaces fmoe_cuda.expert_count + cumsum + assign_pos (+ limit_by_capacity /
@@ -130,6 +137,14 @@ size_t smoe_dispatch_plan_workspace_bytes(int64_t n, int E);
 int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t capacity,
                        int32_t* counts, int32_t* offsets, int64_t* pos, int64_t* inv_pos,
                        int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream);
+/* The same plan in the PADDED layout of a capacity gate's static expert-parallel exchange (SURVEY.md section 8e, Appendix B
+ * `cap` note: "[W, E_local, cap, d] exchange buffers, no count exchange / host sync needed"): expert e owns the slots
+ * [e * capacity, (e + 1) * capacity) whatever its count, slot = e * capacity + rank.  pos_padded has E * capacity entries
+ * (unused slots -1), inv_pos[i] is the padded slot, group_end[e] = e * capacity + counts[e] closes expert e's row range
+ * (smoe_grouped_gemm's `group_end`); counts / offsets as above.  capacity >= 1; E <= 64. */
+int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, int64_t capacity, int32_t* counts, int32_t* offsets,
+                              int32_t* group_end, int64_t* pos_padded, int64_t* inv_pos, int64_t* idx_pruned,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- token scatter (MOEScatter.forward local part: index_select(x, 0, pos // k)) ----
  * buf[s,:] = cast(x[pos[s] / k, :]) for every slot s < n_slots with pos[s] >= 0; other rows untouched.
@@ -165,8 +180,14 @@ int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, cons
  * Optional group -> expert map (group_expert != NULL, i32 [G]): `offsets` then delimits G row groups and
  * group g uses W[group_expert[g]] / bias[group_expert[g]] (expert-parallel receive layout: one group per
  * (source rank, local expert)); n_experts = leading dimension of W / bias.
+ * Optional separate row ranges (group_end != NULL, i32 [G]; persistent kernel only): group g is the rows
+ * [offsets[g], group_end[g]) and `offsets` holds G entries -- the padded [W, E_local, cap] receive buffer of a capacity
+ * gate's static exchange, whose slots are only partly filled (smoe_dispatch_plan_padded); tiles past a group's end are
+ * never scheduled, so the padding costs no MFMA work.
  * Requires K*sizeof(ab) % 128 == 0 and N % 8 == 0.
- * variant: 4 = production choice (8-wave ping-pong kernel, LDS-DMA staging; picks the 256- or 320-row tile by the
+ * variant: 9 = production choice (the 4 below as a PERSISTENT kernel, one workgroup per CU walking tiles, with the
+ * direct-store epilogue for plain 16-bit outputs; 14 = the same with the LDS-staged epilogue everywhere, A/B reference;
+ * 10-13 force tile height / schedule); 4 = production choice (8-wave ping-pong kernel, LDS-DMA staging; picks the 256- or 320-row tile by the
  * number of workgroup rounds and, for K >= 2048, the deep prefetch schedule); 5 / 6 force the 320- / 256-row tile,
  * 7 / 8 the deep schedule on the 256- / 320-row tile; 1-3 earlier LDS-DMA structures and 0 the register-staged
  * kernel (the only one for f32 operands or K % 64 != 0; chosen automatically then) are kept as A/B references.
@@ -175,7 +196,7 @@ int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int
                       const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
                       int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,
                       const void* residual, const int64_t* a_gather, int a_div,
-                      void* out, int out_dtype, int variant, void* stream);
+                      void* out, int out_dtype, int variant, const int32_t* group_end, void* stream);
 
 /* smoe_grouped_gemm_gelu_keep: the first expert linear of the TRAINING forward (fmoe_cuda.linear_forward + the activation, whose
  * input autograd keeps): pre_out = A W^T + bias and out = gelu(pre_out), both [m_rows, N] in the operand dtype (f16 / bf16), from one
@@ -262,6 +283,17 @@ int smoe_a2a_tokens(smoe_ctx* ctx, const void* send, const int64_t* send_rows, v
 int smoe_a2a_wait(smoe_ctx* ctx, void* stream);
 int64_t smoe_a2a_last_ticket(smoe_ctx* ctx);
 int smoe_a2a_wait_ticket(smoe_ctx* ctx, int64_t ticket, void* stream);
+
+/* ---- backward of the dense half of the block (training step, engine.py:52-74) -------------------------
+ * The linears' backward needs no kernel of its own: dgrad = smoe_grouped_gemm with one row group on the transposed weight
+ * image (smoe_transpose_cast), wgrad = smoe_grouped_wgrad_rows with one group, bias gradient = smoe_group_colsum.
+ * smoe_layernorm_bwd: backward of nn.LayerNorm(d, eps) (models/vision_transformer.py:303-311) from x alone (statistics
+ * recomputed): dx = rstd (g - mean(g) - xhat mean(g xhat)) [+ dres: the gradient arriving over the residual connection that
+ * bypasses the norm, fused], g = dy gamma; dgamma_dbeta [2 d] = (sum dy xhat, sum dy), deterministic (partial rows per
+ * workgroup in `workspace`, added in order).  x / dx / dres f32 [T, d]; dy f32 / f16 / bf16; d % 4 == 0, d <= 1024.   */
+size_t smoe_layernorm_bwd_workspace_bytes(int64_t T, int d);
+int smoe_layernorm_bwd(const float* x, const void* dy, int dy_dtype, const float* gamma, const float* dres, float eps, int64_t T,
+                       int d, float* dx, float* dgamma_dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- optimizer side of the training step (engine.py:68-74: timm NativeScaler around torch.optim.AdamW; SURVEY.md 8f
  * rank 3).  Everything stays on the device -- loss scale, non-finite flag, clip coefficient, step count -- so a step has

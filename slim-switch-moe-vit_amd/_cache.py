@@ -5,7 +5,9 @@ must not read it before that kernel has run.  Every entry therefore carries the 
 and the stream it was produced on; ``get`` makes any other stream wait on that event (a no-op for the single-stream
 case, which never leaves the producing stream).  Versioned entries are rebuilt when the source tensor changes
 (``_version`` / ``data_ptr``); in-place updates through ``.data`` do not bump ``_version`` -- call ``invalidate()``
-after those (the modules do it from a load_state_dict post-hook)."""
+after those (the modules do it from a load_state_dict post-hook; optim.AdamW bumps the versions itself after its fused
+step).  A tensor handed to a stream other than its producer's is also registered with the caching allocator
+(``record_stream``), so dropping the entry cannot recycle memory that stream still reads."""
 from __future__ import annotations
 
 import weakref
@@ -42,6 +44,9 @@ class StreamCache:
             st = torch.cuda.current_stream(t.device)
             if st.cuda_stream != sid:
                 st.wait_event(ev)
+                # the consumer's stream is not the one the caching allocator knows this tensor by: without this, a version
+                # bump that drops the entry could hand its memory to a new allocation while this stream still reads it
+                t.record_stream(st)
         return t
 
 

@@ -27,6 +27,8 @@ SIGNATURES = {
     "smoe_dispatch_plan_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "smoe_dispatch_plan": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "smoe_dispatch_plan_padded": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_scatter_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "smoe_gelu": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "smoe_rowdot": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
@@ -46,10 +48,16 @@ SIGNATURES = {
                                     c_int, c_void_p]),
     "smoe_grouped_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
                                   c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
-                                  c_void_p]),
+                                  c_void_p, c_void_p]),
     "smoe_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.c_float, c_int64, c_int, c_void_p, c_int, c_void_p]),
+    "smoe_layernorm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "smoe_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, ctypes.c_float, c_int64, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_attention_supported": (c_int, [c_int, c_int]),
-    "smoe_attention_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p]),
+    "smoe_attention_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p, c_void_p]),
+    "smoe_attention_bwd_supported": (c_int, [c_int, c_int]),
+    "smoe_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                   ctypes.c_float, c_void_p]),
     "smoe_ln_router_supported": (c_int, [c_int, c_int, c_int]),
     "smoe_ln_router_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
@@ -87,7 +95,7 @@ _lib = None
 
 # what csrc/Makefile hashes into smoe_build_id(): the same names, sorted as strings, relative to csrc/
 _HASHED = ["api.hip", "router.hip", "router16.hip", "gate.hip", "dispatch.hip", "gemm.hip", "backward.hip", "attention.hip",
-           "optim.hip", "comm.hip", "smoe_common.h", "router16_kernel.h", "router_mt_kernel.h", "gemm_persistent.h",
+           "optim.hip", "comm.hip", "dense_bwd.hip", "attention_bwd.hip", "smoe_common.h", "router16_kernel.h", "router_mt_kernel.h", "gemm_persistent.h",
            "../../include/slimmoe.h", "Makefile"]
 
 

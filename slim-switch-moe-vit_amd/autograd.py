@@ -57,12 +57,16 @@ class _Scatter(torch.autograd.Function):
 
 
 class _Combine(torch.autograd.Function):
+    """out[t] = sum_j score[t, j] y[inv_pos[t k + j]] (+ residual[t]: the block's `x + mlp(...)` add fused into the store; its
+    gradient is the output's)."""
+
     @staticmethod
-    def forward(ctx, y, score, pos, inv_pos, k, out_dtype):
+    def forward(ctx, y, score, pos, inv_pos, k, out_dtype, residual=None):
         T = score.shape[0]
-        ctx.k, ctx.ydtype = k, y.dtype
+        ctx.k, ctx.ydtype, ctx.has_res = k, y.dtype, residual is not None
         ctx.save_for_backward(y, score, pos, inv_pos)
-        return ops.gather_combine(y, inv_pos, score.detach().float().contiguous(), T, k, out_dtype)
+        return ops.gather_combine(y, inv_pos, score.detach().float().contiguous(), T, k, out_dtype,
+                                  residual=residual.detach() if residual is not None else None)
 
     @staticmethod
     def backward(ctx, dout):
@@ -71,7 +75,7 @@ class _Combine(torch.autograd.Function):
         T, k = score.shape[0], ctx.k
         dy = ops.scatter_rows(dout, pos, k, ctx.ydtype, zero_fill=True, scale=score.float().contiguous().reshape(-1))
         dscore = ops.rowdot(dout, y, inv_pos, k).view(T, k) if ctx.needs_input_grad[1] else None
-        return dy, dscore, None, None, None, None
+        return dy, dscore, None, None, None, None, (dout if ctx.has_res else None)
 
 
 class _AllToAll(torch.autograd.Function):
@@ -230,8 +234,9 @@ def _route_train(mod, x):
     return score, counts, offsets, pos, inv_pos
 
 
-def moe_forward_train(mod, inp: torch.Tensor) -> torch.Tensor:
-    """FMoETransformerMLP.forward with autograd: single rank, or expert parallel (one exchange each way)."""
+def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
+    """FMoETransformerMLP.forward with autograd: single rank, or expert parallel (one exchange each way); ``residual``
+    (inp's shape and dtype) is added in the combine's store."""
     if mod._generic_act is not None or not mod._fused_gelu:
         raise NotImplementedError("training path supports the reference's GELU(+Dropout) activation only")
     cd = mod.compute_dtype or _default_cd()
@@ -269,5 +274,6 @@ def moe_forward_train(mod, inp: torch.Tensor) -> torch.Tensor:
             back = torch.cat([back, back.new_zeros(pos.numel() - back.shape[0], d)], 0)
     else:
         back = Y
-    out = _Combine.apply(back, score, pos, inv_pos, k, x.dtype)
+    res = residual.reshape(-1, d) if residual is not None else None
+    out = _Combine.apply(back, score, pos, inv_pos, k, x.dtype, res)
     return out.reshape(shape)

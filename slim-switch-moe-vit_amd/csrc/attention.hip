@@ -32,7 +32,7 @@ __device__ __forceinline__ int v_lds_off(int row, int dt) { return row * 128 + (
 // kernel is VALU-issue bound -- 54 MFMAs against ~600 VALU per tile).
 template <typename HT, int NKT, bool EXACT>
 __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __restrict__ qkv, HT* __restrict__ out, int N,
-                                                                  int H, float scale_log2e) {
+                                                                  int H, float scale_log2e, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NKT + (NKT & 1);
   constexpr int nkt = NKT;
@@ -211,6 +211,8 @@ __global__ __launch_bounds__(ATT_THREADS, 3) void attn_fwd_kernel(const HT* __re
       __builtin_amdgcn_sched_barrier(0);
     }
     const float inv_l = 1.0f / lacc[0];
+    // training: log2 of the softmax normaliser in the scaled-score domain, p = exp2(s c - lse) (the backward recomputes p from it)
+    if (lse && g == 0 && q0 + qi < N) lse[((int64_t)b * H + h) * N + q0 + qi] = fmaf(m, scale_log2e, __log2f(lacc[0]));
     // ---- store: lane (g, qi) holds head-dim elements 16 dt + 4 g + r of query q0 + qi ----------------------------
     if (q0 + qi < N) {
       HT* op = out + ((int64_t)b * N + q0 + qi) * (H * ATT_D) + h * ATT_D + g * 4;
@@ -417,27 +419,31 @@ int launch_attn_long(const void* qkv, void* out, int B, int N, int H, float scal
 }
 
 template <typename HT, int NKT, bool EXACT>
-int launch_attn(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s) {
+int launch_attn(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s, float* lse) {
   const size_t smem = 2 * (size_t)NKT * 16 * 128;
   auto kern = attn_fwd_kernel<HT, NKT, EXACT>;
   SMOE_ENSURE_SMEM(attn_fwd_kernel<HT, NKT, EXACT>);
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(ATT_THREADS), smem, s, (const HT*)qkv, (HT*)out, N, H,
-                     scale * 1.4426950408889634f);
+                     scale * 1.4426950408889634f, lse);
   SMOE_CHECK_LAUNCH("smoe_attention_fwd");
   return 0;
 }
 
 template <typename HT>
-int attn_dispatch(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s) {
+int attn_dispatch(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s, float* lse) {
   const int nkt = (N + 15) / 16;
-  if (nkt == 13) return launch_attn<HT, 13, true>(qkv, out, B, N, H, scale, s);   // N = 197 / 198 (ViT @224 + cls)
-  if (nkt == 4) return launch_attn<HT, 4, true>(qkv, out, B, N, H, scale, s);
-  if (nkt == 8) return launch_attn<HT, 8, true>(qkv, out, B, N, H, scale, s);
-  if (nkt == 16) return launch_attn<HT, 16, true>(qkv, out, B, N, H, scale, s);
-  if (nkt < 4) return launch_attn<HT, 4, false>(qkv, out, B, N, H, scale, s);
-  if (nkt < 8) return launch_attn<HT, 8, false>(qkv, out, B, N, H, scale, s);
-  if (nkt < 13) return launch_attn<HT, 13, false>(qkv, out, B, N, H, scale, s);
-  if (nkt < 16) return launch_attn<HT, 16, false>(qkv, out, B, N, H, scale, s);
+  if (lse && nkt > 16) {
+    smoe_set_error("smoe_attention_fwd: the log-sum-exp output (training) is kept for N <= 256 only, N=%d", N);
+    return 1;
+  }
+  if (nkt == 13) return launch_attn<HT, 13, true>(qkv, out, B, N, H, scale, s, lse);   // N = 197 / 198 (ViT @224 + cls)
+  if (nkt == 4) return launch_attn<HT, 4, true>(qkv, out, B, N, H, scale, s, lse);
+  if (nkt == 8) return launch_attn<HT, 8, true>(qkv, out, B, N, H, scale, s, lse);
+  if (nkt == 16) return launch_attn<HT, 16, true>(qkv, out, B, N, H, scale, s, lse);
+  if (nkt < 4) return launch_attn<HT, 4, false>(qkv, out, B, N, H, scale, s, lse);
+  if (nkt < 8) return launch_attn<HT, 8, false>(qkv, out, B, N, H, scale, s, lse);
+  if (nkt < 13) return launch_attn<HT, 13, false>(qkv, out, B, N, H, scale, s, lse);
+  if (nkt < 16) return launch_attn<HT, 16, false>(qkv, out, B, N, H, scale, s, lse);
   // long sequences: K / V tiles held in LDS rounded up to the next instantiated size (rows >= N duplicate row N - 1)
   if (nkt <= 20) return launch_attn_long<HT, 20>(qkv, out, B, N, H, scale, s);
   if (nkt <= 30) return launch_attn_long<HT, 30>(qkv, out, B, N, H, scale, s);
@@ -453,14 +459,14 @@ int attn_dispatch(const void* qkv, void* out, int B, int N, int H, float scale, 
 extern "C" int smoe_attention_supported(int N, int head_dim) { return (N >= 1 && N <= 640 && head_dim == ATT_D) ? 1 : 0; }
 
 extern "C" int smoe_attention_fwd(const void* qkv, void* out, int dtype, int B, int N, int H, int head_dim, float scale,
-                                  void* stream) {
+                                  float* lse, void* stream) {
   SMOE_REQUIRE(smoe_attention_supported(N, head_dim), "smoe_attention_fwd: unsupported N=%d head_dim=%d", N, head_dim);
   SMOE_REQUIRE(B >= 0 && H >= 1, "smoe_attention_fwd: bad B=%d H=%d", B, H);
   if (B == 0) return 0;
   SMOE_REQUIRE(qkv && out, "smoe_attention_fwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == SMOE_F16) return attn_dispatch<f16>(qkv, out, B, N, H, scale, s);
-  if (dtype == SMOE_BF16) return attn_dispatch<bf16_bits>(qkv, out, B, N, H, scale, s);
+  if (dtype == SMOE_F16) return attn_dispatch<f16>(qkv, out, B, N, H, scale, s, lse);
+  if (dtype == SMOE_BF16) return attn_dispatch<bf16_bits>(qkv, out, B, N, H, scale, s, lse);
   smoe_set_error("smoe_attention_fwd: dtype must be f16 or bf16");
   return 1;
 }

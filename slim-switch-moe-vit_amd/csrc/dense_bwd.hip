@@ -1,0 +1,181 @@
+// Backward of the dense half of the ViT block for the training step (engine.py:52-74 runs the whole model forward +
+// backward under autocast; models/vision_transformer.py:283-322 is the block): LayerNorm backward here; the linears'
+// backward reuses the grouped GEMM (dgrad, one row group), smoe_grouped_wgrad_rows and smoe_group_colsum.
+//
+// LayerNorm backward (norm1 / norm2 / final norm: nn.LayerNorm(d, eps = 1e-6), models/vision_transformer.py:303-311):
+//   xhat = (x - mean) rstd,  g = dy gamma,  dx = rstd (g - mean(g) - xhat mean(g xhat)) [+ dres],
+//   dgamma = sum_rows dy xhat,  dbeta = sum_rows dy.
+// One wave per row (a row of d <= 1024 floats = up to 16 per lane), statistics recomputed from x in registers (two-pass
+// variance, as the forward kernel) -- nothing but x itself is saved by the forward.  Bound: HBM (x + dy read, dx written).
+// The column sums are deterministic: every wave keeps its own partial sums in registers over the rows it walks, the
+// four waves of a workgroup meet in LDS in wave order, every workgroup writes one partial row, and a second launch adds
+// the partial rows in workgroup order (no atomics).
+#include "smoe_common.h"
+
+namespace {
+
+constexpr int LNB_THREADS = 256;
+constexpr int LNB_WAVES = LNB_THREADS / 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <typename DYT, int NJ>
+__global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const float* __restrict__ x, const DYT* __restrict__ dy,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                                    float eps, int64_t T, int d, float* __restrict__ dx,
+                                                                    float* __restrict__ partial) {
+  __shared__ float red[LNB_WAVES][2][NJ * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunk = d >> 2;
+  float ag[NJ][4], ab[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ag[j][i] = ab[j][i] = 0.f;
+  f32x4 gm[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    gm[j] = (gamma && c < nchunk) ? *reinterpret_cast<const f32x4*>(gamma + c * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+  }
+  const float inv_d = 1.0f / (float)d;
+  const int64_t row0 = (int64_t)blockIdx.x * LNB_WAVES + wave, stride = (int64_t)gridDim.x * LNB_WAVES;
+  for (int64_t t = row0; t < T; t += stride) {
+    float xv[NJ][4], gv[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nchunk) {
+        load4(x + t * (int64_t)d + c * 4, xv[j]);
+        load4(dy + t * (int64_t)d + c * 4, gv[j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[j][i] = gv[j][i] = 0.f;
+      }
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s1 += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+    const float mean = wave_sum(s1) * inv_d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (lane + 64 * j < nchunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float dv = xv[j][i] - mean; s2 = fmaf(dv, dv, s2); }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) * inv_d + eps);
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xh = (lane + 64 * j < nchunk) ? (xv[j][i] - mean) * rstd : 0.f;
+        const float dyv = gv[j][i];
+        ag[j][i] = fmaf(dyv, xh, ag[j][i]);     // dgamma
+        ab[j][i] += dyv;                        // dbeta
+        const float g = dyv * gm[j][i];
+        c1 += g;
+        c2 = fmaf(g, xh, c2);
+        xv[j][i] = xh;
+        gv[j][i] = g;
+      }
+    }
+    c1 = wave_sum(c1) * inv_d;
+    c2 = wave_sum(c2) * inv_d;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nchunk) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = rstd * (gv[j][i] - c1 - xv[j][i] * c2);
+        if (dres) o += *reinterpret_cast<const f32x4*>(dres + t * (int64_t)d + c * 4);
+        *reinterpret_cast<f32x4*>(dx + t * (int64_t)d + c * 4) = o;
+      }
+    }
+  }
+  // the workgroup's column sums, waves added in wave order
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[wave][0][(lane + 64 * j) * 4 + i] = ag[j][i];
+      red[wave][1][(lane + 64 * j) * 4 + i] = ab[j][i];
+    }
+  __syncthreads();
+  for (int c = tid; c < 2 * d; c += LNB_THREADS) {
+    const int which = c >= d, col = which ? c - d : c;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNB_WAVES; ++w) s += red[w][which][col];
+    partial[(int64_t)blockIdx.x * 2 * d + c] = s;
+  }
+}
+
+// dgamma_dbeta[c] (c < 2 d: dgamma then dbeta) = sum over the workgroups' partial rows, in workgroup order
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int n_rows, int two_d,
+                                                                   float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= two_d) return;
+  float s = 0.f;
+  for (int r = 0; r < n_rows; ++r) s += partial[(int64_t)r * two_d + c];
+  out[c] = s;
+}
+
+inline int lnb_grid(int64_t T) {
+  int64_t need = (T + LNB_WAVES - 1) / LNB_WAVES;
+  const int64_t cap = (int64_t)smoe_num_cus() * 4;      // 16 waves per CU: every lane keeps 2 x NJ 16-byte loads in flight
+  if (need > cap) need = cap;
+  return (int)(need < 1 ? 1 : need);
+}
+
+template <typename DYT>
+int lnb_launch(const float* x, const void* dy, const float* gamma, const float* dres, float eps, int64_t T, int d, float* dx,
+               float* partial, float* dgamma_dbeta, hipStream_t s) {
+  const int grid = lnb_grid(T);
+#define LNB(NJ) hipLaunchKernelGGL((layernorm_bwd_kernel<DYT, NJ>), dim3(grid), dim3(LNB_THREADS), 0, s, x, (const DYT*)dy, gamma, dres, eps, T, d, dx, partial)
+  const int nj = (d / 4 + 63) / 64;
+  switch (nj) {
+    case 1: LNB(1); break;
+    case 2: LNB(2); break;
+    case 3: LNB(3); break;
+    case 4: LNB(4); break;
+    default: smoe_set_error("smoe_layernorm_bwd: d=%d out of range (d <= 1024)", d); return 1;
+  }
+#undef LNB
+  SMOE_CHECK_LAUNCH("smoe_layernorm_bwd");
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, s, partial, grid, 2 * d, dgamma_dbeta);
+  SMOE_CHECK_LAUNCH("smoe_layernorm_bwd/reduce");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t smoe_layernorm_bwd_workspace_bytes(int64_t T, int d) {
+  if (T < 0 || d <= 0) return 0;
+  return (size_t)lnb_grid(T) * 2 * (size_t)d * sizeof(float);
+}
+
+extern "C" int smoe_layernorm_bwd(const float* x, const void* dy, int dy_dtype, const float* gamma, const float* dres, float eps,
+                                  int64_t T, int d, float* dx, float* dgamma_dbeta, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  SMOE_REQUIRE(T >= 0 && d > 0 && d % 4 == 0 && d <= 1024, "smoe_layernorm_bwd: bad sizes T=%lld d=%d (d %% 4 == 0, d <= 1024)",
+               (long long)T, d);
+  SMOE_REQUIRE(dgamma_dbeta && workspace, "smoe_layernorm_bwd: null pointer");
+  SMOE_REQUIRE(workspace_bytes >= smoe_layernorm_bwd_workspace_bytes(T, d), "smoe_layernorm_bwd: workspace too small");
+  SMOE_REQUIRE(T == 0 || (x && dy && dx), "smoe_layernorm_bwd: null pointer");
+  SMOE_REQUIRE(smoe_dtype_ok(dy_dtype), "smoe_layernorm_bwd: bad dy dtype");
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = reinterpret_cast<float*>(workspace);
+  switch (dy_dtype) {
+    case SMOE_F32: return lnb_launch<float>(x, dy, gamma, dres, eps, T, d, dx, partial, dgamma_dbeta, s);
+    case SMOE_F16: return lnb_launch<f16>(x, dy, gamma, dres, eps, T, d, dx, partial, dgamma_dbeta, s);
+    default: return lnb_launch<bf16_bits>(x, dy, gamma, dres, eps, T, d, dx, partial, dgamma_dbeta, s);
+  }
+}

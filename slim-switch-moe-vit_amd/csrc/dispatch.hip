@@ -74,11 +74,15 @@ __global__ __launch_bounds__(1024) void plan_scan_kernel(const int32_t* __restri
 
 // FUSED: rawbase_or_cnt is blockcnt[nblk][E]; the scan (base ranks of this chunk, totals, capacity clamp, offsets)
 // happens here in LDS, workgroup 0 publishes counts / offsets, and every workgroup clears its share of the pos tail.
+// PADDED layout (slot_stride > 0; the static exchange buffers of a capacity gate under expert parallelism): expert e owns the
+// slots [e * slot_stride, (e + 1) * slot_stride) whatever the counts are, slot = e * slot_stride + rank; pos has E * slot_stride
+// entries (unused ones -1) and group_end_out[e] = e * slot_stride + counts[e] closes expert e's row range for the grouped GEMM.
 template <bool FUSED>
 __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
     const int64_t* __restrict__ idx, int64_t n, int E, int64_t capacity, const int32_t* __restrict__ rawbase_or_cnt,
     const int32_t* __restrict__ offsets_in, int64_t* __restrict__ pos, int64_t* __restrict__ inv_pos,
-    int64_t* __restrict__ idx_pruned, int nblk, int32_t* __restrict__ counts_out, int32_t* __restrict__ offsets_out) {
+    int64_t* __restrict__ idx_pruned, int nblk, int32_t* __restrict__ counts_out, int32_t* __restrict__ offsets_out,
+    int64_t slot_stride, int32_t* __restrict__ group_end_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // run[w][e]: raw rank of the next entry of expert e seen by wave w (wave w owns a contiguous quarter of the chunk)
   int32_t* run = reinterpret_cast<int32_t*>(smem);  // [PLAN_WAVES][E]
@@ -118,11 +122,22 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
     if (me == 0) {
       for (int e = tid; e < E; e += PLAN_THREADS) counts_out[e] = stot[e];
       for (int e = tid; e <= E; e += PLAN_THREADS) offsets_out[e] = soff[e];
+      if (group_end_out)
+        for (int e = tid; e < E; e += PLAN_THREADS) group_end_out[e] = (int32_t)(e * slot_stride) + stot[e];
     }
-    // tail: slots [kept, n) hold no entry
-    const int64_t kept = soff[E];
-    for (int64_t i = chunk_base + tid; i < chunk_base + PLAN_CH && i < n; i += PLAN_THREADS)
-      if (i >= kept) pos[i] = -1;
+    if (slot_stride > 0) {
+      // unused slots of every expert's fixed range hold no entry; the workgroups share the E * slot_stride slots evenly
+      const int64_t total = (int64_t)E * slot_stride, share = (total + nblk - 1) / nblk;
+      for (int64_t sl = (int64_t)me * share + tid; sl < (int64_t)(me + 1) * share && sl < total; sl += PLAN_THREADS) {
+        const int e = (int)(sl / slot_stride);
+        if (sl - (int64_t)e * slot_stride >= stot[e]) pos[sl] = -1;
+      }
+    } else {
+      // tail: slots [kept, n) hold no entry
+      const int64_t kept = soff[E];
+      for (int64_t i = chunk_base + tid; i < chunk_base + PLAN_CH && i < n; i += PLAN_THREADS)
+        if (i >= kept) pos[i] = -1;
+    }
   }
   const int32_t* offsets = FUSED ? soff : offsets_in;
   __syncthreads();
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
       const int32_t raw = myrun[e] + rank_in_step;
       const bool keep = (capacity < 0) || ((int64_t)raw < capacity);
       if (keep) {
-        const int64_t slot = (int64_t)offsets[e] + raw;
+        const int64_t slot = slot_stride > 0 ? (int64_t)e * slot_stride + raw : (int64_t)offsets[e] + raw;
         pos[slot] = i;
         inv_pos[i] = slot;
       } else {
@@ -371,9 +386,9 @@ extern "C" size_t smoe_dispatch_plan_workspace_bytes(int64_t n, int E) {
   return 16 + 2 * per;
 }
 
-extern "C" int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t capacity, int32_t* counts,
-                                  int32_t* offsets, int64_t* pos, int64_t* inv_pos, int64_t* idx_pruned,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+static int plan_impl(const int64_t* idx, int64_t n, int E, int64_t capacity, int32_t* counts, int32_t* offsets, int64_t* pos,
+                     int64_t* inv_pos, int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream,
+                     int64_t slot_stride, int32_t* group_end) {
   SMOE_REQUIRE(counts && offsets && workspace, "smoe_dispatch_plan: null pointer");
   SMOE_REQUIRE(n >= 0 && n < (1ll << 31), "smoe_dispatch_plan: n=%lld out of range", (long long)n);
   SMOE_REQUIRE(E >= 1 && E <= 8192, "smoe_dispatch_plan: E=%d out of range [1, 8192]", E);
@@ -390,15 +405,18 @@ extern "C" int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t 
   SMOE_CHECK_LAUNCH("smoe_dispatch_plan/count");
   if (n > 0 && E <= PLAN_FUSED_E && nblk * E <= PLAN_FUSED_MAX) {
     hipLaunchKernelGGL(plan_assign_kernel<true>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)(PLAN_WAVES * E + 3 * E + 1) * 4, s,
-                       idx, n, E, capacity, blockcnt, nullptr, pos, inv_pos, idx_pruned, (int)nblk, counts, offsets);
+                       idx, n, E, capacity, blockcnt, nullptr, pos, inv_pos, idx_pruned, (int)nblk, counts, offsets, slot_stride,
+                       group_end);
     SMOE_CHECK_LAUNCH("smoe_dispatch_plan/assign_fused");
     return 0;
   }
+  SMOE_REQUIRE(slot_stride == 0, "smoe_dispatch_plan_padded: the padded layout needs E <= %d and ceil(n / %d) * E <= %d",
+               PLAN_FUSED_E, PLAN_CH, PLAN_FUSED_MAX);
   const int scan_threads = E < 64 ? 64 : (E > 1024 ? 1024 : ((E + 63) / 64) * 64);
   hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(scan_threads), (size_t)E * 4, s, blockcnt, (int)nblk, E, capacity, rawbase, counts, offsets);
   SMOE_CHECK_LAUNCH("smoe_dispatch_plan/scan");
   if (n > 0) {
-    hipLaunchKernelGGL(plan_assign_kernel<false>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)PLAN_WAVES * E * 4, s, idx, n, E, capacity, rawbase, offsets, pos, inv_pos, idx_pruned, (int)nblk, nullptr, nullptr);
+    hipLaunchKernelGGL(plan_assign_kernel<false>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)PLAN_WAVES * E * 4, s, idx, n, E, capacity, rawbase, offsets, pos, inv_pos, idx_pruned, (int)nblk, nullptr, nullptr, (int64_t)0, nullptr);
     SMOE_CHECK_LAUNCH("smoe_dispatch_plan/assign");
     int tb = (int)((n + 255) / 256);
     if (tb > 1024) tb = 1024;
@@ -406,6 +424,22 @@ extern "C" int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t 
     SMOE_CHECK_LAUNCH("smoe_dispatch_plan/tail");
   }
   return 0;
+}
+
+extern "C" int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t capacity, int32_t* counts,
+                                  int32_t* offsets, int64_t* pos, int64_t* inv_pos, int64_t* idx_pruned,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  return plan_impl(idx, n, E, capacity, counts, offsets, pos, inv_pos, idx_pruned, workspace, workspace_bytes, stream, 0, nullptr);
+}
+
+extern "C" int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, int64_t capacity, int32_t* counts,
+                                         int32_t* offsets, int32_t* group_end, int64_t* pos_padded, int64_t* inv_pos,
+                                         int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream) {
+  SMOE_REQUIRE(capacity >= 1 && n >= 1, "smoe_dispatch_plan_padded: needs a capacity >= 1 and n >= 1");
+  SMOE_REQUIRE(group_end, "smoe_dispatch_plan_padded: null pointer");
+  SMOE_REQUIRE((int64_t)E * capacity < (1ll << 31), "smoe_dispatch_plan_padded: E * capacity out of range");
+  return plan_impl(idx, n, E, capacity, counts, offsets, pos_padded, inv_pos, idx_pruned, workspace, workspace_bytes, stream,
+                   capacity, group_end);
 }
 
 extern "C" int smoe_scatter_rows(const void* x, int x_dtype, const int64_t* pos, const float* scale, int64_t n_slots,

@@ -95,6 +95,19 @@ template <> struct OutPack<bf16_bits> {
   }
 };
 
+// four f32 -> four 16-bit outputs in two dwords (element 0 in the low half of the first), rounded as OutPack::write4 does
+template <typename OT> __device__ __forceinline__ void pack4(const f32x4& v, uint32_t& lo, uint32_t& hi);
+template <> __device__ __forceinline__ void pack4<f16>(const f32x4& v, uint32_t& lo, uint32_t& hi) {
+  f16x4 t; t[0] = (f16)v[0]; t[1] = (f16)v[1]; t[2] = (f16)v[2]; t[3] = (f16)v[3];
+  const u32x2 r = __builtin_bit_cast(u32x2, t);
+  lo = r[0]; hi = r[1];
+}
+template <> __device__ __forceinline__ void pack4<bf16_bits>(const f32x4& v, uint32_t& lo, uint32_t& hi) {
+  lo = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  hi = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+}
+template <> __device__ __forceinline__ void pack4<float>(const f32x4&, uint32_t&, uint32_t&) {}   // never used (DIRECT is 16-bit only)
+
 // scale 16 bytes of output elements in place (fused combine)
 template <typename OT> __device__ __forceinline__ u32x4 scale16(u32x4 raw, float s);
 template <> __device__ __forceinline__ u32x4 scale16<float>(u32x4 raw, float s) {
@@ -1250,7 +1263,7 @@ template <typename AB, typename OT>
 int launch_variant(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets,
                    const int32_t* group_expert, int E, int64_t m_rows_max, int K, int N, int epilogue,
                    const int64_t* row_map, const float* row_scale, const void* residual, void* out, hipStream_t s,
-                   const int64_t* a_gather, int a_div) {
+                   const int64_t* a_gather, int a_div, const int32_t* group_end) {
   if constexpr (sizeof(AB) == 2) {
     switch (variant) {
       case 1: return launch_glds<AB, OT, 128, 128, 2, 2, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 8, s);
@@ -1287,16 +1300,29 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
         const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c320 = (double)((t320 + cus - 1) / cus) * 1.25;
         const bool deep = K >= 2048;
         if (c320 <= c256) {
-          if (deep) return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
-          return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+          if (deep) return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
+          return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
         }
-        if (deep) return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
-        return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+        if (deep) return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
+        return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
       }
-      case 10: return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
-      case 11: return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
-      case 12: return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
-      case 13: return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
+      case 14: {  // as 9 with the LDS-staged epilogue everywhere (A/B reference of the direct-store epilogue)
+        const int ntn = (N + 255) / 256;
+        const int64_t t256 = ((m_rows_max + 255) / 256 + E / 2) * ntn, t320 = ((m_rows_max + 319) / 320 + E / 2) * ntn;
+        const int cus = smoe_num_cus();
+        const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c320 = (double)((t320 + cus - 1) / cus) * 1.25;
+        const bool deep = K >= 2048;
+        if (c320 <= c256) {
+          if (deep) return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, false);
+          return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, false);
+        }
+        if (deep) return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, false);
+        return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, false);
+      }
+      case 10: return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
+      case 11: return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
+      case 12: return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
+      case 13: return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
       case 6: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
       case 7: return launch_pp256<AB, OT, 16, 4>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
       case 8: return launch_pp256<AB, OT, 16, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
@@ -1318,11 +1344,12 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
 template <typename AB>
 int dispatch_out(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                  int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
-                 const void* residual, void* out, int out_dtype, hipStream_t s, const int64_t* a_gather, int a_div) {
+                 const void* residual, void* out, int out_dtype, hipStream_t s, const int64_t* a_gather, int a_div,
+                 const int32_t* group_end) {
   switch (out_dtype) {
-    case SMOE_F32: return launch_variant<AB, float>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div);
-    case SMOE_F16: return launch_variant<AB, f16>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div);
-    case SMOE_BF16: return launch_variant<AB, bf16_bits>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div);
+    case SMOE_F32: return launch_variant<AB, float>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div, group_end);
+    case SMOE_F16: return launch_variant<AB, f16>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div, group_end);
+    case SMOE_BF16: return launch_variant<AB, bf16_bits>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div, group_end);
   }
   smoe_set_error("smoe_grouped_gemm: bad out_dtype %d", out_dtype);
   return 1;
@@ -1345,7 +1372,7 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
                                  const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
                                  int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,
                                  const void* residual, const int64_t* a_gather, int a_div, void* out, int out_dtype,
-                                 int variant, void* stream) {
+                                 int variant, const int32_t* group_end, void* stream) {
   SMOE_REQUIRE(offsets && G >= 1 && G <= 65536, "smoe_grouped_gemm: bad G=%d / offsets", G);
   SMOE_REQUIRE(n_experts >= 1 && (group_expert || n_experts == G), "smoe_grouped_gemm: n_experts=%d != G=%d without a group map", n_experts, G);
   SMOE_REQUIRE(m_rows_max >= 0 && m_rows_max < (1ll << 31), "smoe_grouped_gemm: m_rows_max=%lld out of range",
@@ -1362,19 +1389,22 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   if (m_rows_max == 0) return 0;
   SMOE_REQUIRE(A && W && out, "smoe_grouped_gemm: null pointer");
   if (K % 64 != 0 || smoe_dtype_size(ab_dtype) != 2) variant = 0;
-  SMOE_REQUIRE(!a_gather || (variant >= 4 && variant <= 13 && a_div >= 1),
-               "smoe_grouped_gemm: a_gather needs variant 4-13 (16-bit operands, K %% 64 == 0)");
-  if (variant >= 9 && variant <= 13) {
+  SMOE_REQUIRE(!a_gather || (variant >= 4 && variant <= 14 && a_div >= 1),
+               "smoe_grouped_gemm: a_gather needs variant 4-14 (16-bit operands, K %% 64 == 0)");
+  if (variant >= 9 && variant <= 14) {
     // the persistent kernel addresses both operands with 32-bit byte offsets; operands of 4 GiB and more take the
-    // one-workgroup-per-tile kernel of the same tile height / schedule (9 -> 4, 10 -> 5, 11 -> 6, 12 -> 7, 13 -> 8)
+    // one-workgroup-per-tile kernel of the same tile height / schedule (9, 14 -> 4, 10 -> 5, 11 -> 6, 12 -> 7, 13 -> 8)
     const uint64_t a_bytes = (uint64_t)m_rows_max * (uint64_t)K * 2u, w_bytes = (uint64_t)n_experts * (uint64_t)N * (uint64_t)K * 2u;
-    if (a_bytes >= (1ull << 32) || w_bytes >= (1ull << 32) || G > 63) variant -= 5;   // (its group table: 64 lanes)
+    if (a_bytes >= (1ull << 32) || w_bytes >= (1ull << 32) || G > 63) variant = variant == 14 ? 4 : variant - 5;   // (its group table: 64 lanes)
   }
+  SMOE_REQUIRE(!group_end || (variant >= 9 && variant <= 14),
+               "smoe_grouped_gemm: group_end (separate row ranges per group) needs the persistent kernel: variant 9-14, 16-bit "
+               "operands under 4 GiB, K %% 64 == 0, at most 63 groups");
   hipStream_t s = (hipStream_t)stream;
   switch (ab_dtype) {
-    case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div);
-    case SMOE_F16: return dispatch_out<f16>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div);
-    case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div);
+    case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div, group_end);
+    case SMOE_F16: return dispatch_out<f16>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div, group_end);
+    case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div, group_end);
   }
   return 1;
 }
@@ -1394,8 +1424,8 @@ extern "C" int smoe_grouped_gemm_gelu_keep(const void* A, const void* W, const f
   if (K % 64 != 0 || G > 63 || a_bytes >= (1ull << 32) || w_bytes >= (1ull << 32)) return -1;
   hipStream_t s = (hipStream_t)stream;
   if (ab_dtype == SMOE_F16)
-    return launch_ps<f16, f16, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1);
-  return launch_ps<bf16_bits, bf16_bits, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1);
+    return launch_ps<f16, f16, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1, nullptr);
+  return launch_ps<bf16_bits, bf16_bits, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1, nullptr);
 }
 
 // Weight gradients of a grouped linear (fmoe_cuda.linear_backward's grad_W):

@@ -34,13 +34,26 @@ __device__ unsigned long long smoe_diag_stamps[256 * 12 * 16];
 // the backward needs H for gelu' and gelu(H) as the operand of the second linear's weight gradient; a separate GELU pass over
 // H was 620 MB of HBM traffic (110 us at ViT-B).  `residual` carries the address that RECEIVES H; no row map / residual fusion.
 // Its own instantiation (320-row tile, 5 staging passes of 2 x 64 rows): the inference kernels' registers are untouched.
-template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false>
+//
+// DIRECT (16-bit outputs without row map / residual: GEMM-1, qkv, patch embedding): the output tile does not pass through
+// LDS at all.  The swapped MFMA leaves every lane with 4 consecutive columns of one row per 16 x 16 fragment; after the
+// conversion two v_permlane16_swap per pair of neighbouring fragments give it 8 consecutive columns = one 16-byte store
+// (a wave-instruction writes a 64-byte segment of 16 rows; the next one completes their 128-byte lines).  The stores are
+// asynchronous and leave between the GELU arithmetic of the following fragments, so the staged form's store phase (two
+// LDS read + store sweeps of ~4.5 k cycles per tile behind two barriers) overlaps the VALU phase, no epilogue barrier is left
+// besides the one that publishes the next tile's first K-tile, and -- the staging region being unused -- the next tile's
+// K-tile 1 streams under the epilogue as well.  Rows past the group's end are dropped by the buffer descriptor's range check
+// (num_records = the rows of this tile that exist), so every wave issues the same number of stores and the wait that
+// publishes K-tile 0 can be a counted one (the stores are younger than the operand pieces).  Same arithmetic per element
+// as the staged epilogue: bit-identical results.
+template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false, bool DIRECT = false>
 __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
     const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* residual, OT* out, int n_tiles_n,
-    int group_m, const int64_t* __restrict__ a_gather, int a_div, int gather_len) {
+    int group_m, const int64_t* __restrict__ a_gather, int a_div, int gather_len, const int32_t* __restrict__ group_end) {
   static_assert(sizeof(AB) == 2, "16-bit operands");
+  static_assert(!DIRECT || (sizeof(OT) == 2 && !KEEP), "the direct epilogue stores 16-bit outputs, one output per tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TBM = 64 * AFR, TBN = 256, NT = 512, NW = 8;
   constexpr int STAGE = (TBM + TBN) * BK_BYTES;  // 64 KiB (72 KiB for the 320-row tile)
@@ -59,12 +72,14 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   // m-tiles in front of group l (lane E: offsets[E] and the total).  Locating a tile is then a ballot, a count-leading-
   // zeros and three v_readlane -- no memory access; the scalar scan over `offsets` it replaces cost ~2,300 cycles per
   // tile (stamps: tools/gemm_stamps.py).
-  int t_off = 0, t_tb = 0, t_ge = lane;
+  // group_end != NULL (the padded exchange buffers of a capacity gate): group l is the rows [offsets[l], group_end[l]) and
+  // `offsets` has E entries; otherwise the groups are contiguous, [offsets[l], offsets[l + 1]).
+  int t_off = 0, t_end = 0, t_tb = 0, t_ge = lane;
   {
-    const int li = lane <= E ? lane : E;
+    const int li = lane < E ? lane : (group_end ? E - 1 : E);
     t_off = offsets[li];
-    const int nxt = offsets[li < E ? li + 1 : E];
-    int cnt = lane < E ? (nxt - t_off + TBM - 1) / TBM : 0;
+    t_end = group_end ? group_end[li] : offsets[li < E ? li + 1 : E];
+    int cnt = lane < E ? (t_end - t_off + TBM - 1) / TBM : 0;
     int incl = cnt;                                 // inclusive scan over the wave
 #pragma unroll
     for (int sft = 1; sft < 64; sft <<= 1) {
@@ -90,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
         const unsigned long long msk = __ballot(lane < E && t_tb <= mt);
         const int gi = 63 - __builtin_clzll(msk);
         m0 = __builtin_amdgcn_readlane(t_off, gi) + (mt - __builtin_amdgcn_readlane(t_tb, gi)) * TBM;
-        m_end = __builtin_amdgcn_readlane(t_off, gi + 1);
+        m_end = __builtin_amdgcn_readlane(t_end, gi);
         e = __builtin_amdgcn_readlane(t_ge, gi);
         n0 = (rem / group_m) * TBN;
         return true;
@@ -420,8 +435,60 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       issue_bias(bias_par ^ 1);
       PS_STAMP(3);
       issue_kt0();    // its first K-tile streams into buffer 0 under the epilogue below
+      if constexpr (DIRECT) issue_kt1();   // nothing is staged through buffer 1: K-tile 1 may follow at once
     }
     PS_STAMP(4);
+
+    if constexpr (DIRECT) {
+      // ---- direct epilogue of (ce, cm0, cm_end, cn0): registers -> global memory ------------------------------------------
+      (void)ce;
+      const int fr = lane_e & 15, fq = lane_e >> 4;
+      f32x4 bv[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int nl = wc * 64 + ni * 16 + fq * 4;
+        bv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias) bv[ni] = *reinterpret_cast<const f32x4*>(bias_lds + bias_par * 1024 + nl * 4);
+      }
+      bias_par ^= 1;
+      // this tile's rows as a buffer: rows >= cm_end fall outside num_records and are dropped by the hardware
+      const int rows_here = (cm_end - cm0 < TBM) ? (cm_end - cm0) : TBM;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char*>(out) + (int64_t)cm0 * N * 2, 0, rows_here * N * 2, 0x00020000);
+      // after the swaps lane (fr, fq) holds columns  (2 q + (fq & 1)) * 16 + (fq >> 1) * 8 ... + 7  of fragment pair q
+      const int cq = wc * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+      const uint32_t OOR = 0x80000000u;                   // beyond any tile's num_records (320 rows x N x 2 B < 2 GiB)
+      uint32_t off0 = (uint32_t)(((wr * (TBM / 2) + fr) * N + cn0 + cq) * 2);
+      const bool ok0 = cn0 + cq < N, ok1 = cn0 + cq + 32 < N;   // N % 8 == 0: a lane's 8 columns exist together
+      const uint32_t row16 = (uint32_t)(16 * N * 2);
+#pragma unroll
+      for (int mi = 0; mi < 2 * AFR; ++mi) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          f32x4 va = acc[mi][2 * q] + bv[2 * q], vb = acc[mi][2 * q + 1] + bv[2 * q + 1];
+          if (epilogue == SMOE_EPI_GELU) { va = gelu_fast4(va); vb = gelu_fast4(vb); }
+          uint32_t a0, a1, b0, b1;
+          pack4<OT>(va, a0, a1);
+          pack4<OT>(vb, b0, b1);
+          // odd 16-lane rows of the first operand <-> even rows of the second: (a, b) -> 8 consecutive columns per lane
+          const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+          const u32x4 v = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          const uint32_t off = off0 + (uint32_t)(q * 64);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)((q ? ok1 : ok0) ? off : OOR), 0, 0);
+        }
+        off0 += row16;
+      }
+      PS_STAMP(5);
+      if (!more) break;
+      // the next tile's K-tile 0 (and 1) were issued BEFORE these stores: a counted wait that leaves only the stores in
+      // flight publishes them without waiting for a single store
+      if constexpr (AFR == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      PP_BARRIER();
+      PS_STAMP(12);
+      continue;
+    }
 
     // ---- epilogue of (ce, cm0, cm_end, cn0) in row passes through LDS ------------------------------------------------
     (void)ce;
@@ -574,7 +641,8 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
 template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false>
 int launch_ps(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert, int E,
               int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
-              const void* residual, void* out, int group_m, hipStream_t s, const int64_t* a_gather, int a_div) {
+              const void* residual, void* out, int group_m, hipStream_t s, const int64_t* a_gather, int a_div,
+              const int32_t* group_end, bool allow_direct = true) {
   constexpr int TBM = 64 * AFR, TBN = 256;
   const int n_tiles_n = (N + TBN - 1) / TBN;
   const int64_t max_tiles = ((m_rows_max + TBM - 1) / TBM + E) * n_tiles_n;
@@ -584,10 +652,21 @@ int launch_ps(const void* A, const void* W, const float* bias, const int32_t* of
 #ifdef SMOE_DIAG
   if (const char* gcap = getenv("SMOE_PS_GRID")) grid = atoi(gcap) & ~7;   // diagnostic: fewer CUs (is a phase chip- or CU-bound?)
 #endif
+  if constexpr (!KEEP && sizeof(OT) == 2) {
+    // plain 16-bit outputs (GEMM-1, qkv, patch embedding): the epilogue that stores from the registers
+    if (allow_direct && !row_map && !residual && (epilogue == SMOE_EPI_NONE || epilogue == SMOE_EPI_GELU) && (int64_t)N * TBM * 2 < (1ll << 31)) {
+      SMOE_ENSURE_SMEM(grouped_gemm_ps<AB, OT, AFR, DEEP, false, true>);
+      hipLaunchKernelGGL((grouped_gemm_ps<AB, OT, AFR, DEEP, false, true>), dim3(grid), dim3(512), 160 * 1024, s, (const AB*)A,
+                         (const AB*)W, bias, offsets, group_expert, E, K, N, epilogue, row_map, row_scale, (const OT*)residual,
+                         (OT*)out, n_tiles_n, group_m, a_gather, a_div, (int)m_rows_max, group_end);
+      SMOE_CHECK_LAUNCH("smoe_grouped_gemm/persistent-direct");
+      return 0;
+    }
+  }
   SMOE_ENSURE_SMEM(grouped_gemm_ps<AB, OT, AFR, DEEP, KEEP>);
   hipLaunchKernelGGL((grouped_gemm_ps<AB, OT, AFR, DEEP, KEEP>), dim3(grid), dim3(512), 160 * 1024, s, (const AB*)A, (const AB*)W,
                      bias, offsets, group_expert, E, K, N, epilogue, row_map, row_scale, (const OT*)residual, (OT*)out,
-                     n_tiles_n, group_m, a_gather, a_div, (int)m_rows_max);
+                     n_tiles_n, group_m, a_gather, a_div, (int)m_rows_max, group_end);
   SMOE_CHECK_LAUNCH("smoe_grouped_gemm/persistent");
   return 0;
 }

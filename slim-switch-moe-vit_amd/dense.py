@@ -1,0 +1,119 @@
+"""Training-side autograd Functions for the dense half of the ViT block on the library's own kernels.
+
+The reference trains the whole model forward + backward under fp16 autocast (engine.py:52-74); the block is
+models/vision_transformer.py:283-322: LayerNorm -> qkv -> attention -> proj (+ residual) -> LayerNorm -> MoE (+ residual).
+Under ``torch.autocast`` torch would run these as ``native_layer_norm`` (f32), casts, hipBLASLt GEMMs and an aotriton
+attention, forward and backward.  Here:
+
+    LayerNormFn   forward = smoe_layernorm (f32 rows -> f16 or f32, the cast autocast inserts fused);
+                  backward = smoe_layernorm_bwd (statistics recomputed from x; dgamma / dbeta deterministic), optionally with
+                  the gradient of the residual connection that bypasses the norm added in the same pass
+    LinearFn      forward = smoe_grouped_gemm with one row group (f16 operands, f32 accumulate -- what autocast's GEMM
+                  computes), optional f32 residual added in the store;
+                  backward: dX = dY W through the same GEMM on the transposed weight image (smoe_transpose_cast),
+                  dW = dY^T X by smoe_grouped_wgrad_rows with one group, db = smoe_group_colsum
+    AttentionFn   forward = smoe_attention_fwd on the fused [B, N, 3, H, 64] qkv layout;
+                  backward = smoe_attention_bwd (scores recomputed per (image, head); dqkv in the same fused layout)
+
+Shapes the kernels do not cover are reported by ``supported_*`` so that the caller keeps torch's path for them (loudly:
+vit.SlimMoEFallbackWarning)."""
+from __future__ import annotations
+
+import torch
+
+import os
+
+from . import ops
+
+TRAIN_BACKEND = os.environ.get("SLIMMOE_DENSE_TRAIN", "own")   # "own": the kernels below; "torch": autocast's own ops (A/B, tests)
+
+
+def autocast_half_training(x: torch.Tensor) -> bool:
+    return (TRAIN_BACKEND == "own" and x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.float16)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        ctx.eps = eps
+        ctx.save_for_backward(x, weight)
+        return ops.layernorm(x, weight.detach().float() if weight is not None else None,
+                             bias.detach().float() if bias is not None else None, eps, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dw, db = ops.layernorm_bwd(x, dy.contiguous(), weight.detach().float() if weight is not None else None, ctx.eps)
+        return dx, dw.to(weight.dtype) if weight is not None else None, db if ctx.needs_input_grad[2] else None, None, None
+
+
+def layer_norm(x: torch.Tensor, norm: torch.nn.LayerNorm, out_dtype: torch.dtype) -> torch.Tensor:
+    """``norm(x)`` for contiguous f32 rows on the HIP LayerNorm with its HIP backward; output in ``out_dtype``."""
+    return LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps, out_dtype)
+
+
+def layer_norm_supported(x: torch.Tensor, norm) -> bool:
+    return (isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine and x.is_cuda and x.dtype == torch.float32
+            and x.is_contiguous() and x.shape[-1] in ops.LN_DIMS and tuple(norm.normalized_shape) == (x.shape[-1],))
+
+
+class LinearFn(torch.autograd.Function):
+    """``x16 [M, K] @ weight[N, K]^T + bias`` (+ residual, f32) with f16 operands; ``cache`` is the module's _HalfCache."""
+
+    @staticmethod
+    def forward(ctx, x16, weight, bias, residual, cache, out_dtype, name):
+        from .vit import _linear16
+        out = _linear16(cache, x16, weight, bias, out_dtype, residual=residual, name=name)
+        if out is None:
+            raise RuntimeError(f"{name}: shape {tuple(x16.shape)} x {tuple(weight.shape)} is outside the GEMM kernel's reach "
+                               "(check linear_supported first)")
+        ctx.cache, ctx.has_bias, ctx.has_res, ctx.name = cache, bias is not None, residual is not None, name
+        ctx.save_for_backward(x16, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, weight = ctx.saved_tensors
+        N, K = weight.shape[0], x16.shape[1]
+        M = x16.shape[0]
+        dres = dy if ctx.has_res else None                   # the residual's gradient is the output's
+        dy16 = dy if dy.dtype == torch.float16 else dy.to(torch.float16)
+        dy16 = dy16.contiguous()
+        offs = ctx.cache.offsets(M, x16.device)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = ctx.cache.get_t(weight)                     # [1, K, N] f16: the dgrad GEMM contracts over N
+            dx = ops.grouped_gemm(dy16, wt, None, offs, ops.EPI_NONE, torch.float16, variant=ops.DEFAULT_GEMM_VARIANT,
+                                  prof_name=ctx.name + "_dgrad")
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ops.grouped_wgrad_rows(dy16, x16, offs)[0].reshape(weight.shape).to(weight.dtype)
+        db = ops.group_colsum(dy16, offs)[0] if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, dres, None, None, None
+
+
+def linear_supported(x16: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Forward and backward GEMMs take these shapes (K and N multiples of 64: both are contraction lengths once)."""
+    M, K = x16.shape
+    N = weight.shape[0]
+    return (x16.is_cuda and x16.dtype == torch.float16 and x16.is_contiguous() and M > 0 and K % 64 == 0 and N % 64 == 0
+            and weight.dim() >= 2 and weight.numel() == N * K)
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T scale) v on the fused qkv layout [B, N, 3, H, 64] (16-bit), forward and backward on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, N, H, hd, scale):
+        ctx.dims = (B, N, H, hd, scale)
+        o, lse = ops.attention(qkv, B, N, H, hd, scale, want_lse=True)
+        ctx.save_for_backward(qkv, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        B, N, H, hd, scale = ctx.dims
+        dqkv = ops.attention_bwd(qkv, o, do.contiguous(), lse, B, N, H, hd, scale)
+        return dqkv, None, None, None, None, None

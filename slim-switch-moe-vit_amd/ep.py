@@ -201,6 +201,90 @@ def drain(gen):
         return stop.value
 
 
+_starts_cache = StreamCache()
+
+
+_same_T_cache = {}
+
+
+def _all_ranks_hold(T: int, group, device) -> bool:
+    """True when every rank of the group brings the same number of rows T to this layer (the capacity, hence the slot
+    size of the static buffers, is a function of T).  One small all-gather the FIRST time a row count is seen (batch
+    sizes repeat: data-parallel loaders hand every rank the same batch size), cached afterwards; every rank computes
+    the same answer, so all of them take the same path."""
+    key = (id(group) if group is not None else 0, int(T))
+    hit = _same_T_cache.get(key)
+    if hit is None:
+        W = dist.get_world_size(group)
+        mine = torch.tensor([T], dtype=torch.int64, device=device if dist.get_backend(group) != "gloo" else "cpu")
+        got = [torch.empty_like(mine) for _ in range(W)]
+        dist.all_gather(got, mine, group=group)
+        hit = all(int(t) == T for t in got)
+        if len(_same_T_cache) > 256:
+            _same_T_cache.clear()
+        _same_T_cache[key] = hit
+    return hit
+
+
+def static_exchange_supported(mod, T: int, cap: int, cd, device) -> bool:
+    """The capacity-padded exchange needs the padded plan (E <= 64 groups of the fused plan kernel), the persistent GEMM's
+    separate row ranges (at most 63 row groups, 16-bit operands) and the same slot size on every rank (the same T);
+    SLIMMOE_EP_STATIC=0 switches it off (A/B)."""
+    if os.environ.get("SLIMMOE_EP_STATIC", "1") == "0":
+        return False
+    E_tot = mod.gate.tot_expert
+    ok = (E_tot <= 63 and (-(-T * mod.top_k // 1024)) * E_tot <= 8192 and mod.gemm_variant in (9, 10, 11, 12, 13, 14)
+          and cd in (torch.float16, torch.bfloat16) and mod.d_model % 64 == 0 and mod.d_hidden % 64 == 0 and mod._fused_gelu
+          and not (mod._drop_p > 0 and mod.training))
+    if ok and mod.world_size > 1:
+        ok = _all_ranks_hold(T, mod.moe_group, device)
+    return ok
+
+
+def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual):
+    """Expert-parallel forward of a CAPACITY gate on static buffers ("cfg 5 (capacity-bounded) can use
+    fixed-size padded buffers -> no host sync"; Appendix B's `cap` note).  A rank keeps at most `cap` of its rows per
+    global expert, so every (source rank, expert) pair owns a fixed slot of `cap` rows: the send buffer is
+    [W, E_local, cap, d], both all-to-alls have EQUAL splits known without looking at the routing, and nothing of the layer
+    waits for the host -- the received counts stay on the device, where the grouped GEMM takes them as the end of each slot's
+    row range (group_end) and never schedules a tile over padding.  Yields at the two exchanges (micro-batch pipelining)."""
+    from . import ops
+    from .fmoe import SwitchGate
+
+    g = mod.gate
+    W, E_local, k, d = mod.world_size, mod.num_expert, mod.top_k, mod.d_model
+    group = mod.moe_group
+    T = x.shape[0]
+    E_tot = g.tot_expert
+    counts, offsets, gend, pos_pad, inv_pos, pruned = ops.dispatch_plan_padded(idx, E_tot, cap)
+    mod.last_plan = (idx, score, counts, offsets, pos_pad, inv_pos)
+    if isinstance(g, SwitchGate):
+        from .autograd import switch_aux_loss
+        g.set_loss(switch_aux_loss(pruned, probs, E_tot))
+    # counts travel device to device ([W, E_local] each way); nobody on the host ever reads them
+    recv_counts = torch.empty_like(counts)
+    _a2a(recv_counts.view(W, E_local), counts.view(W, E_local), group=group)
+    send = ops.scatter_rows(src, pos_pad, k, cd)                       # [E_tot * cap, d]; unused slots stay unwritten
+    recv = torch.empty_like(send)
+    work = _a2a(recv, send, group=group, async_op=True)                # equal splits: E_local * cap rows per peer
+    yield                                                              # dispatch all-to-all in flight
+    if work is not None:
+        work.wait()
+    starts = _starts_cache.get((E_tot, cap, str(x.device)), 0,
+                               lambda: (torch.arange(E_tot, dtype=torch.int32, device=x.device) * cap))
+    ends = starts + recv_counts                                        # group l = (source rank, local expert): rows [l cap, l cap + n)
+    gexp = _group_expert_ids(W, E_local, x.device)
+    y = mod._experts_fwd(recv, starts, cd, out_dtype=cd, group_expert=gexp, group_end=ends)
+    back = torch.empty_like(y)
+    work2 = _a2a(back, y, group=group, async_op=True)
+    yield                                                              # return all-to-all in flight
+    if work2 is not None:
+        work2.wait()
+    out = torch.empty((T, d), dtype=x.dtype, device=x.device)
+    ops.gather_combine(back, inv_pos, score, T, k, x.dtype, out=out, residual=residual)
+    return out
+
+
 def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.Tensor] = None,
                norm: Optional[torch.nn.Module] = None) -> torch.Tensor:
     """Expert-parallel FMoETransformerMLP forward for this rank's tokens x [T, d] -> [T, d] (see ep_forward_steps)."""
@@ -242,6 +326,8 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
         src = xn16
     else:
         idx, score, _, probs = ops.router_topk(x, gw, gb, k, g.kind, noise, want_probs=isinstance(g, SwitchGate))
+    if cap >= 1 and T > 0 and static_exchange_supported(mod, T, cap, cd, x.device):
+        return (yield from _ep_forward_static(mod, x, src, idx, score, probs, cap, cd, residual))
     plans = []
     for (t0, t1) in bounds:
         plans.append(ops.dispatch_plan(idx[t0:t1], g.tot_expert, cap))

@@ -252,6 +252,9 @@ class FMoETransformerMLP(nn.Module):
         models/vision_transformer.py:321); same arithmetic as the unfused form, one HBM pass fewer."""
         if torch.is_grad_enabled() and (inp.requires_grad or residual.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
+            if inp.is_cuda and residual.shape == inp.shape and residual.dtype == inp.dtype and residual.is_contiguous():
+                from .autograd import moe_forward_train
+                return moe_forward_train(self, inp, residual=residual)   # the add rides in the combine, forward and backward
             return residual + self.forward(inp)
         if residual.shape != inp.shape or residual.dtype != inp.dtype:
             return residual + self.forward(inp)
@@ -416,22 +419,23 @@ class FMoETransformerMLP(nn.Module):
         return idx, score, probs, counts, offsets, pos, inv_pos, pruned
 
     def _experts_fwd(self, rows: torch.Tensor, offsets: torch.Tensor, cd: torch.dtype, out=None, row_map=None,
-                     row_scale=None, out_dtype=None, group_expert=None, residual=None):
+                     row_scale=None, out_dtype=None, group_expert=None, residual=None, group_end=None):
         ex = self.experts
         w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
         b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
         b2 = ex.h4toh.bias.detach().float() if ex.h4toh.bias is not None else None
         if self._fused_gelu:
             h = ops.grouped_gemm(rows, w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant,
-                                 group_expert=group_expert)
+                                 group_expert=group_expert, group_end=group_end)
             if self._drop_p > 0 and self.training:
                 h = torch.nn.functional.dropout(h, self._drop_p, True)
         else:
             h = ops.grouped_gemm(rows, w1, b1, offsets, ops.EPI_NONE, cd, variant=self.gemm_variant,
-                                 group_expert=group_expert)
+                                 group_expert=group_expert, group_end=group_end)
             h = self._generic_act(h).to(cd).contiguous()
         return ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, out_dtype, row_map=row_map, row_scale=row_scale,
-                                out=out, variant=self.gemm_variant, group_expert=group_expert, residual=residual)
+                                out=out, variant=self.gemm_variant, group_expert=group_expert, residual=residual,
+                                group_end=group_end)
 
     def _forward_infer(self, inp: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         shape = inp.shape

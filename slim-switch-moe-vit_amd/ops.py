@@ -145,21 +145,67 @@ def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[to
     return out
 
 
+def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, weight: Optional[torch.Tensor], eps: float,
+                  dres: Optional[torch.Tensor] = None):
+    """Backward of LayerNorm over the last dim from x alone: (dx f32 [same shape] (+ dres), dweight f32 [d], dbias f32 [d])."""
+    _chk(x, "x", torch.float32)
+    _chk(dy, "dy")
+    d = x.shape[-1]
+    T = x.numel() // d
+    if dy.numel() != x.numel():
+        raise RuntimeError("layernorm_bwd: dy must have x's shape")
+    if dres is not None:
+        _chk(dres, "dres", torch.float32)
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    gb = torch.empty(2 * d, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.smoe_layernorm_bwd_workspace_bytes(T, d)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    with _timed("layernorm_bwd", {"bytes": T * d * (8 + dy.element_size())}, x):
+        rc = lib.smoe_layernorm_bwd(_ptr(x), _ptr(dy), dtype_code(dy.dtype), _ptr(weight), _ptr(dres), float(eps), T, d,
+                                    _ptr(dx), _ptr(gb), _ptr(ws), ws_bytes, _stream(x))
+    _lib.check(rc, "smoe_layernorm_bwd")
+    return dx, gb[:d], gb[d:]
+
+
 def attention_supported(N: int, head_dim: int) -> bool:
     return bool(_lib.load().smoe_attention_supported(N, head_dim))
 
 
-def attention(qkv: torch.Tensor, B: int, N: int, H: int, head_dim: int, scale: float) -> torch.Tensor:
-    """qkv [B*N, 3*H*head_dim] (or [B,N,3,H,hd]) 16-bit -> softmax(q k^T * scale) v as [B, N, H*head_dim]."""
+def attention(qkv: torch.Tensor, B: int, N: int, H: int, head_dim: int, scale: float, want_lse: bool = False):
+    """qkv [B*N, 3*H*head_dim] (or [B,N,3,H,hd]) 16-bit -> softmax(q k^T * scale) v as [B, N, H*head_dim]; with
+    ``want_lse`` also the [B, H, N] f32 log2-normalisers the backward needs (returns (out, lse))."""
     _chk(qkv, "qkv")
     if qkv.dtype not in (torch.float16, torch.bfloat16) or qkv.numel() != B * N * 3 * H * head_dim:
         raise RuntimeError("qkv: expected a 16-bit [B,N,3,H,hd] tensor")
     out = torch.empty((B, N, H * head_dim), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device) if want_lse else None
     with _timed("attention", {"flops": 4.0 * B * H * N * N * head_dim}, qkv):
         rc = _lib.load().smoe_attention_fwd(_ptr(qkv), _ptr(out), dtype_code(qkv.dtype), B, N, H, head_dim, float(scale),
-                                            _stream(qkv))
+                                            _ptr(lse), _stream(qkv))
     _lib.check(rc, "smoe_attention_fwd")
-    return out
+    return (out, lse) if want_lse else out
+
+
+def attention_bwd_supported(N: int, head_dim: int) -> bool:
+    return bool(_lib.load().smoe_attention_bwd_supported(N, head_dim))
+
+
+def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int, N: int, H: int,
+                  head_dim: int, scale: float) -> torch.Tensor:
+    """dqkv (qkv's shape and dtype) of softmax(q k^T scale) v from the forward's ``out`` and ``lse``."""
+    _chk(qkv, "qkv")
+    _chk(out, "out", qkv.dtype)
+    _chk(dout, "dout", qkv.dtype)
+    _chk(lse, "lse", torch.float32)
+    if out.numel() != B * N * H * head_dim or dout.numel() != out.numel() or lse.numel() != B * H * N:
+        raise RuntimeError("attention_bwd: shapes do not match [B,N,H*hd] / [B,H,N]")
+    dqkv = torch.empty_like(qkv)
+    with _timed("attention_bwd", {"flops": 10.0 * B * H * N * N * head_dim}, qkv):
+        rc = _lib.load().smoe_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), dtype_code(qkv.dtype), B, N,
+                                            H, head_dim, float(scale), _stream(qkv))
+    _lib.check(rc, "smoe_attention_bwd")
+    return dqkv
 
 
 def ln_router_supported(d: int, E: int, k: int) -> bool:
@@ -298,6 +344,30 @@ def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Op
     return counts, offsets, pos, inv_pos, pruned
 
 
+def dispatch_plan_padded(idx: torch.Tensor, E: int, capacity: int):
+    """The plan in the padded layout of a capacity gate's static exchange: expert e owns the slots [e * capacity, (e + 1) *
+    capacity).  Returns (counts i32 [E], offsets i32 [E+1] (compact prefix), group_end i32 [E] = e * capacity + counts[e],
+    pos_padded i64 [E * capacity] (-1 = unused slot), inv_pos i64 [n] (padded slot or -1), idx_pruned i64 [n])."""
+    _chk(idx, "idx", torch.int64, align=8)
+    flat = idx.reshape(-1)
+    n = flat.numel()
+    dev = idx.device
+    lib = _lib.load()
+    ws_bytes = lib.smoe_dispatch_plan_workspace_bytes(n, E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    counts = torch.empty(E, dtype=torch.int32, device=dev)
+    offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    group_end = torch.empty(E, dtype=torch.int32, device=dev)
+    pos = torch.empty(E * int(capacity), dtype=torch.int64, device=dev)
+    inv_pos = torch.empty(n, dtype=torch.int64, device=dev)
+    pruned = torch.empty(n, dtype=torch.int64, device=dev)
+    with _timed("plan", {"bytes": n * 24}, idx):
+        rc = lib.smoe_dispatch_plan_padded(_ptr(flat), n, E, int(capacity), _ptr(counts), _ptr(offsets), _ptr(group_end),
+                                           _ptr(pos), _ptr(inv_pos), _ptr(pruned), _ptr(ws), ws_bytes, _stream(idx))
+    _lib.check(rc, "smoe_dispatch_plan_padded")
+    return counts, offsets, group_end, pos, inv_pos, pruned
+
+
 def scatter_rows(x: torch.Tensor, pos: torch.Tensor, k: int, out_dtype: torch.dtype,
                  out: Optional[torch.Tensor] = None, zero_fill: bool = False,
                  scale: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -355,9 +425,11 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
                  out: Optional[torch.Tensor] = None, variant: int = 0,
                  group_expert: Optional[torch.Tensor] = None, rows_hint: Optional[int] = None,
                  residual: Optional[torch.Tensor] = None, a_gather: Optional[torch.Tensor] = None,
-                 a_div: int = 1, prof_name: str = "grouped_gemm") -> torch.Tensor:
+                 a_div: int = 1, prof_name: str = "grouped_gemm", group_end: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[r] = epi(A[r] @ W[e]^T + bias[e]) for r in [offsets[g], offsets[g+1]), e = group_expert[g] (or g).
-    W [E,N,K].  ``rows_hint`` = number of rows actually routed (for the profiler's FLOP count only)."""
+    W [E,N,K].  ``rows_hint`` = number of rows actually routed (for the profiler's FLOP count only).
+    ``group_end`` (i32 [G]): separate row ranges [offsets[g], group_end[g]) -- ``offsets`` then has G entries (the padded
+    buffers of a capacity gate's static exchange; persistent kernel only)."""
     _chk(A, "A", ndim=2)
     _chk(W, "W", A.dtype, 3)
     _chk(offsets, "offsets", torch.int32, 1)
@@ -369,6 +441,11 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     if K2 != K:
         raise RuntimeError(f"W: expected [E,N,{K}], got {tuple(W.shape)}")
     G = offsets.numel() - 1
+    if group_end is not None:
+        _chk(group_end, "group_end", torch.int32, 1)
+        G = offsets.numel()
+        if group_end.numel() != G:
+            raise RuntimeError("group_end: expected one entry per row group (offsets then holds the G starts)")
     if group_expert is None:
         if G != E:
             raise RuntimeError("offsets: expected E+1 entries")
@@ -403,7 +480,8 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     with _timed(prof_name, {"flops": 2.0 * rows * K * N, "K": K, "N": N, "epilogue": epilogue}, A):
         rc = lib.smoe_grouped_gemm(_ptr(A), _ptr(W), _ptr(bias), _ptr(offsets), _ptr(group_expert), G, E, M, K, N,
                                    dtype_code(A.dtype), epilogue, _ptr(row_map), _ptr(row_scale), _ptr(residual),
-                                   _ptr(a_gather), a_div, _ptr(out), dtype_code(out_dtype), variant, _stream(A))
+                                   _ptr(a_gather), a_div, _ptr(out), dtype_code(out_dtype), variant, _ptr(group_end),
+                                   _stream(A))
     _lib.check(rc, "smoe_grouped_gemm")
     return out
 

@@ -122,6 +122,14 @@ class _HalfCache(StreamCache):
             return out if p.dim() > 1 else out.reshape(rows)
         return super().get(("pad", id(p), rows, dtype), param_version(p), make)
 
+    def get_t(self, p: torch.Tensor) -> torch.Tensor:
+        """fp16 image of ``p [N, K]`` transposed, ``[1, K, N]``: the operand of the backward's dgrad GEMM (it contracts
+        over N), made in one HIP pass from the f32 master (N, K multiples of 64)."""
+        from . import ops
+        N = p.shape[0]
+        return super().get(("t", id(p)), param_version(p),
+                            lambda: ops.transpose_cast(p.detach().float().reshape(1, N, -1).contiguous(), torch.float16))
+
     def get_f32(self, p: torch.Tensor) -> torch.Tensor:
         """f32 view of a (bias) parameter: the parameter itself unless it is stored in another dtype."""
         if p.dtype == torch.float32:
@@ -221,6 +229,9 @@ class Attention(nn.Module):
         """``residual`` (optional, inference fast path only): returns (residual + attn(x), True) when the add was
         fused into the projection, else (attn(x), False)."""
         B, N, C = x.shape
+        tr = self._forward_train(x, residual)
+        if tr is not None:
+            return tr if residual is not None else tr[0]
         if residual is None:
             return self._forward(x)
         if x.dtype == torch.float16 and _autocast_half_inference(x):
@@ -251,6 +262,36 @@ class Attention(nn.Module):
             return F.linear(o, hc.get(self.proj.weight), hc.get(self.proj.bias)).reshape(B, N, C), False
         return self._forward(x), False
 
+    def _forward_train(self, x, residual):
+        """The training step's attention half on the library's kernels, forward AND backward (dense.py): fp16 rows from the
+        HIP LayerNorm -> qkv GEMM -> attention -> projection GEMM (+ the f32 residual in its store).  None when a
+        precondition does not hold (the caller then takes torch's path): fp16 autocast with gradients, no attention /
+        projection dropout (the reference's defaults, main.py --drop 0.0), shapes the kernels cover."""
+        from . import dense, ops
+        if not (x.dtype == torch.float16 and dense.autocast_half_training(x) and x.is_contiguous()):
+            return None
+        if self.training and (self.attn_drop.p > 0 or self.proj_drop.p > 0):
+            return None
+        B, N, C = x.shape
+        hd = C // self.num_heads
+        x2 = x.reshape(B * N, C)
+        if not (dense.linear_supported(x2, self.qkv.weight) and dense.linear_supported(x2, self.proj.weight)
+                and ops.attention_supported(N, hd) and ops.attention_bwd_supported(N, hd) and DENSE_GEMM == "own"):
+            _warn_fallback("attention (training)", "shape outside the backward kernels' reach (N <= 256, head dim 64, C % 64 == 0)",
+                           (B, N, C, self.num_heads))
+            return None
+        if residual is not None and not (residual.dtype == torch.float32 and residual.is_contiguous()):
+            return None
+        hc = _half_cache(self)
+        qkv = dense.LinearFn.apply(x2, self.qkv.weight, self.qkv.bias, None, hc, torch.float16, "qkv_gemm")
+        o = dense.AttentionFn.apply(qkv, B, N, self.num_heads, hd, self.scale).reshape(B * N, C)
+        if residual is not None:
+            out = dense.LinearFn.apply(o, self.proj.weight, self.proj.bias, residual.reshape(B * N, C), hc, torch.float32,
+                                       "attn_proj_gemm")
+            return out.reshape(B, N, C), True
+        out = dense.LinearFn.apply(o, self.proj.weight, self.proj.bias, None, hc, torch.float16, "attn_proj_gemm")
+        return out.reshape(B, N, C), False
+
     def _forward(self, x):
         B, N, C = x.shape
         q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
@@ -280,6 +321,10 @@ class Block(nn.Module):
             from . import ops
             return ops.layernorm(x, n.weight.detach(), n.bias.detach() if n.bias is not None else None, n.eps,
                                  torch.float16)
+        from . import dense
+        if dense.autocast_half_training(x) and dense.layer_norm_supported(x, n):
+            # training: the same HIP LayerNorm (fp16 rows for the qkv GEMM) with its HIP backward
+            return dense.layer_norm(x, n, torch.float16)
         return n(x)
 
     def forward(self, x):
@@ -294,6 +339,15 @@ class Block(nn.Module):
             x = a if added else x + a
         else:
             x = x + self.drop_path(self.attn(self._norm1(x)))
+        from . import dense
+        if (dense.autocast_half_training(x) and dense.layer_norm_supported(x, self.norm2)
+                and getattr(self.mlp, "forward_add", None) is not None):
+            # training: HIP LayerNorm (f32 rows: the router routes on them) forward and backward, then the MoE operator's
+            # training path; without stochastic depth the residual add rides in the operator's combine
+            xn = dense.layer_norm(x, self.norm2, torch.float32)
+            if isinstance(self.drop_path, nn.Identity):
+                return self.mlp.forward_add(xn, x)
+            return x + self.drop_path(self.mlp(xn))
         if isinstance(self.drop_path, nn.Identity):
             steps = getattr(self.mlp, "forward_norm_add_steps", None)
             if steps is not None:
@@ -375,6 +429,20 @@ class VisionTransformer(nn.Module):
             torch.add(tok, self.pos_embed[:, 1:], out=out[:, 1:])
             out[:, 0] = self.cls_token[0, 0] + self.pos_embed[0, 0]
             return out
+        from . import dense
+        if (type(pe) is PatchEmbed and dense.autocast_half_training(x) and x.dtype == torch.float32
+                and tuple(x.shape[-2:]) == pe.img_size and DENSE_GEMM == "own"):
+            # training: the per-patch projection on the own GEMM, forward and backward (the images need no gradient)
+            B, C = x.shape[0], x.shape[1]
+            (ph, pw), (gh, gw) = pe.patch_size, pe.grid_size
+            p16 = torch.empty((B, gh, gw, C, ph, pw), dtype=torch.float16, device=x.device)
+            p16.copy_(x.detach().reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5))
+            p2 = p16.reshape(B * gh * gw, C * ph * pw)
+            if dense.linear_supported(p2, pe.proj.weight):
+                tok = dense.LinearFn.apply(p2, pe.proj.weight, pe.proj.bias, None, _half_cache(self), torch.float16,
+                                           "patch_embed_gemm").reshape(B, gh * gw, -1)
+                x = torch.cat((self.cls_token.expand(B, -1, -1), tok.float()), dim=1)
+                return self.pos_drop(x + self.pos_embed)
         x = pe(x)
         x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
         return self.pos_drop(x + self.pos_embed)
@@ -394,6 +462,11 @@ class VisionTransformer(nn.Module):
         """``self.norm(x)[:, 0]`` (models/vision_transformer.py:826-830).  LayerNorm is per token, so normalising the
         class token alone gives the identical row and skips a pass over the other 196 tokens of every image."""
         if isinstance(self.norm, nn.LayerNorm):
+            from . import dense
+            if dense.autocast_half_training(x):
+                cls = x[:, 0].contiguous()
+                if dense.layer_norm_supported(cls, self.norm):
+                    return dense.layer_norm(cls, self.norm, torch.float32)
             return self.norm(x[:, 0])
         return self.norm(x)[:, 0]
 
@@ -489,6 +562,13 @@ class VisionTransformer(nn.Module):
                 return out
             return F.linear(f16, hc.get(self.head.weight),
                             hc.get(self.head.bias) if self.head.bias is not None else None)
+        from . import dense
+        if isinstance(self.head, nn.Linear) and f.dim() == 2 and dense.autocast_half_training(f) and DENSE_GEMM == "own":
+            f16 = f.to(torch.float16)
+            if dense.linear_supported(f16, self.head.weight):
+                return dense.LinearFn.apply(f16, self.head.weight, self.head.bias, None, _half_cache(self), torch.float16,
+                                            "head_gemm")
+            _warn_fallback("head_gemm (training)", "the backward GEMMs need N % 64 == 0", (f.shape[0], f.shape[1], self.head.weight.shape[0]))
         return self.head(f)
 
 

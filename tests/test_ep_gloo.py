@@ -11,6 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from _mp import join_or_kill
+
 from oracle import moe_oracle as mo
 
 
@@ -95,10 +97,7 @@ def test_ep_exchange_matches_single_rank_oracle(W, E_local, k, n_chunks):
     procs = [ctx.Process(target=_worker, args=(r, W, port, E_local, k, n_chunks, q)) for r in range(W)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(120)
-    for p in procs:
-        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    join_or_kill(procs, 120)
     got = sorted(q.get(timeout=5) for _ in range(W))
     assert [r for r, _ in got] == list(range(W))
     for _, err in got:
@@ -147,9 +146,6 @@ def test_all_to_all_autograd_adjoint_is_the_reverse_exchange():
     procs = [ctx.Process(target=_a2a_grad_worker, args=(r, W, port, q)) for r in range(W)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(120)
-    for p in procs:
-        assert p.exitcode == 0
+    join_or_kill(procs, 120)
     got = sorted(q.get(timeout=5) for _ in range(W))
     assert all(ok and shp for _, ok, shp in got)

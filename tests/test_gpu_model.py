@@ -509,3 +509,88 @@ def test_baseline_shapes_never_leave_the_own_kernels_and_other_shapes_say_so():
             model(images)
     hits = [w for w in rec if issubclass(w.category, vit.SlimMoEFallbackWarning)]
     assert len(hits) == 1 and "attention" in str(hits[0].message), [str(w.message) for w in rec]
+
+
+def _static_exchange_worker(rank, world, port, q):
+    """One rank of the capacity gate's static exchange: SwitchGate (capacity factor 1.0 -> drops), W ranks sharing cuda:0
+    over gloo; the operator with this rank's expert slice must reproduce the single-rank operator holding all experts on
+    this rank's tokens (capacity is per source rank, so the kept set is the same), with no host sync in the layer."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d, h, E = 192, 768, 8
+        E_local = E // world
+        g = torch.Generator().manual_seed(77)
+        wg = torch.randn(E, d, generator=g) * 0.3
+        bg = torch.zeros(E); bg[1] = 1.0                      # skew: expert 1 overflows its capacity
+        w1 = torch.randn(E, h, d, generator=g) * 0.02; b1 = torch.randn(E, h, generator=g) * 0.02
+        w2 = torch.randn(E, d, h, generator=g) * 0.02; b2 = torch.randn(E, d, generator=g) * 0.02
+        T = 937
+
+        def build(ws):
+            m = sm.FMoETransformerMLP(E // ws, d, h, torch.nn.GELU(), top_k=1, gate="switch", capacity_factor=1.0, world_size=ws)
+            sl = slice(rank * E_local, (rank + 1) * E_local) if ws > 1 else slice(0, E)
+            with torch.no_grad():
+                m.gate.gate.weight.copy_(wg); m.gate.gate.bias.copy_(bg)
+                m.experts.htoh4.weight.copy_(w1[sl]); m.experts.htoh4.bias.copy_(b1[sl])
+                m.experts.h4toh.weight.copy_(w2[sl]); m.experts.h4toh.bias.copy_(b2[sl])
+            return m.to(DEV).eval()
+
+        full, part = build(1), build(world)
+        from slim_switch_moe_vit_amd import ep
+        calls = {"n": 0}
+        real = ep.PendingCounts.finish
+
+        def counting(self):
+            calls["n"] += 1
+            return real(self)
+        ep.PendingCounts.finish = counting                     # the dynamic path's host sync: must never run here
+
+        def run(T):
+            x = torch.randn(T, d, generator=torch.Generator().manual_seed(500 + rank)).to(DEV)
+            res = torch.randn(T, d, generator=torch.Generator().manual_seed(600 + rank)).to(DEV)
+            with torch.no_grad():
+                ref = full.forward_add(x, res)
+                got = part.forward_add(x, res)
+                ln = torch.nn.LayerNorm(d, eps=1e-6).to(DEV)
+                ref_ln, got_ln = full.forward_norm_add(x, ln), part.forward_norm_add(x, ln)
+            return float((got - ref).abs().max()), float((got_ln - ref_ln).abs().max()), int(full.last_plan[3][-1]) < T, \
+                bool(torch.equal(part.last_plan[2], full.last_plan[2]))
+
+        err, err_ln, dropped, same_counts = run(T)             # every rank brings the same T: static buffers
+        static_syncs = calls["n"]
+        err_r, err_ln_r, _, same_r = run(T + 11 * rank)        # ragged row counts: every rank falls back to the counted exchange
+        q.put((rank, max(err, err_r), max(err_ln, err_ln_r), static_syncs, int(dropped), same_counts and same_r, calls["n"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_static_capacity_padded_exchange_ranks_on_one_gpu(world):
+    """BASELINE cfg 5's layout (capacity gate under expert parallelism): [W, E_local, cap, d] exchange buffers with equal
+    all-to-all splits, received counts kept on the device as the end of each slot's row range (smoe_grouped_gemm's
+    group_end) -- the layer never waits for the host.  W processes on one GPU over gloo."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_static_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    _join_or_kill(procs, 300)
+    got = sorted(q.get(timeout=10) for _ in range(world))
+    for rank, err, err_ln, host_syncs, dropped, same_counts, syncs_ragged in got:
+        print(f"rank {rank}/{world}: |ep - single| {err:.2e} (with LayerNorm fused {err_ln:.2e}), count read-backs {host_syncs} "
+              f"(static), {syncs_ragged} (after the ragged batch)")
+        assert host_syncs == 0, "the static exchange must not read the counts back"
+        assert syncs_ragged == 2, "ragged row counts take the counted exchange (one read-back per forward)"
+        assert dropped == 1, "the test must exercise dropping"
+        assert same_counts
+        assert err <= 2e-3 and err_ln <= 2e-3, (rank, err, err_ln)

@@ -816,6 +816,24 @@ def test_cabi_exchange_context_world_of_one_and_ep_transport():
         assert torch.equal(got2, big) and torch.isfinite(busy)
         empty = ctx.all_to_all_rows(rows[:0], [0], [0])
         assert empty.shape == (0, 192)
+        # two exchanges in flight, waited for OUT OF ORDER through their tickets (a micro-batch pipeline does exactly this)
+        a = ctx.all_to_all_rows(big, [50000], [50000], wait=False)
+        ta = ctx.last_ticket()
+        b = ctx.all_to_all_rows(rows, [777], [777], wait=False)
+        tb = ctx.last_ticket()
+        assert tb == ta + 1
+        ctx.wait_stream(b, tb)
+        assert torch.equal(b, rows[:777])
+        ctx.wait_stream(a, ta)
+        assert torch.equal(a, big)
+        # more exchanges in flight than the completion ring holds: the oldest ticket still waits correctly (for a later one)
+        outs = [(ctx.all_to_all_rows(rows, [100 + i], [100 + i], wait=False), ctx.last_ticket()) for i in range(40)]
+        for i in (0, 39, 17):
+            o, t = outs[i]
+            ctx.wait_stream(o, t)
+            assert torch.equal(o, rows[:100 + i])
+        with pytest.raises(Exception):
+            ctx.wait_stream(rows, ctx.last_ticket() + 5)    # no such exchange
     finally:
         ctx.close()
     with socket.socket() as sk:
@@ -841,3 +859,58 @@ def test_cabi_exchange_context_world_of_one_and_ep_transport():
             c.close()
         ep._ctx_cache.clear()
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------- static (capacity-padded) exchange layout
+@pytest.mark.parametrize("n,E,cap", [(50432, 8, 6304), (3000, 8, 100), (777, 4, 1000), (36928, 32, 1154), (5000, 16, 1)])
+def test_dispatch_plan_padded_layout_bit_exact(n, E, cap):
+    """smoe_dispatch_plan_padded: expert e owns slots [e cap, (e + 1) cap); same kept set, same order inside an expert as the
+    compact plan (= the oracle's), unused slots -1, group_end = e cap + counts."""
+    rng = np.random.default_rng(n + E)
+    idx = rng.integers(-1 if n % 2 else 0, E, size=n).astype(np.int64)
+    idx[rng.random(n) < 0.3] = 0   # overloaded expert: drops
+    counts, offsets, gend, pos_pad, inv_pos, pruned = ops.dispatch_plan_padded(torch.from_numpy(idx).to(DEV), E, cap)
+    p = mo.dispatch_plan(idx, E, cap)
+    assert np.array_equal(counts.cpu().numpy(), p.counts) and np.array_equal(offsets.cpu().numpy(), p.offsets)
+    assert np.array_equal(pruned.cpu().numpy(), p.idx_pruned)
+    assert np.array_equal(gend.cpu().numpy(), np.arange(E) * cap + p.counts)
+    want_pos = np.full(E * cap, -1, dtype=np.int64)
+    want_inv = np.full(n, -1, dtype=np.int64)
+    for e in range(E):
+        seg = p.pos[p.offsets[e]:p.offsets[e + 1]]
+        want_pos[e * cap:e * cap + len(seg)] = seg
+        want_inv[seg] = e * cap + np.arange(len(seg))
+    assert np.array_equal(pos_pad.cpu().numpy(), want_pos)
+    assert np.array_equal(inv_pos.cpu().numpy(), want_inv)
+
+
+@pytest.mark.parametrize("variant", [9, 10, 14])
+@pytest.mark.parametrize("out_dt", [torch.float16, torch.float32])
+def test_grouped_gemm_separate_row_ranges_touch_only_their_rows(variant, out_dt):
+    """group_end: G padded slots of `cap` rows, only [start, end) of each filled (some empty, one full, one past a tile
+    boundary); rows outside the ranges hold NaN in A and a sentinel in out -- neither may matter / change."""
+    cap, K, N = 700, 256, 328
+    fill = [700, 0, 1, 321, 64, 699, 320, 5]
+    gexp = torch.tensor([0, 1, 2, 0, 1, 2, 0, 1], dtype=torch.int32)
+    G, E = len(fill), 3
+    g = _gen(variant)
+    A = torch.randn(G * cap, K, generator=g).half()
+    W = (torch.randn(E, N, K, generator=g) * 0.05).half()
+    bias = torch.randn(E, N, generator=g) * 0.1
+    starts = (torch.arange(G) * cap).int()
+    ends = starts + torch.tensor(fill, dtype=torch.int32)
+    valid = torch.zeros(G * cap, dtype=torch.bool)
+    for l in range(G):
+        valid[l * cap:l * cap + fill[l]] = True
+    A_dev = A.clone()
+    A_dev[~valid] = float("nan")
+    out = torch.full((G * cap, N), 7.0, dtype=out_dt, device=DEV)
+    ops.grouped_gemm(A_dev.to(DEV), W.to(DEV), bias.to(DEV), starts.to(DEV), ops.EPI_GELU, out_dt, out=out, variant=variant,
+                     group_expert=gexp.to(DEV), group_end=ends.to(DEV))
+    got = out.float().cpu()
+    assert torch.all(got[~valid] == 7.0), "rows outside the ranges must stay untouched"
+    ref = torch.zeros(G * cap, N, dtype=torch.float64)
+    for l in range(G):
+        r = slice(l * cap, l * cap + fill[l])
+        ref[r] = torch.nn.functional.gelu(A[r].double() @ W[gexp[l]].double().t() + bias[gexp[l]].double())
+    assert (got.double()[valid] - ref[valid]).abs().max() <= 1e-3 * max(1.0, float(ref.abs().max()))
