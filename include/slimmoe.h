@@ -58,7 +58,10 @@ const char* smoe_last_error(void);
  * x [T,d] (x_dtype), wg [E,d] f32, bg [E] f32 or NULL, noise [T,E] f32 or NULL.
  * idx [T,k] i64, score [T,k] f32, logits_out [T,E] f32 or NULL.
  * Requires d % 8 == 0, d <= 2048, 1 <= k <= E, k <= 4.  workspace: smoe_router_workspace_bytes(T) bytes
- * (redo counter + list of tokens handed to the f64 pass).                                          */
+ * (redo counter + list of tokens handed to the f64 pass).  The calls clear the counter words with a small launch of
+ * their own -- unless the caller keeps ONE workspace per stream and says so (gate_kind | 0x200; smoe_gate_ln_router:
+ * with_ln | 2): every redo pass leaves the counter words zero on its way out, so a workspace that was zero before its
+ * first use stays ready, and the clearing launch in front of every router call disappears.                          */
 size_t smoe_router_workspace_bytes(int64_t T);
 int smoe_router_topk(const void* x, int x_dtype, const float* wg, const float* bg, const float* noise,
                      int64_t T, int d, int E, int k, int gate_kind,
@@ -139,12 +142,13 @@ int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t capacity,
                        int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream);
 /* The same plan in the PADDED layout of a capacity gate's static expert-parallel exchange (SURVEY.md section 8e, Appendix B
  * `cap` note: "[W, E_local, cap, d] exchange buffers, no count exchange / host sync needed"): expert e owns the slots
- * [e * capacity, (e + 1) * capacity) whatever its count, slot = e * capacity + rank.  pos_padded has E * capacity entries
- * (unused slots -1), inv_pos[i] is the padded slot, group_end[e] = e * capacity + counts[e] closes expert e's row range
- * (smoe_grouped_gemm's `group_end`); counts / offsets as above.  capacity >= 1; E <= 64. */
-int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, int64_t capacity, int32_t* counts, int32_t* offsets,
-                              int32_t* group_end, int64_t* pos_padded, int64_t* inv_pos, int64_t* idx_pruned,
-                              void* workspace, size_t workspace_bytes, void* stream);
+ * [e * slot_rows, (e + 1) * slot_rows) whatever its count, slot = e * slot_rows + rank (slot_rows >= capacity: the slot
+ * size every rank agreed on, e.g. the capacity of the largest local batch; `capacity` is what THIS rank keeps).  pos_padded
+ * has E * slot_rows entries (unused slots -1), inv_pos[i] is the padded slot, group_end[e] = e * slot_rows + counts[e] closes
+ * expert e's row range (smoe_grouped_gemm's `group_end`); counts / offsets as above.  capacity >= 1; E <= 64. */
+int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, int64_t capacity, int64_t slot_rows, int32_t* counts,
+                              int32_t* offsets, int32_t* group_end, int64_t* pos_padded, int64_t* inv_pos,
+                              int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- token scatter (MOEScatter.forward local part: index_select(x, 0, pos // k)) ----
  * buf[s,:] = cast(x[pos[s] / k, :]) for every slot s < n_slots with pos[s] >= 0; other rows untouched.
@@ -160,6 +164,12 @@ int smoe_scatter_rows(const void* x, int x_dtype, const int64_t* pos, const floa
 int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, const float* score,
                         int64_t T, int k, int d, const void* residual, void* out, int out_dtype,
                         void* stream);
+/* smoe_gather_combine_ln: the same combine (+ residual, f32 out [T,d]) AND LayerNorm(out row) -> xn [T,d] (f16 / bf16) in one pass:
+ * the next block's `norm1` of exactly the row this call produces (models/vision_transformer.py:320) -- the expert-parallel
+ * return path saves a 155-MB read per layer.  y f16 / bf16; k <= 4; d % 8 == 0, d <= 1024; gamma / beta f32 [d].             */
+int smoe_gather_combine_ln(const void* y, int y_dtype, const int64_t* inv_pos, const float* score, int64_t T, int k, int d,
+                           const float* residual, float* out, const float* gamma, const float* beta, float eps, void* xn,
+                           int xn_dtype, void* stream);
 
 /* ---- grouped (variable-batch) expert GEMM on MFMA ----------------------------------------------------
  * Replaces fmoe_cuda.linear_forward = MOELinear / FMoELinear: for each local
@@ -291,6 +301,9 @@ int smoe_a2a_wait_ticket(smoe_ctx* ctx, int64_t ticket, void* stream);
  * recomputed): dx = rstd (g - mean(g) - xhat mean(g xhat)) [+ dres: the gradient arriving over the residual connection that
  * bypasses the norm, fused], g = dy gamma; dgamma_dbeta [2 d] = (sum dy xhat, sum dy), deterministic (partial rows per
  * workgroup in `workspace`, added in order).  x / dx / dres f32 [T, d]; dy f32 / f16 / bf16; d % 4 == 0, d <= 1024.   */
+/* smoe_gate_dgrad: the router linear's input gradient dx [T, d] = dl [T, E] W [E, d] (f32 in, out f32 / f16 / bf16): K = E is too
+ * thin for the matrix cores, the kernel is bound by its [T, d] store.                                                            */
+int smoe_gate_dgrad(const float* dl, const float* w, int64_t T, int E, int d, void* out, int out_dtype, void* stream);
 size_t smoe_layernorm_bwd_workspace_bytes(int64_t T, int d);
 int smoe_layernorm_bwd(const float* x, const void* dy, int dy_dtype, const float* gamma, const float* dres, float eps, int64_t T,
                        int d, float* dx, float* dgamma_dbeta, void* workspace, size_t workspace_bytes, void* stream);

@@ -27,7 +27,7 @@ SIGNATURES = {
     "smoe_dispatch_plan_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "smoe_dispatch_plan": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
-    "smoe_dispatch_plan_padded": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+    "smoe_dispatch_plan_padded": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_scatter_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "smoe_gelu": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
@@ -46,10 +46,13 @@ SIGNATURES = {
     "smoe_group_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_gather_combine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                     c_int, c_void_p]),
+    "smoe_gather_combine_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, ctypes.c_float, c_void_p, c_int, c_void_p]),
     "smoe_grouped_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
                                   c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p]),
     "smoe_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.c_float, c_int64, c_int, c_void_p, c_int, c_void_p]),
+    "smoe_gate_dgrad": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "smoe_layernorm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "smoe_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, ctypes.c_float, c_int64, c_int, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),

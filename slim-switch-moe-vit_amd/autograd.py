@@ -158,7 +158,7 @@ class _GroupFFN(torch.autograd.Function):
 
 class _GateLogits(torch.autograd.Function):
     """logits = x Wg^T + bg.  Forward value: the logits the HIP router already computed (f32 accumulate, f64 for the
-    tokens it had to re-evaluate) -- no second projection; backward: dx = dl Wg (a thin library GEMM), dWg = dl^T x as a
+    tokens it had to re-evaluate) -- no second projection; backward: dx = dl Wg (smoe_gate_dgrad: K = E is too thin for a GEMM), dWg = dl^T x as a
     streaming reduction (smoe_gate_wgrad; the library's skinny-output GEMM needs 4x the HBM time), dbg = column sums."""
 
     @staticmethod
@@ -171,7 +171,12 @@ class _GateLogits(torch.autograd.Function):
     def backward(ctx, dl):
         x, w = ctx.saved_tensors
         dl = dl.float().contiguous()
-        dx = (dl @ w.float()).to(x.dtype) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if x.is_cuda and x.shape[1] % 4 == 0 and x.dtype in ops._DT and w.dtype == torch.float32 and w.is_contiguous():
+                dx = ops.gate_dgrad(dl, w.detach(), x.dtype)       # [T, E] x [E, d]: a streaming kernel, not a GEMM
+            else:
+                dx = (dl @ w.float()).to(x.dtype)
         dw = None
         if ctx.needs_input_grad[1]:
             if x.is_cuda and dl.shape[1] <= 16 and x.shape[1] % 4 == 0 and x.dtype in (torch.float32, torch.float16, torch.bfloat16):

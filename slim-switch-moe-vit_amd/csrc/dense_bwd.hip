@@ -11,6 +11,7 @@
 // four waves of a workgroup meet in LDS in wave order, every workgroup writes one partial row, and a second launch adds
 // the partial rows in workgroup order (no atomics).
 #include "smoe_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -155,7 +156,55 @@ int lnb_launch(const float* x, const void* dy, const float* gamma, const float* 
   return 0;
 }
 
+// ---- router input gradient: dx[t, :] = dl[t, :] W  (dl [T, E] f32 = d loss / d logits, W [E, d] f32: gate.gate.weight) ----------
+// The backward of the gate's nn.Linear w.r.t. its input (models/resmoe_flop_hook.py:7 names that layer): K = E <= 64 is far too
+// thin for a matrix-core GEMM -- the kernel is the [T, d] store.  One thread = 4 consecutive columns of one row; the E weights of
+// those columns come from L1 (W is E x d floats, shared by every row), the row's E gradients are wave-broadcast loads.
+template <typename OT>
+__global__ __launch_bounds__(256) void gate_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w, int64_t T, int E,
+                                                          int d, OT* __restrict__ out) {
+  const int nchunk = d >> 2;
+  const int64_t total = T * (int64_t)nchunk;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / nchunk;
+    const int c = (int)(i - t * nchunk) * 4;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* dr = dl + t * E;
+    for (int e = 0; e < E; ++e) {
+      const float g = dr[e];
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (int64_t)e * d + c);
+      acc[0] = fmaf(g, wv[0], acc[0]); acc[1] = fmaf(g, wv[1], acc[1]); acc[2] = fmaf(g, wv[2], acc[2]); acc[3] = fmaf(g, wv[3], acc[3]);
+    }
+    OT* dst = out + t * (int64_t)d + c;
+    if constexpr (std::is_same<OT, float>::value) {
+      *reinterpret_cast<f32x4*>(dst) = acc;
+    } else if constexpr (std::is_same<OT, f16>::value) {
+      f16x4 v; v[0] = (f16)acc[0]; v[1] = (f16)acc[1]; v[2] = (f16)acc[2]; v[3] = (f16)acc[3];
+      *reinterpret_cast<f16x4*>(dst) = v;
+    } else {
+      s16x4 v; v[0] = (short)f32_to_bf16(acc[0]); v[1] = (short)f32_to_bf16(acc[1]); v[2] = (short)f32_to_bf16(acc[2]); v[3] = (short)f32_to_bf16(acc[3]);
+      *reinterpret_cast<s16x4*>(dst) = v;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int smoe_gate_dgrad(const float* dl, const float* w, int64_t T, int E, int d, void* out, int out_dtype, void* stream) {
+  SMOE_REQUIRE(T >= 0 && E >= 1 && d > 0 && d % 4 == 0, "smoe_gate_dgrad: bad sizes T=%lld E=%d d=%d", (long long)T, E, d);
+  if (T == 0) return 0;
+  SMOE_REQUIRE(dl && w && out && smoe_dtype_ok(out_dtype), "smoe_gate_dgrad: null pointer / bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = (T * (d / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  switch (out_dtype) {
+    case SMOE_F32: hipLaunchKernelGGL(gate_dgrad_kernel<float>, dim3((int)blocks), dim3(256), 0, s, dl, w, T, E, d, (float*)out); break;
+    case SMOE_F16: hipLaunchKernelGGL(gate_dgrad_kernel<f16>, dim3((int)blocks), dim3(256), 0, s, dl, w, T, E, d, (f16*)out); break;
+    default: hipLaunchKernelGGL(gate_dgrad_kernel<bf16_bits>, dim3((int)blocks), dim3(256), 0, s, dl, w, T, E, d, (bf16_bits*)out); break;
+  }
+  SMOE_CHECK_LAUNCH("smoe_gate_dgrad");
+  return 0;
+}
 
 extern "C" size_t smoe_layernorm_bwd_workspace_bytes(int64_t T, int d) {
   if (T < 0 || d <= 0) return 0;

@@ -280,6 +280,86 @@ __global__ __launch_bounds__(256) void gather_combine_kernel(const YT* __restric
   }
 }
 
+// gather + combine + residual AND the LayerNorm that reads the result next (the expert-parallel path's return side: the block's
+// `x + mlp(...)` is produced here row by row, and the NEXT block starts with norm1 of exactly that row, models/
+// vision_transformer.py:320): the wave that owns a row holds it whole in registers, so mean / variance (two-pass, as
+// smoe_layernorm) and the normalised 16-bit row cost no further HBM read -- one 155-MB pass per layer less.
+template <typename YT, typename NT, int KMAX, int NJ>
+__global__ __launch_bounds__(256) void gather_combine_ln_kernel(const YT* __restrict__ y, const int64_t* __restrict__ inv_pos,
+                                                                const float* __restrict__ score, int64_t T, int k, int d,
+                                                                const float* __restrict__ residual, float* __restrict__ out,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float eps, NT* __restrict__ xn) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const float inv_d = 1.0f / (float)d;
+  for (int64_t t = wave_gid; t < T; t += nwaves) {
+    int64_t slot[KMAX];
+    float sc[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      slot[j] = (j < k) ? inv_pos[t * k + j] : -1;
+      sc[j] = (j < k) ? score[t * k + j] : 0.f;
+    }
+    float acc[NJ][8];
+#pragma unroll
+    for (int it = 0; it < NJ; ++it) {
+      const int c = lane * 8 + 512 * it;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[it][q] = 0.f;
+      if (c < d) {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+          if (slot[j] >= 0) {
+            float v[8];
+            load8(y + slot[j] * (int64_t)d + c, v);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[it][q] = fmaf(sc[j], v[q], acc[it][q]);
+          }
+        }
+        if (residual) {
+          float r[8];
+          load8(residual + t * (int64_t)d + c, r);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[it][q] += r[q];
+        }
+        store8(out + t * (int64_t)d + c, acc[it]);
+      }
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NJ; ++it)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s1 += acc[it][q];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s1 += __shfl_xor(s1, m, 64);
+    const float mean = s1 * inv_d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NJ; ++it)
+      if (lane * 8 + 512 * it < d) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float dv = acc[it][q] - mean; s2 = fmaf(dv, dv, s2); }
+      }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
+    const float rstd = rsqrtf(s2 * inv_d + eps);
+#pragma unroll
+    for (int it = 0; it < NJ; ++it) {
+      const int c = lane * 8 + 512 * it;
+      if (c < d) {
+        float g[8], b[8], o[8];
+        load8(gamma + c, g);
+        load8(beta + c, b);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = fmaf((acc[it][q] - mean) * rstd, g[q], b[q]);
+        store8(xn + t * (int64_t)d + c, o);
+      }
+    }
+  }
+}
+
 template <typename ST, typename DT>
 __global__ __launch_bounds__(256) void cast_kernel(const ST* __restrict__ src, DT* __restrict__ dst, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
@@ -432,14 +512,17 @@ extern "C" int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t 
   return plan_impl(idx, n, E, capacity, counts, offsets, pos, inv_pos, idx_pruned, workspace, workspace_bytes, stream, 0, nullptr);
 }
 
-extern "C" int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, int64_t capacity, int32_t* counts,
-                                         int32_t* offsets, int32_t* group_end, int64_t* pos_padded, int64_t* inv_pos,
-                                         int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, int64_t capacity, int64_t slot_rows,
+                                         int32_t* counts, int32_t* offsets, int32_t* group_end, int64_t* pos_padded,
+                                         int64_t* inv_pos, int64_t* idx_pruned, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
   SMOE_REQUIRE(capacity >= 1 && n >= 1, "smoe_dispatch_plan_padded: needs a capacity >= 1 and n >= 1");
+  SMOE_REQUIRE(slot_rows >= capacity, "smoe_dispatch_plan_padded: slot_rows=%lld < capacity=%lld", (long long)slot_rows,
+               (long long)capacity);
   SMOE_REQUIRE(group_end, "smoe_dispatch_plan_padded: null pointer");
-  SMOE_REQUIRE((int64_t)E * capacity < (1ll << 31), "smoe_dispatch_plan_padded: E * capacity out of range");
+  SMOE_REQUIRE((int64_t)E * slot_rows < (1ll << 31), "smoe_dispatch_plan_padded: E * slot_rows out of range");
   return plan_impl(idx, n, E, capacity, counts, offsets, pos_padded, inv_pos, idx_pruned, workspace, workspace_bytes, stream,
-                   capacity, group_end);
+                   slot_rows, group_end);
 }
 
 extern "C" int smoe_scatter_rows(const void* x, int x_dtype, const int64_t* pos, const float* scale, int64_t n_slots,
@@ -472,6 +555,39 @@ extern "C" int smoe_gather_combine(const void* y, int y_dtype, const int64_t* in
   }
   smoe_set_error("smoe_gather_combine: bad y_dtype %d", y_dtype);
   return 1;
+}
+
+namespace {
+template <typename YT, typename NT>
+int combine_ln_launch(const void* y, const int64_t* inv_pos, const float* score, int64_t T, int k, int d, const float* residual,
+                      float* out, const float* gamma, const float* beta, float eps, void* xn, hipStream_t s) {
+  const int grid = rows_grid(T);
+#define CLN(KMAX, NJ) hipLaunchKernelGGL((gather_combine_ln_kernel<YT, NT, KMAX, NJ>), dim3(grid), dim3(256), 0, s, (const YT*)y, inv_pos, score, T, k, d, residual, out, gamma, beta, eps, (NT*)xn)
+  const int nj = (d + 511) / 512;
+  if (nj == 1) { if (k == 1) CLN(1, 1); else if (k == 2) CLN(2, 1); else CLN(4, 1); }
+  else { if (k == 1) CLN(1, 2); else if (k == 2) CLN(2, 2); else CLN(4, 2); }
+#undef CLN
+  SMOE_CHECK_LAUNCH("smoe_gather_combine_ln");
+  return 0;
+}
+}  // namespace
+
+extern "C" int smoe_gather_combine_ln(const void* y, int y_dtype, const int64_t* inv_pos, const float* score, int64_t T, int k, int d,
+                                      const float* residual, float* out, const float* gamma, const float* beta, float eps,
+                                      void* xn, int xn_dtype, void* stream) {
+  SMOE_REQUIRE(T >= 0 && k >= 1 && k <= 4 && d > 0 && d % 8 == 0 && d <= 1024, "smoe_gather_combine_ln: bad sizes T=%lld k=%d d=%d",
+               (long long)T, k, d);
+  if (T == 0) return 0;
+  SMOE_REQUIRE(y && inv_pos && score && out && gamma && beta && xn, "smoe_gather_combine_ln: null pointer");
+  SMOE_REQUIRE((y_dtype == SMOE_F16 || y_dtype == SMOE_BF16) && (xn_dtype == SMOE_F16 || xn_dtype == SMOE_BF16),
+               "smoe_gather_combine_ln: y and xn must be f16 / bf16");
+  hipStream_t s = (hipStream_t)stream;
+  if (y_dtype == SMOE_F16) {
+    if (xn_dtype == SMOE_F16) return combine_ln_launch<f16, f16>(y, inv_pos, score, T, k, d, residual, out, gamma, beta, eps, xn, s);
+    return combine_ln_launch<f16, bf16_bits>(y, inv_pos, score, T, k, d, residual, out, gamma, beta, eps, xn, s);
+  }
+  if (xn_dtype == SMOE_F16) return combine_ln_launch<bf16_bits, f16>(y, inv_pos, score, T, k, d, residual, out, gamma, beta, eps, xn, s);
+  return combine_ln_launch<bf16_bits, bf16_bits>(y, inv_pos, score, T, k, d, residual, out, gamma, beta, eps, xn, s);
 }
 
 extern "C" int smoe_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {

@@ -15,7 +15,7 @@ struct GLnArgs {
 
 template <int NJ, bool LN, typename NT, int GATE>
 int launch_gate(const float* x, const GLnArgs& ln, const SkipGateArgs& ga, const float* wg, const float* bg, int64_t T, int d,
-                int E, int k, int32_t* rc, int32_t* rl, int64_t* idx, float* score, hipStream_t s) {
+                int E, int k, int32_t* rc, int32_t* rl, int64_t* idx, float* score, hipStream_t s, bool ws_zero) {
   constexpr int EB = 8;
   constexpr size_t smem = router16_smem<NJ, LN, EB, GATE>();
   const int64_t tok_per_block = (R16_THREADS / 64) * 4;
@@ -23,10 +23,12 @@ int launch_gate(const float* x, const GLnArgs& ln, const SkipGateArgs& ga, const
   constexpr int64_t max_wg = 768;
   const int64_t iters = (need + max_wg - 1) / max_wg;
   const int grid = (int)(need < 1 ? 1 : (need + iters - 1) / (iters < 1 ? 1 : iters));
-  hipError_t me = smoe_zero_words(rc, 4, s);
-  if (me != hipSuccess) {
-    smoe_set_error("smoe_gate_ln_router: counter clear failed: %s", hipGetErrorString(me));
-    return (int)me;
+  if (!ws_zero) {   // (a kept workspace is zero already: the redo pass clears its counter words on the way out)
+    hipError_t me = smoe_zero_words(rc, 4, s);
+    if (me != hipSuccess) {
+      smoe_set_error("smoe_gate_ln_router: counter clear failed: %s", hipGetErrorString(me));
+      return (int)me;
+    }
   }
   if (smem > 64 * 1024) {
     SMOE_ENSURE_SMEM(router16_kernel<float, NJ, 0, LN, NT, EB, GATE>);
@@ -46,12 +48,12 @@ int launch_gate(const float* x, const GLnArgs& ln, const SkipGateArgs& ga, const
 
 template <bool LN, typename NT, int GATE>
 int gate_by_d(const float* x, const GLnArgs& ln, const SkipGateArgs& ga, const float* wg, const float* bg, int64_t T, int d,
-              int E, int k, int32_t* rc, int32_t* rl, int64_t* idx, float* score, hipStream_t s) {
+              int E, int k, int32_t* rc, int32_t* rl, int64_t* idx, float* score, hipStream_t s, bool ws_zero) {
   switch (d) {
-    case 192: return launch_gate<3, LN, NT, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s);
-    case 384: return launch_gate<6, LN, NT, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s);
-    case 768: return launch_gate<12, LN, NT, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s);
-    case 1024: return launch_gate<16, LN, NT, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s);
+    case 192: return launch_gate<3, LN, NT, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s, ws_zero);
+    case 384: return launch_gate<6, LN, NT, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s, ws_zero);
+    case 768: return launch_gate<12, LN, NT, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s, ws_zero);
+    case 1024: return launch_gate<16, LN, NT, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s, ws_zero);
   }
   smoe_set_error("smoe_gate_ln_router: unsupported d=%d", d);
   return 1;
@@ -59,14 +61,15 @@ int gate_by_d(const float* x, const GLnArgs& ln, const SkipGateArgs& ga, const f
 
 template <int GATE>
 int gate_by_ln(bool with_ln, const float* x, const GLnArgs& ln, const SkipGateArgs& ga, const float* wg, const float* bg,
-               int64_t T, int d, int E, int k, int32_t* rc, int32_t* rl, int64_t* idx, float* score, hipStream_t s) {
+               int64_t T, int d, int E, int k, int32_t* rc, int32_t* rl, int64_t* idx, float* score, hipStream_t s,
+               bool ws_zero) {
   const bool bf = ln.xn16_dtype == SMOE_BF16;
   if (with_ln) {
-    if (bf) return gate_by_d<true, bf16_bits, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s);
-    return gate_by_d<true, f16, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s);
+    if (bf) return gate_by_d<true, bf16_bits, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s, ws_zero);
+    return gate_by_d<true, f16, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s, ws_zero);
   }
-  if (bf) return gate_by_d<false, bf16_bits, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s);
-  return gate_by_d<false, f16, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s);
+  if (bf) return gate_by_d<false, bf16_bits, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s, ws_zero);
+  return gate_by_d<false, f16, GATE>(x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s, ws_zero);
 }
 
 // out[c] = sum_j score_j (sum_h W2[e_j][c,h] gelu(b1[e_j][h]) + b2[e_j][c]);  (e_j, score_j) = the NaiveGate routing of an
@@ -137,8 +140,9 @@ extern "C" int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, cons
   GLnArgs ln{ln_gamma, ln_beta, ln_eps, xn16, xn16_dtype, xn32};
   SkipGateArgs ga{gate_w, gate_b, threshold, skip_count, mask, zero_out, E > 0 ? idx_plan : nullptr};
   hipStream_t s = (hipStream_t)stream;
-  if (E == 0) return gate_by_ln<2>(with_ln != 0, (const float*)x, ln, ga, nullptr, nullptr, T, d, 0, 1, rc, rl, nullptr, nullptr, s);
-  return gate_by_ln<1>(with_ln != 0, (const float*)x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s);
+  const bool ws_zero = (with_ln & 2) != 0;   // bit 1: the caller keeps the workspace's counter words zero between calls
+  if (E == 0) return gate_by_ln<2>((with_ln & 1) != 0, (const float*)x, ln, ga, nullptr, nullptr, T, d, 0, 1, rc, rl, nullptr, nullptr, s, ws_zero);
+  return gate_by_ln<1>((with_ln & 1) != 0, (const float*)x, ln, ga, wg, bg, T, d, E, k, rc, rl, idx, score, s, ws_zero);
 }
 
 extern "C" int smoe_zero_row_output(const float* bg, int E, int k, const float* w2, const float* b1, const float* b2, int d,

@@ -299,6 +299,17 @@ __global__ __launch_bounds__(ROUTER_THREADS, (MODE == 0 ? 4 : 2)) void router_ke
     }
     __builtin_amdgcn_wave_barrier();
   }
+  // the redo pass leaves the counter words zero for the next call (router16_kernel.h: the last workgroup to finish clears them)
+  if (MODE == 1 && redo_list) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int old = atomicAdd(&redo_count[1], 1);
+      if (old == (int)gridDim.x - 1) {
+        redo_count[1] = 0;
+        redo_count[0] = 0;
+      }
+    }
+  }
 }
 
 template <typename XT, int NCH>
@@ -315,16 +326,20 @@ int launch_router(const void* x, const float* wg, const float* bg, const float* 
 #define ROUTER_LAUNCH(WL, MODE, GRID, RC, RL)                                                                      \
   hipLaunchKernelGGL((router_kernel<XT, NCH, WL, MODE>), dim3(GRID), dim3(ROUTER_THREADS), smem, stream,          \
                      (const XT*)x, wg, bg, noise, T, d, E, k, gate_kind, RC, RL, idx, score, logits_out, probs)
+  const bool ws_zero = (force_f64 & 2) != 0;
+  force_f64 &= 1;
   if (force_f64) {
     if (w_lds) ROUTER_LAUNCH(true, 1, grid, nullptr, nullptr);
     else ROUTER_LAUNCH(false, 1, grid, nullptr, nullptr);
     SMOE_CHECK_LAUNCH("smoe_router_topk/f64");
     return 0;
   }
-  hipError_t me = smoe_zero_words(redo_count, 4, stream);
-  if (me != hipSuccess) {
-    smoe_set_error("smoe_router_topk: counter clear failed: %s", hipGetErrorString(me));
-    return (int)me;
+  if (!ws_zero) {
+    hipError_t me = smoe_zero_words(redo_count, 4, stream);
+    if (me != hipSuccess) {
+      smoe_set_error("smoe_router_topk: counter clear failed: %s", hipGetErrorString(me));
+      return (int)me;
+    }
   }
   if (w_lds) ROUTER_LAUNCH(true, 0, grid, redo_count, redo_list);
   else ROUTER_LAUNCH(false, 0, grid, redo_count, redo_list);
@@ -370,7 +385,7 @@ extern "C" int smoe_router_topk(const void* x, int x_dtype, const float* wg, con
                                 int64_t T, int d, int E, int k, int gate_kind, int64_t* idx, float* score,
                                 float* logits_out, float* probs, void* workspace, size_t workspace_bytes,
                                 void* stream) {
-  const int force_f64 = (gate_kind & 0x100) ? 1 : 0;
+  const int force_f64 = ((gate_kind & 0x100) ? 1 : 0) | ((gate_kind & 0x200) ? 2 : 0);   // bit 1: counter words kept zero by the caller
   gate_kind &= 0xff;
   if (T == 0) return 0;  // empty batch: nothing to route (zero-sized tensors have null data pointers)
   SMOE_REQUIRE(x && wg && idx && score, "smoe_router_topk: null pointer");

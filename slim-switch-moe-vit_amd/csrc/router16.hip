@@ -116,15 +116,19 @@ int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, 
                      dim3(MODE == 0 ? NTH : R16_THREADS), smem, s, (const XT*)x,                                      \
                      ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, noise, T, d, E, k, gate_kind, RC, RL, idx,   \
                      score, logits_out, probs, SkipGateArgs{})
+  const bool ws_zero = (force_f64 & 2) != 0;
+  force_f64 &= 1;
   if (force_f64 && !LN) {
     R16_LAUNCH(1, grid, nullptr, nullptr);
     SMOE_CHECK_LAUNCH("smoe_router_topk/f64");
     return 0;
   }
-  hipError_t me = smoe_zero_words(rc, 4, s);
-  if (me != hipSuccess) {
-    smoe_set_error("smoe_router_topk: counter clear failed: %s", hipGetErrorString(me));
-    return (int)me;
+  if (!ws_zero) {   // (a kept workspace is zero already: the redo pass clears its counter on the way out)
+    hipError_t me = smoe_zero_words(rc, 4, s);
+    if (me != hipSuccess) {
+      smoe_set_error("smoe_router_topk: counter clear failed: %s", hipGetErrorString(me));
+      return (int)me;
+    }
   }
   if (force_f64 && LN) {  // f64 mode still needs the normalised rows written: run the f32 pass for its stores first
     R16_LAUNCH(0, grid, rc, rl);
@@ -166,15 +170,19 @@ int launch_mt(const void* x, const LnArgs& ln, const float* wg, const float* bg,
   hipLaunchKernelGGL((router_mt_kernel<XT, MP, MODE, LN, NT, EB>), dim3(GRID), dim3(MT_THREADS), smem, s, (const XT*)x, \
                      ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, noise, T, E, k, gate_kind, RC, RL, idx, score,  \
                      logits_out, probs)
+  const bool ws_zero = (force_f64 & 2) != 0;
+  force_f64 &= 1;
   if (force_f64 && !LN) {
     MT_LAUNCH(1, grid, nullptr, nullptr);
     SMOE_CHECK_LAUNCH("smoe_router_topk/mt f64");
     return 0;
   }
-  hipError_t me = smoe_zero_words(rc, 4, s);
-  if (me != hipSuccess) {
-    smoe_set_error("smoe_router_topk: counter clear failed: %s", hipGetErrorString(me));
-    return (int)me;
+  if (!ws_zero) {
+    hipError_t me = smoe_zero_words(rc, 4, s);
+    if (me != hipSuccess) {
+      smoe_set_error("smoe_router_topk: counter clear failed: %s", hipGetErrorString(me));
+      return (int)me;
+    }
   }
   MT_LAUNCH(0, grid, rc, rl);
   SMOE_CHECK_LAUNCH("smoe_router_topk/mt f32");
@@ -272,7 +280,7 @@ extern "C" int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_g
                                    const float* noise, int64_t T, int d, int E, int k, int gate_kind, int64_t* idx,
                                    float* score, float* logits_out, float* probs, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-  const int force_f64 = (gate_kind & 0x100) ? 1 : 0;
+  const int force_f64 = ((gate_kind & 0x100) ? 1 : 0) | ((gate_kind & 0x200) ? 2 : 0);   // bit 1: the workspace's counter words are kept zero by the caller
   gate_kind &= 0xff;
   if (T == 0) return 0;
   SMOE_REQUIRE(x && wg && idx && score, "smoe_ln_router_topk: null pointer");

@@ -497,6 +497,19 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
       if (tid == 0 && *wg_cnt) atomicAdd(ga.skip_count, *wg_cnt);
     }
   }
+  // The redo pass leaves the counter words as it needs to find them next time: the workgroup that finishes last (every
+  // workgroup has read the count long before it finishes) clears the count and the arrival word, so a caller that keeps the
+  // workspace (ops: one per device and stream) never launches a clearing kernel (gate_kind | 0x200 says so).
+  if (MODE == 1 && redo_list) {
+    __syncthreads();
+    if (tid == 0) {
+      const int old = atomicAdd(&redo_count[1], 1);
+      if (old == (int)gridDim.x - 1) {
+        redo_count[1] = 0;
+        redo_count[0] = 0;
+      }
+    }
+  }
 }
 
 // dynamic LDS of one workgroup of router16_kernel

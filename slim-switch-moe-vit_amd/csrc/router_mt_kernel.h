@@ -415,6 +415,17 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
       xv[m][1] = xnx[m][1];
     }
   }
+  // the redo pass leaves the counter words zero for the next call (router16_kernel.h: the last workgroup to finish clears them)
+  if (MODE == 1 && redo_list) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int old = atomicAdd(&redo_count[1], 1);
+      if (old == (int)gridDim.x - 1) {
+        redo_count[1] = 0;
+        redo_count[0] = 0;
+      }
+    }
+  }
 }
 
 }  // namespace rmt

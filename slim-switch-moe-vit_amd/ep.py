@@ -204,48 +204,50 @@ def drain(gen):
 _starts_cache = StreamCache()
 
 
-_same_T_cache = {}
-
-
-def _all_ranks_hold(T: int, group, device) -> bool:
-    """True when every rank of the group brings the same number of rows T to this layer (the capacity, hence the slot
-    size of the static buffers, is a function of T).  One small all-gather the FIRST time a row count is seen (batch
-    sizes repeat: data-parallel loaders hand every rank the same batch size), cached afterwards; every rank computes
-    the same answer, so all of them take the same path."""
-    key = (id(group) if group is not None else 0, int(T))
-    hit = _same_T_cache.get(key)
-    if hit is None:
-        W = dist.get_world_size(group)
-        mine = torch.tensor([T], dtype=torch.int64, device=device if dist.get_backend(group) != "gloo" else "cpu")
-        got = [torch.empty_like(mine) for _ in range(W)]
-        dist.all_gather(got, mine, group=group)
-        hit = all(int(t) == T for t in got)
-        if len(_same_T_cache) > 256:
-            _same_T_cache.clear()
-        _same_T_cache[key] = hit
-    return hit
+def static_slot_tokens(mod, T: int, device) -> int:
+    """The row count T_slot the static exchange buffers of ``mod`` are sized for (every (source rank, expert) slot holds
+    capacity(T_slot) rows).  It must be the same on every rank, whatever each rank's own batch is, and it must be known
+    WITHOUT communication once training runs -- so it is agreed once: the first expert-parallel forward of the module
+    all-gathers the ranks' row counts and keeps the largest (every rank runs the same layers in the same order, so this
+    one collective matches); later batches must fit (a smaller batch leaves its slots emptier; a larger one raises: call
+    ``mod.ep_static_tokens = n`` on every rank before the first forward to size the buffers for the largest batch)."""
+    have = getattr(mod, "ep_static_tokens", None)
+    if have is None:
+        if mod.world_size > 1:
+            group = mod.moe_group
+            mine = torch.tensor([T], dtype=torch.int64, device=device if dist.get_backend(group) != "gloo" else "cpu")
+            got = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+            dist.all_gather(got, mine, group=group)
+            have = max(int(t) for t in got)
+        else:
+            have = T
+        mod.ep_static_tokens = have
+    if T > have:
+        if mod.world_size == 1:          # nobody to agree with: grow
+            mod.ep_static_tokens = have = T
+        else:
+            raise RuntimeError(f"expert-parallel static exchange: this rank brings {T} rows, the buffers were agreed for {have}; "
+                               "set `ep_static_tokens` on every rank's module to the largest local batch's row count")
+    return have
 
 
 def static_exchange_supported(mod, T: int, cap: int, cd, device) -> bool:
-    """The capacity-padded exchange needs the padded plan (E <= 64 groups of the fused plan kernel), the persistent GEMM's
-    separate row ranges (at most 63 row groups, 16-bit operands) and the same slot size on every rank (the same T);
-    SLIMMOE_EP_STATIC=0 switches it off (A/B)."""
+    """The capacity-padded exchange needs the padded plan (E <= 64 groups of the fused plan kernel) and the persistent GEMM's
+    separate row ranges (at most 63 row groups, 16-bit operands); SLIMMOE_EP_STATIC=0 switches it off (A/B)."""
     if os.environ.get("SLIMMOE_EP_STATIC", "1") == "0":
         return False
     E_tot = mod.gate.tot_expert
-    ok = (E_tot <= 63 and (-(-T * mod.top_k // 1024)) * E_tot <= 8192 and mod.gemm_variant in (9, 10, 11, 12, 13, 14)
-          and cd in (torch.float16, torch.bfloat16) and mod.d_model % 64 == 0 and mod.d_hidden % 64 == 0 and mod._fused_gelu
-          and not (mod._drop_p > 0 and mod.training))
-    if ok and mod.world_size > 1:
-        ok = _all_ranks_hold(T, mod.moe_group, device)
-    return ok
+    return (E_tot <= 63 and (-(-T * mod.top_k // 1024)) * E_tot <= 8192 and mod.gemm_variant in (9, 10, 11, 12, 13, 14)
+            and cd in (torch.float16, torch.bfloat16) and mod.d_model % 64 == 0 and mod.d_hidden % 64 == 0 and mod._fused_gelu
+            and not (mod._drop_p > 0 and mod.training))
 
 
-def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual):
+def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual, next_norm=None):
     """Expert-parallel forward of a CAPACITY gate on static buffers ("cfg 5 (capacity-bounded) can use
     fixed-size padded buffers -> no host sync"; Appendix B's `cap` note).  A rank keeps at most `cap` of its rows per
-    global expert, so every (source rank, expert) pair owns a fixed slot of `cap` rows: the send buffer is
-    [W, E_local, cap, d], both all-to-alls have EQUAL splits known without looking at the routing, and nothing of the layer
+    global expert, so every (source rank, expert) pair owns a fixed slot of `slot` >= `cap` rows (the capacity of the row
+    count all ranks agreed on, static_slot_tokens): the send buffer is [W, E_local, slot, d], both all-to-alls have EQUAL
+    splits known without looking at the routing, and nothing of the layer
     waits for the host -- the received counts stay on the device, where the grouped GEMM takes them as the end of each slot's
     row range (group_end) and never schedules a tile over padding.  Yields at the two exchanges (micro-batch pipelining)."""
     from . import ops
@@ -256,7 +258,8 @@ def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual):
     group = mod.moe_group
     T = x.shape[0]
     E_tot = g.tot_expert
-    counts, offsets, gend, pos_pad, inv_pos, pruned = ops.dispatch_plan_padded(idx, E_tot, cap)
+    slot = max(cap, g.capacity(static_slot_tokens(mod, T, x.device)))
+    counts, offsets, gend, pos_pad, inv_pos, pruned = ops.dispatch_plan_padded(idx, E_tot, cap, slot)
     mod.last_plan = (idx, score, counts, offsets, pos_pad, inv_pos)
     if isinstance(g, SwitchGate):
         from .autograd import switch_aux_loss
@@ -266,13 +269,13 @@ def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual):
     _a2a(recv_counts.view(W, E_local), counts.view(W, E_local), group=group)
     send = ops.scatter_rows(src, pos_pad, k, cd)                       # [E_tot * cap, d]; unused slots stay unwritten
     recv = torch.empty_like(send)
-    work = _a2a(recv, send, group=group, async_op=True)                # equal splits: E_local * cap rows per peer
+    work = _a2a(recv, send, group=group, async_op=True)                # equal splits: E_local * slot rows per peer
     yield                                                              # dispatch all-to-all in flight
     if work is not None:
         work.wait()
-    starts = _starts_cache.get((E_tot, cap, str(x.device)), 0,
-                               lambda: (torch.arange(E_tot, dtype=torch.int32, device=x.device) * cap))
-    ends = starts + recv_counts                                        # group l = (source rank, local expert): rows [l cap, l cap + n)
+    starts = _starts_cache.get((E_tot, slot, str(x.device)), 0,
+                               lambda: (torch.arange(E_tot, dtype=torch.int32, device=x.device) * slot))
+    ends = starts + recv_counts                                        # group l = (source rank, local expert): rows [l slot, l slot + n)
     gexp = _group_expert_ids(W, E_local, x.device)
     y = mod._experts_fwd(recv, starts, cd, out_dtype=cd, group_expert=gexp, group_end=ends)
     back = torch.empty_like(y)
@@ -280,9 +283,7 @@ def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual):
     yield                                                              # return all-to-all in flight
     if work2 is not None:
         work2.wait()
-    out = torch.empty((T, d), dtype=x.dtype, device=x.device)
-    ops.gather_combine(back, inv_pos, score, T, k, x.dtype, out=out, residual=residual)
-    return out
+    return _combine_maybe_ln(back, inv_pos, score, T, k, x, residual, next_norm)
 
 
 def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.Tensor] = None,
@@ -291,8 +292,22 @@ def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.T
     return drain(ep_forward_steps(mod, x, cd, residual, norm))
 
 
+def _combine_maybe_ln(back, inv_pos, score, T, k, x, residual, next_norm):
+    """The return side's last kernel: gather + combine (+ residual); with ``next_norm`` also that LayerNorm of the produced rows
+    (16 bit) in the same pass -> (out, xn) instead of out."""
+    from . import ops
+    d = x.shape[1]
+    if (next_norm is not None and x.dtype == torch.float32 and back.dtype in (torch.float16, torch.bfloat16) and k <= 4
+            and d % 8 == 0 and d <= 1024 and next_norm.bias is not None):
+        return ops.gather_combine_ln(back, inv_pos, score, T, k, residual, next_norm.weight.detach().float(),
+                                     next_norm.bias.detach().float(), next_norm.eps, torch.float16)
+    out = torch.empty((T, d), dtype=x.dtype, device=x.device)
+    ops.gather_combine(back, inv_pos, score, T, k, x.dtype, out=out, residual=residual)
+    return out
+
+
 def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.Tensor] = None,
-                     norm: Optional[torch.nn.Module] = None):
+                     norm: Optional[torch.nn.Module] = None, next_norm: Optional[torch.nn.Module] = None):
     """Generator form of the expert-parallel forward: ``yield``s wherever this micro-batch has to wait for something
     that is not GPU compute -- (1) the count matrices reaching the host, (2) the dispatch all-to-all, (3) the return
     all-to-all -- so that a caller interleaving several micro-batches (vit.VisionTransformer) keeps the compute
@@ -327,7 +342,7 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
     else:
         idx, score, _, probs = ops.router_topk(x, gw, gb, k, g.kind, noise, want_probs=isinstance(g, SwitchGate))
     if cap >= 1 and T > 0 and static_exchange_supported(mod, T, cap, cd, x.device):
-        return (yield from _ep_forward_static(mod, x, src, idx, score, probs, cap, cd, residual))
+        return (yield from _ep_forward_static(mod, x, src, idx, score, probs, cap, cd, residual, next_norm))
     plans = []
     for (t0, t1) in bounds:
         plans.append(ops.dispatch_plan(idx[t0:t1], g.tot_expert, cap))
@@ -369,6 +384,10 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
         returning.append((y, back, work2))
     yield                                                                # (3) return all-to-all in flight
     # stage C: gather + combine in sender order
+    if next_norm is not None and len(bounds) == 1 and T > 0 and returning[0][1].shape[0] > 0:
+        y, back, work2 = returning[0]
+        work2.wait()
+        return _combine_maybe_ln(back, plans[0][3], score, T, k, x, residual, next_norm)
     for c, (t0, t1) in enumerate(bounds):
         y, back, work2 = returning[c]
         work2.wait()

@@ -271,10 +271,12 @@ class FMoETransformerMLP(nn.Module):
     def ep_active(self) -> bool:
         return self.world_size > 1 or bool(getattr(self, "force_ep", False))
 
-    def forward_norm_add_steps(self, x: torch.Tensor, norm: nn.Module):
+    def forward_norm_add_steps(self, x: torch.Tensor, norm: nn.Module, next_norm: Optional[nn.Module] = None):
         """Generator form of ``forward_norm_add``: under expert parallelism it yields at the points where this
         micro-batch waits for the host or for an all-to-all (ep.ep_forward_steps) so that the caller can interleave
-        another micro-batch; otherwise it never yields.  The result is the generator's return value."""
+        another micro-batch; otherwise it never yields.  The result is the generator's return value.  With ``next_norm``
+        (the LayerNorm that reads the result next) the expert-parallel combine also produces ``next_norm(result)`` in
+        16 bit and the return value is the pair."""
         cd = self.compute_dtype or default_compute_dtype()
         g = self.gate
         ok = (x.is_cuda and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine
@@ -291,7 +293,9 @@ class FMoETransformerMLP(nn.Module):
             x2 = x.reshape(-1, self.d_model)
             if not x2.is_contiguous():
                 x2 = x2.contiguous()
-            out = yield from ep_forward_steps(self, x2, cd, residual=x2, norm=norm)
+            out = yield from ep_forward_steps(self, x2, cd, residual=x2, norm=norm, next_norm=next_norm)
+            if isinstance(out, tuple):      # (x + mlp(norm(x)), next_norm(of that)): the combine produced both
+                return out[0].reshape(x.shape), out[1].reshape(x.shape)
             return out.reshape(x.shape)
         shape = x.shape
         d, k = self.d_model, self.top_k

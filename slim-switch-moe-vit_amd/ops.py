@@ -95,6 +95,22 @@ def _chk(t: torch.Tensor, name: str, dtype=None, ndim=None, align: int = 16):
         raise RuntimeError(f"{name}: data pointer must be {align}-byte aligned")
 
 
+_router_ws = {}   # (device index, stream) -> uint8 workspace whose counter words are zero between calls
+WS_KEPT_ZERO = 0x200   # gate_kind flag (router entry points) / with_ln bit 1 (smoe_gate_ln_router): "the counter words are zero"
+
+
+def _router_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """The router's redo workspace (counter words + token list), one per device and stream, allocated ZEROED once: every
+    redo pass clears the counter words on its way out (csrc/router16_kernel.h), so no call has to launch a clearing kernel
+    in front of the router -- the caller says so with WS_KEPT_ZERO.  Keyed by the stream: two compute streams never share
+    counters; a captured graph replays on the tensor it captured."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _router_ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = _router_ws[key] = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+    return t
+
+
 def router_topk(x: torch.Tensor, wg: torch.Tensor, bg: Optional[torch.Tensor], k: int, gate_kind: int = GATE_NAIVE,
                 noise: Optional[torch.Tensor] = None, want_logits: bool = False, want_probs: bool = False,
                 force_f64: bool = False):
@@ -119,10 +135,11 @@ def router_topk(x: torch.Tensor, wg: torch.Tensor, bg: Optional[torch.Tensor], k
     probs = torch.empty((T, E), dtype=torch.float32, device=x.device) if want_probs else None
     lib = _lib.load()
     ws_bytes = lib.smoe_router_workspace_bytes(T)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    # (the all-f64 test mode runs its f32 pass without a redo pass behind it: it gets a scratch workspace and the clearing launch)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if force_f64 else _router_workspace(x.device, ws_bytes)
     with _timed("router", {"bytes": T * d * x.element_size()}, x):
         rc = lib.smoe_router_topk(_ptr(x), dtype_code(x.dtype), _ptr(wg), _ptr(bg), _ptr(noise), T, d, E, k,
-                                  gate_kind | (0x100 if force_f64 else 0), _ptr(idx), _ptr(score), _ptr(logits),
+                                  gate_kind | (0x100 if force_f64 else WS_KEPT_ZERO), _ptr(idx), _ptr(score), _ptr(logits),
                                   _ptr(probs), _ptr(ws), ws_bytes, _stream(x))
     _lib.check(rc, "smoe_router_topk")
     return idx, score, logits, probs
@@ -233,12 +250,12 @@ def ln_router_topk(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: 
     probs = torch.empty((T, E), dtype=torch.float32, device=dev) if want_probs else None
     lib = _lib.load()
     ws_bytes = lib.smoe_router_workspace_bytes(T)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if force_f64 else _router_workspace(dev, ws_bytes)
     nbytes = T * d * (x.element_size() + (2 if xn16 is not None else 0) + (4 if want_xn32 else 0))
     with _timed("ln_router", {"bytes": nbytes}, x):
         rc = lib.smoe_ln_router_topk(_ptr(x), dtype_code(x.dtype), _ptr(ln_weight), _ptr(ln_bias), float(eps), _ptr(xn16),
                                      dtype_code(xn16_dtype) if xn16_dtype is not None else F16, _ptr(xn32), _ptr(wg),
-                                     _ptr(bg), _ptr(noise), T, d, E, k, gate_kind | (0x100 if force_f64 else 0),
+                                     _ptr(bg), _ptr(noise), T, d, E, k, gate_kind | (0x100 if force_f64 else WS_KEPT_ZERO),
                                      _ptr(idx), _ptr(score), _ptr(logits), _ptr(probs), _ptr(ws), ws_bytes, _stream(x))
     _lib.check(rc, "smoe_ln_router_topk")
     return xn16, xn32, idx, score, logits, probs
@@ -295,10 +312,10 @@ def gate_ln_router(x: torch.Tensor, gate_w: torch.Tensor, gate_b: Optional[torch
         _chk(skip_count, "skip_count", torch.int32, align=4)
     lib = _lib.load()
     ws_bytes = lib.smoe_router_workspace_bytes(T)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws = _router_workspace(dev, ws_bytes)
     nbytes = T * d * (4 + (2 if xn16 is not None else 0) + (4 if xn32 is not None else 0))
     with _timed("gate_ln_router" if E else "gate_ln", {"bytes": nbytes}, x):
-        rc = lib.smoe_gate_ln_router(_ptr(x), F32, 1 if ln is not None else 0, _ptr(lg), _ptr(lb), float(eps), _ptr(gw),
+        rc = lib.smoe_gate_ln_router(_ptr(x), F32, (1 if ln is not None else 0) | 2, _ptr(lg), _ptr(lb), float(eps), _ptr(gw),
                                      _ptr(gb), _ptr(thr), _ptr(xn16),
                                      dtype_code(xn16_dtype) if xn16_dtype is not None else F16, _ptr(xn32),
                                      _ptr(zero_out), _ptr(wg), _ptr(bg), T, d, E, k, _ptr(idx), _ptr(idx_plan),
@@ -344,10 +361,12 @@ def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Op
     return counts, offsets, pos, inv_pos, pruned
 
 
-def dispatch_plan_padded(idx: torch.Tensor, E: int, capacity: int):
-    """The plan in the padded layout of a capacity gate's static exchange: expert e owns the slots [e * capacity, (e + 1) *
-    capacity).  Returns (counts i32 [E], offsets i32 [E+1] (compact prefix), group_end i32 [E] = e * capacity + counts[e],
-    pos_padded i64 [E * capacity] (-1 = unused slot), inv_pos i64 [n] (padded slot or -1), idx_pruned i64 [n])."""
+def dispatch_plan_padded(idx: torch.Tensor, E: int, capacity: int, slot_rows: Optional[int] = None):
+    """The plan in the padded layout of a capacity gate's static exchange: expert e owns the slots [e * slot_rows, (e + 1) *
+    slot_rows) (slot_rows >= capacity, default = capacity).  Returns (counts i32 [E], offsets i32 [E+1] (compact prefix),
+    group_end i32 [E] = e * slot_rows + counts[e], pos_padded i64 [E * slot_rows] (-1 = unused slot), inv_pos i64 [n] (padded
+    slot or -1), idx_pruned i64 [n])."""
+    slot_rows = int(capacity) if slot_rows is None else int(slot_rows)
     _chk(idx, "idx", torch.int64, align=8)
     flat = idx.reshape(-1)
     n = flat.numel()
@@ -358,11 +377,11 @@ def dispatch_plan_padded(idx: torch.Tensor, E: int, capacity: int):
     counts = torch.empty(E, dtype=torch.int32, device=dev)
     offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
     group_end = torch.empty(E, dtype=torch.int32, device=dev)
-    pos = torch.empty(E * int(capacity), dtype=torch.int64, device=dev)
+    pos = torch.empty(E * slot_rows, dtype=torch.int64, device=dev)
     inv_pos = torch.empty(n, dtype=torch.int64, device=dev)
     pruned = torch.empty(n, dtype=torch.int64, device=dev)
     with _timed("plan", {"bytes": n * 24}, idx):
-        rc = lib.smoe_dispatch_plan_padded(_ptr(flat), n, E, int(capacity), _ptr(counts), _ptr(offsets), _ptr(group_end),
+        rc = lib.smoe_dispatch_plan_padded(_ptr(flat), n, E, int(capacity), slot_rows, _ptr(counts), _ptr(offsets), _ptr(group_end),
                                            _ptr(pos), _ptr(inv_pos), _ptr(pruned), _ptr(ws), ws_bytes, _stream(idx))
     _lib.check(rc, "smoe_dispatch_plan_padded")
     return counts, offsets, group_end, pos, inv_pos, pruned
@@ -417,6 +436,28 @@ def gather_combine(y: torch.Tensor, inv_pos: torch.Tensor, score: torch.Tensor, 
                                      _ptr(out), dtype_code(out_dtype), _stream(y))
     _lib.check(rc, "smoe_gather_combine")
     return out
+
+
+def gather_combine_ln(y: torch.Tensor, inv_pos: torch.Tensor, score: torch.Tensor, T: int, k: int,
+                      residual: Optional[torch.Tensor], ln_weight: torch.Tensor, ln_bias: torch.Tensor, eps: float,
+                      xn_dtype: torch.dtype = torch.float16):
+    """(out f32 [T,d], xn [T,d] 16-bit): out[t] = residual[t] + sum_j score[t,j] y[inv_pos[t k + j]]; xn = LayerNorm(out)."""
+    _chk(y, "y", ndim=2)
+    _chk(inv_pos, "inv_pos", torch.int64, align=8)
+    _chk(score, "score", torch.float32, align=4)
+    _chk(ln_weight, "ln_weight", torch.float32, 1)
+    _chk(ln_bias, "ln_bias", torch.float32, 1)
+    d = y.shape[1]
+    if residual is not None:
+        _chk(residual, "residual", torch.float32, 2)
+    out = torch.empty((T, d), dtype=torch.float32, device=y.device)
+    xn = torch.empty((T, d), dtype=xn_dtype, device=y.device)
+    with _timed("combine_ln", {"bytes": T * d * (k * y.element_size() + 8 + 2)}, y):
+        rc = _lib.load().smoe_gather_combine_ln(_ptr(y), dtype_code(y.dtype), _ptr(inv_pos), _ptr(score), T, k, d, _ptr(residual),
+                                                _ptr(out), _ptr(ln_weight), _ptr(ln_bias), float(eps), _ptr(xn), dtype_code(xn_dtype),
+                                                _stream(y))
+    _lib.check(rc, "smoe_gather_combine_ln")
+    return out, xn
 
 
 def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], offsets: torch.Tensor,
@@ -674,6 +715,20 @@ def gate_wgrad(dl: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
     rc = lib.smoe_gate_wgrad(_ptr(dl), _ptr(x), dtype_code(x.dtype), T, E, C, _ptr(out), _ptr(ws), ws_bytes, _stream(x))
     _lib.check(rc, "smoe_gate_wgrad")
+    return out
+
+
+def gate_dgrad(dl: torch.Tensor, w: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    """dx [T, d] = dl [T, E] @ w [E, d] (f32 inputs): the router linear's input gradient as a streaming kernel."""
+    _chk(dl, "dl", torch.float32, 2, align=4)
+    _chk(w, "w", torch.float32, 2)
+    T, E = dl.shape
+    if w.shape[0] != E:
+        raise RuntimeError("gate_dgrad: dl / w disagree on E")
+    d = w.shape[1]
+    out = torch.empty((T, d), dtype=out_dtype, device=dl.device)
+    rc = _lib.load().smoe_gate_dgrad(_ptr(dl), _ptr(w), T, E, d, _ptr(out), dtype_code(out_dtype), _stream(dl))
+    _lib.check(rc, "smoe_gate_dgrad")
     return out
 
 

@@ -331,14 +331,19 @@ class Block(nn.Module):
         from .ep import drain
         return drain(self.forward_steps(x))
 
-    def forward_steps(self, x):
+    def forward_steps(self, x, xn1=None, next_norm=None):
         """The block as a generator (result = return value): it yields only inside an expert-parallel MoE ``mlp``, at
-        the points where this micro-batch waits for the host or an all-to-all (ep.ep_forward_steps)."""
+        the points where this micro-batch waits for the host or an all-to-all (ep.ep_forward_steps).
+
+        ``xn1``: ``norm1(x)`` already computed by the previous block's combine (see ``next_norm``).  ``next_norm``: the NEXT
+        block's ``norm1``; when this block's expert-parallel combine can produce that LayerNorm in the same pass
+        (smoe_gather_combine_ln) the result is ``(x, norm1_next(x))`` instead of ``x``."""
+        xin = xn1 if xn1 is not None else self._norm1(x)
         if isinstance(self.drop_path, nn.Identity) and x.is_contiguous() and isinstance(self.attn, Attention):
-            a, added = self.attn(self._norm1(x), residual=x)
+            a, added = self.attn(xin, residual=x)
             x = a if added else x + a
         else:
-            x = x + self.drop_path(self.attn(self._norm1(x)))
+            x = x + self.drop_path(self.attn(xin))
         from . import dense
         if (dense.autocast_half_training(x) and dense.layer_norm_supported(x, self.norm2)
                 and getattr(self.mlp, "forward_add", None) is not None):
@@ -352,7 +357,9 @@ class Block(nn.Module):
             steps = getattr(self.mlp, "forward_norm_add_steps", None)
             if steps is not None:
                 # x + mlp(norm2(x)): LN + router, scatter, combine + add all fused
-                return (yield from steps(x, self.norm2))
+                fuse_next = (next_norm is not None and _autocast_half_inference(x) and isinstance(next_norm, nn.LayerNorm)
+                             and next_norm.elementwise_affine and x.dtype == torch.float32 and x.shape[-1] in _LN_DIMS)
+                return (yield from steps(x, self.norm2, next_norm=next_norm if fuse_next else None))
             fused = getattr(self.mlp, "forward_add", None)
             if fused is not None:
                 return fused(self.norm2(x), x)  # x + mlp(norm2(x)), add fused into the MoE combine store
@@ -455,7 +462,11 @@ class VisionTransformer(nn.Module):
                 and x.shape[0] >= 2):
             return self._forward_features_two_streams(x)
         x = self._embed(x)
-        x = self.blocks(x)
+        if x.is_cuda and not torch.is_grad_enabled() and self._ep_blocks():
+            from .ep import drain
+            x = drain(self._blocks_steps(x))
+        else:
+            x = self.blocks(x)
         return self.pre_logits(self._final_norm_cls(x))
 
     def _final_norm_cls(self, x):
@@ -528,10 +539,27 @@ class VisionTransformer(nn.Module):
                 ep = True
         return n if ep else 1
 
+    def _blocks_steps(self, x):
+        """``self.blocks(x)`` as a generator, handing every block the next block's ``norm1`` so that an expert-parallel
+        combine can produce it on the way out (one pass over the residual stream less per layer)."""
+        blocks = list(self.blocks)
+        xn = None
+        for i, blk in enumerate(blocks):
+            if not hasattr(blk, "forward_steps") or "forward" in blk.__dict__:   # e.g. resmoe.forward_residule_moe
+                x, xn = blk(x), None
+                continue
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+            nn1 = nxt.norm1 if (nxt is not None and hasattr(nxt, "forward_steps") and "forward" not in nxt.__dict__) else None
+            r = yield from blk.forward_steps(x, xn1=xn, next_norm=nn1)
+            x, xn = r if isinstance(r, tuple) else (r, None)
+        return x
+
+    def _ep_blocks(self) -> bool:
+        return any(hasattr(getattr(b, "mlp", None), "ep_active") and b.mlp.ep_active() for b in self.blocks)
+
     def _features_steps(self, x):
         x = self._embed(x)
-        for blk in self.blocks:
-            x = yield from blk.forward_steps(x)
+        x = yield from self._blocks_steps(x)
         return self.pre_logits(self._final_norm_cls(x))
 
     def _forward_features_pipelined(self, x, n: int):

@@ -561,10 +561,18 @@ def _static_exchange_worker(rank, world, port, q):
             return float((got - ref).abs().max()), float((got_ln - ref_ln).abs().max()), int(full.last_plan[3][-1]) < T, \
                 bool(torch.equal(part.last_plan[2], full.last_plan[2]))
 
-        err, err_ln, dropped, same_counts = run(T)             # every rank brings the same T: static buffers
-        static_syncs = calls["n"]
-        err_r, err_ln_r, _, same_r = run(T + 11 * rank)        # ragged row counts: every rank falls back to the counted exchange
-        q.put((rank, max(err, err_r), max(err_ln, err_ln_r), static_syncs, int(dropped), same_counts and same_r, calls["n"]))
+        err, err_ln, dropped, same_counts = run(T + 13 * rank)  # ragged first batch: the slot size is agreed once (the largest)
+        err_r, err_ln_r, _, same_r = run(T - 7 * rank)          # later, smaller batches use the same buffers, no communication
+        too_big = False
+        if rank == world - 1:
+            try:
+                part.ep_static_tokens = 10                      # (a batch that does not fit raises instead of mis-matching)
+                part.forward_add(torch.zeros(64, d, device=DEV), torch.zeros(64, d, device=DEV))
+            except RuntimeError:
+                too_big = True
+        else:
+            too_big = True
+        q.put((rank, max(err, err_r), max(err_ln, err_ln_r), calls["n"], int(dropped), same_counts and same_r, too_big))
     finally:
         dist.destroy_process_group()
 
@@ -584,13 +592,12 @@ def test_static_capacity_padded_exchange_ranks_on_one_gpu(world):
     procs = [ctx.Process(target=_static_exchange_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    _join_or_kill(procs, 300)
+    _join_or_kill(procs, 120)
     got = sorted(q.get(timeout=10) for _ in range(world))
-    for rank, err, err_ln, host_syncs, dropped, same_counts, syncs_ragged in got:
-        print(f"rank {rank}/{world}: |ep - single| {err:.2e} (with LayerNorm fused {err_ln:.2e}), count read-backs {host_syncs} "
-              f"(static), {syncs_ragged} (after the ragged batch)")
+    for rank, err, err_ln, host_syncs, dropped, same_counts, too_big in got:
+        print(f"rank {rank}/{world}: |ep - single| {err:.2e} (with LayerNorm fused {err_ln:.2e}), count read-backs {host_syncs}")
         assert host_syncs == 0, "the static exchange must not read the counts back"
-        assert syncs_ragged == 2, "ragged row counts take the counted exchange (one read-back per forward)"
+        assert too_big, "a batch larger than the agreed slot size must raise"
         assert dropped == 1, "the test must exercise dropping"
         assert same_counts
         assert err <= 2e-3 and err_ln <= 2e-3, (rank, err, err_ln)

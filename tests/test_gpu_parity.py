@@ -237,7 +237,11 @@ def _gemm_ref(A, W, bias, offsets, gelu):
                                         ([700, 650, 600, 800, 655, 690, 710, 640], 768, 3072)])
 @pytest.mark.parametrize("cd,tol", [(torch.float32, 2e-5), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("gelu", [False, True])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+# variants in the default matrix: 0 reference (register-staged; the f32-exact mode), 1 small-M dense GEMMs (classifier head),
+# 4 one-workgroup-per-tile fallback (operands >= 4 GiB, > 63 groups), 9 production (persistent, direct-store epilogues),
+# 10 / 13 forced 320-row tile without / with the deep schedule, 14 persistent with the LDS-staged epilogue (A/B reference).
+# The other A/B structures (2, 3, 5-8, 11, 12) stay reachable through `variant=` but no longer run on every GPU test pass.
+@pytest.mark.parametrize("variant", [0, 1, 4, 9, 10, 13, 14])
 def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu, variant):
     if variant and (cd == torch.float32 or K % 64):
         pytest.skip("glds variants take 16-bit operands and K % 64 == 0")
@@ -258,11 +262,12 @@ def test_grouped_gemm_matches_fp64_reference(counts, K, N, cd, tol, gelu, varian
     assert torch.all(got[M:] == 7.0), "rows past the last expert must stay untouched"
 
 
-@pytest.mark.parametrize("variant", [0, 3, 5, 6, 7, 8, 10, 12])
+@pytest.mark.parametrize("variant", [0, 4, 9, 10, 14])
 def test_grouped_gemm_gelu_epilogue_over_the_whole_input_range(variant):
     """The fused GELU (a fitted sigmoid form without a range clamp in the MFMA kernels, erf form in variant 0) must
     follow the exact-erf GELU from the saturated negative side to the saturated positive side: pre-activations
-    from -6e4 to 6e4 are produced exactly (one non-zero product per output), f32 output."""
+    from -6e4 to 6e4 are produced exactly (one non-zero product per output), f32 output (variant 9: the direct f32
+    epilogue; 14: the staged one)."""
     vals = torch.tensor([0.0, 1e-3, 0.5, 1.0, 2.5, 4.0, 5.5, 7.9, 8.0, 8.1, 9.0, 12.0, 20.0, 64.0, 300.0, 4096.0,
                          60000.0], dtype=torch.float64)
     vals = torch.cat([vals, -vals])
@@ -282,11 +287,10 @@ def test_grouped_gemm_gelu_epilogue_over_the_whole_input_range(variant):
     assert (got[pre <= -9.0] == 0).all() and (got[pre >= 9.0] == pre[pre >= 9.0]).all()
 
 
-@pytest.mark.parametrize("variant,cd", [(0, torch.float32), (0, torch.float16), (1, torch.float16), (3, torch.float16),
-                                        (3, torch.bfloat16), (4, torch.float16), (4, torch.bfloat16), (5, torch.float16),
-                                        (5, torch.bfloat16), (6, torch.float16), (7, torch.float16), (8, torch.float16),
-                                        (8, torch.bfloat16), (9, torch.float16), (10, torch.float16), (10, torch.bfloat16),
-                                        (11, torch.float16), (12, torch.float16), (13, torch.float16), (13, torch.bfloat16)])
+@pytest.mark.parametrize("variant,cd", [(0, torch.float32), (0, torch.float16), (1, torch.float16), (4, torch.float16),
+                                        (4, torch.bfloat16), (9, torch.float16), (9, torch.bfloat16), (10, torch.float16),
+                                        (10, torch.bfloat16), (11, torch.float16), (13, torch.float16), (13, torch.bfloat16),
+                                        (14, torch.float16), (14, torch.bfloat16)])
 def test_grouped_gemm_fused_combine_row_map(variant, cd):
     E, K, N, T = 4, 128, 64, 1000
     g = _gen(3)
@@ -308,7 +312,7 @@ def test_grouped_gemm_fused_combine_row_map(variant, cd):
     assert (out.cpu().double() - ref).abs().max() < (2e-5 if cd == torch.float32 else 1e-4)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5, 6, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", [1, 4, 9, 10, 11, 12, 13, 14])
 def test_grouped_gemm_variants_are_race_free_and_agree_bitwise(variant):
     """The staged variants hand tiles between waves through LDS DMA + barriers; a missing wait shows up as
     rare wrong tiles.  Same inputs, 15 launches, ragged groups, long K: every launch must be bit-identical
@@ -757,7 +761,7 @@ def test_expert_parallel_data_path_simulated_ranks(W_ranks, E_local, k, d, h):
         _float_bar(got, ref, 1e-3)
 
 
-@pytest.mark.parametrize("variant", [9, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", [9, 10, 11, 12, 13, 14])
 def test_persistent_gemm_equals_one_workgroup_per_tile_kernel_bitwise(variant):
     """grouped_gemm_ps (one workgroup per CU walking tiles, the next tile's operands streaming under the epilogue) must
     reproduce grouped_gemm_pp256 bit for bit in every fused form it is used in: gathered A rows + bias + GELU (GEMM-1),
@@ -775,7 +779,7 @@ def test_persistent_gemm_equals_one_workgroup_per_tile_kernel_bitwise(variant):
     b2 = (torch.randn(E, d, generator=g) * 0.1).to(DEV)
     score = torch.rand(M, generator=g).to(DEV)
     res = torch.randn(M, d, generator=g).to(DEV)
-    base = {9: 4, 10: 5, 11: 6, 12: 7, 13: 8}[variant]     # the same tile height / schedule, one workgroup per tile
+    base = {9: 4, 10: 5, 11: 6, 12: 7, 13: 8, 14: 4}[variant]     # the same tile height / schedule, one workgroup per tile
     for _ in range(3):
         h_ref = ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_GELU, torch.float16, variant=base, a_gather=pos)
         h_ps = ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_GELU, torch.float16, variant=variant, a_gather=pos)
@@ -864,13 +868,15 @@ def test_cabi_exchange_context_world_of_one_and_ep_transport():
 # ------------------------------------------------------------------------- static (capacity-padded) exchange layout
 @pytest.mark.parametrize("n,E,cap", [(50432, 8, 6304), (3000, 8, 100), (777, 4, 1000), (36928, 32, 1154), (5000, 16, 1)])
 def test_dispatch_plan_padded_layout_bit_exact(n, E, cap):
-    """smoe_dispatch_plan_padded: expert e owns slots [e cap, (e + 1) cap); same kept set, same order inside an expert as the
-    compact plan (= the oracle's), unused slots -1, group_end = e cap + counts."""
+    """smoe_dispatch_plan_padded: expert e owns slots [e slot, (e + 1) slot), slot >= cap (the size every rank agreed on); same
+    kept set, same order inside an expert as the compact plan (= the oracle's), unused slots -1, group_end = e slot + counts."""
+    slot = cap + (n % 3) * 5
     rng = np.random.default_rng(n + E)
     idx = rng.integers(-1 if n % 2 else 0, E, size=n).astype(np.int64)
     idx[rng.random(n) < 0.3] = 0   # overloaded expert: drops
-    counts, offsets, gend, pos_pad, inv_pos, pruned = ops.dispatch_plan_padded(torch.from_numpy(idx).to(DEV), E, cap)
+    counts, offsets, gend, pos_pad, inv_pos, pruned = ops.dispatch_plan_padded(torch.from_numpy(idx).to(DEV), E, cap, slot)
     p = mo.dispatch_plan(idx, E, cap)
+    cap_keep, cap = cap, slot       # below: the layout's stride
     assert np.array_equal(counts.cpu().numpy(), p.counts) and np.array_equal(offsets.cpu().numpy(), p.offsets)
     assert np.array_equal(pruned.cpu().numpy(), p.idx_pruned)
     assert np.array_equal(gend.cpu().numpy(), np.arange(E) * cap + p.counts)

@@ -11,6 +11,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from slim_switch_moe_vit_amd import ops, _lib  # noqa: E402
+if os.environ.get("SMOE_LIB"):
+    _lib.LIB_PATH = os.environ["SMOE_LIB"]          # a diagnostic build (make DIAG=-DSMOE_DIAG) next to the production library
 
 
 def main():
@@ -55,6 +57,10 @@ def main():
              (4, 5): "pass0: rows + GELU + LDS write", (5, 6): "pass0: wait + barrier", (6, 7): "pass0: LDS read + stores",
              (8, 9): "last pass: vmcnt(0)", (9, 10): "last pass: barrier", (10, 11): "last pass: stores", (11, 12): "last barrier",
              (0, 12): "whole tile", (1, 12): "tile boundary (everything but the main loop)"}
+    if shape == "fc1" and variant != 14:   # the direct-store epilogue (16-bit output, no row map): stamps 5 and 12 only
+        names = {(0, 1): "main loop", (1, 2): "advance", (2, 3): "setup (gather addresses)", (3, 4): "issue kt0 + kt1",
+                 (4, 5): "direct epilogue: bias + GELU + pack + swaps + 20 stores issued", (5, 12): "wait for K-tile 0 + barrier",
+                 (0, 12): "whole tile", (1, 12): "tile boundary (everything but the main loop)"}
     sel = st[:, 1:6, :]          # tiles 1..5 of every workgroup (steady state, a next tile exists)
     ok = (sel[:, :, 12] > 0) & (sel[:, :, 0] > 0)
     print(f"variant {variant} {shape} grid={os.environ.get('SMOE_PS_GRID', 'all')} epi={os.environ.get('SMOE_EPI', 'default')}: {int(ok.sum())} tiles sampled; s_memtime = shader cycles (k = 1000 cycles)")
