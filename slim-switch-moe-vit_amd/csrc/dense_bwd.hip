@@ -119,14 +119,25 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const float*
   }
 }
 
-// dgamma_dbeta[c] (c < 2 d: dgamma then dbeta) = sum over the workgroups' partial rows, in workgroup order
+// dgamma_dbeta[c] (c < 2 d: dgamma then dbeta) = sum over the workgroups' partial rows.  A workgroup takes 32 columns (one
+// 128-byte segment of every partial row); thread (column c, slice r of 8) adds rows r, r + 8, ... in order, the eight slices meet
+// in LDS in slice order: deterministic, and the 6-MB table is read at streaming rate (the first version gave every column to one
+// thread walking all 1,024 rows: 226 us per call, 10 % of the training step).
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int n_rows, int two_d,
                                                                    float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= two_d) return;
+  __shared__ float red[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
   float s = 0.f;
-  for (int r = 0; r < n_rows; ++r) s += partial[(int64_t)r * two_d + c];
-  out[c] = s;
+  if (c < two_d)
+    for (int row = r; row < n_rows; row += 8) s += partial[(int64_t)row * two_d + c];
+  red[r][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (r == 0 && c < two_d) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][threadIdx.x & 31];
+    out[c] = t;
+  }
 }
 
 inline int lnb_grid(int64_t T) {
@@ -151,7 +162,7 @@ int lnb_launch(const float* x, const void* dy, const float* gamma, const float* 
   }
 #undef LNB
   SMOE_CHECK_LAUNCH("smoe_layernorm_bwd");
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, s, partial, grid, 2 * d, dgamma_dbeta);
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, s, partial, grid, 2 * d, dgamma_dbeta);
   SMOE_CHECK_LAUNCH("smoe_layernorm_bwd/reduce");
   return 0;
 }

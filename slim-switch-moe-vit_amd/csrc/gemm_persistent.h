@@ -435,7 +435,12 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       issue_bias(bias_par ^ 1);
       PS_STAMP(3);
       issue_kt0();    // its first K-tile streams into buffer 0 under the epilogue below
-      if constexpr (DIRECT) issue_kt1();   // nothing is staged through buffer 1: K-tile 1 may follow at once
+      // DIRECT: nothing is staged through buffer 1, so K-tile 1 could follow at once -- and did at first: the tile boundary then
+      // pushes 144 KB of operand pieces + 160 KB of output through the CU's vector-memory path in one burst, ~17 k cycles at
+      // ~20 B/clk whatever the epilogue's arithmetic costs (stamps: 2.1 k issue + 9.1 k epilogue + 6.6 k wait; the same sum with
+      // the GELU switched off).  The plain schedule issues K-tile 1 BEHIND the stores instead (below); the deep schedule's
+      // K-tile-1 pieces differ per wave (no exact count for the wait), so it keeps the early issue.
+      if constexpr (DIRECT && DEEP) issue_kt1();
     }
     PS_STAMP(4);
 
@@ -481,10 +486,21 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       }
       PS_STAMP(5);
       if (!more) break;
-      // the next tile's K-tile 0 (and 1) were issued BEFORE these stores: a counted wait that leaves only the stores in
-      // flight publishes them without waiting for a single store
-      if constexpr (AFR == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      // The next tile's K-tile 0 was issued BEFORE these stores: a counted wait that leaves the stores (and, on the plain
+      // schedule, the K-tile-1 pieces issued behind them: AFR + 4 per wave) in flight publishes it without waiting for a store.
+      if constexpr (DEEP) {
+        if constexpr (AFR == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else {
+        issue_kt1();
+        if (nk > 1) {
+          if constexpr (AFR == 5) asm volatile("s_waitcnt vmcnt(29)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        } else {
+          if constexpr (AFR == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        }
+      }
       PP_BARRIER();
       PS_STAMP(12);
       continue;

@@ -48,6 +48,37 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dw.to(weight.dtype) if weight is not None else None, db if ctx.needs_input_grad[2] else None, None, None
 
 
+class LayerNormResFn(torch.autograd.Function):
+    """``(norm(x), x)``: the pre-norm block reads x twice -- through the LayerNorm and over the residual connection that
+    bypasses it (models/vision_transformer.py:320-321) -- and autograd would add the two gradients with a kernel of its own
+    (a 155-MB read-modify-write per half block).  Returning the bypass from the same Function lets the LayerNorm backward add
+    the residual's gradient while it writes dx (smoe_layernorm_bwd's ``dres``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        ctx.eps = eps
+        ctx.save_for_backward(x, weight)
+        y = ops.layernorm(x, weight.detach().float() if weight is not None else None,
+                          bias.detach().float() if bias is not None else None, eps, out_dtype)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, weight = ctx.saved_tensors
+        if dy is None:      # only the bypass was used
+            return dres, None, None, None, None
+        if dres is not None and not (dres.dtype == torch.float32 and dres.is_contiguous()):
+            dres = dres.float().contiguous()
+        dx, dw, db = ops.layernorm_bwd(x, dy.contiguous(), weight.detach().float() if weight is not None else None, ctx.eps,
+                                       dres=dres)
+        return dx, dw.to(weight.dtype) if weight is not None else None, db if ctx.needs_input_grad[2] else None, None, None
+
+
+def layer_norm_res(x: torch.Tensor, norm: torch.nn.LayerNorm, out_dtype: torch.dtype):
+    """``(norm(x), x)`` with the two gradients of x summed inside the LayerNorm backward kernel."""
+    return LayerNormResFn.apply(x, norm.weight, norm.bias, norm.eps, out_dtype)
+
+
 def layer_norm(x: torch.Tensor, norm: torch.nn.LayerNorm, out_dtype: torch.dtype) -> torch.Tensor:
     """``norm(x)`` for contiguous f32 rows on the HIP LayerNorm with its HIP backward; output in ``out_dtype``."""
     return LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps, out_dtype)
@@ -88,9 +119,25 @@ class LinearFn(torch.autograd.Function):
                                   prof_name=ctx.name + "_dgrad")
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = ops.grouped_wgrad_rows(dy16, x16, offs)[0].reshape(weight.shape).to(weight.dtype)
+            # dW = dY^T X contracts over the M rows: with ONE row group the wgrad kernel's grid is only (N / 256) x (K / 256)
+            # tiles (27 for the qkv projection: a tenth of the chip, 700 us at ViT-B).  The rows are cut into S pseudo-groups
+            # so that S x tiles fill the CUs once; the S partial [N, K] products are summed in group order (deterministic).
+            S = _wgrad_splits(M, N, K, x16.device)
+            if S > 1:
+                offs_s = ctx.cache.split_offsets(M, S, x16.device)
+                dw = ops.grouped_wgrad_rows(dy16, x16, offs_s).sum(0)
+            else:
+                dw = ops.grouped_wgrad_rows(dy16, x16, offs)[0]
+            dw = dw.reshape(weight.shape).to(weight.dtype)
         db = ops.group_colsum(dy16, offs)[0] if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, dres, None, None, None
+
+
+def _wgrad_splits(M: int, N: int, K: int, device) -> int:
+    """Row slices for a single-group weight gradient: enough (<= 16, >= 2,048 rows each) for one round of workgroups."""
+    tiles = -(-N // 256) * -(-K // 256)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    return max(1, min(16, cus // max(tiles, 1), M // 2048))
 
 
 def linear_supported(x16: torch.Tensor, weight: torch.Tensor) -> bool:

@@ -109,6 +109,16 @@ class _HalfCache(StreamCache):
         return super().get(("offs", rows, str(device)), 0,
                            lambda: torch.tensor([0, rows], dtype=torch.int32, device=device))
 
+    def split_offsets(self, rows: int, parts: int, device) -> torch.Tensor:
+        """[0, r_1, ..., rows]: ``rows`` cut into ``parts`` near-equal slices (multiples of 64 rows): the pseudo-groups of a
+        single-group weight gradient (dense.LinearFn.backward)."""
+        def make():
+            step = -(-rows // parts)
+            step = -(-step // 64) * 64
+            cuts = [min(i * step, rows) for i in range(parts)] + [rows]
+            return torch.tensor(cuts, dtype=torch.int32, device=device)
+        return super().get(("split", rows, parts, str(device)), 0, make)
+
     def get(self, p: torch.Tensor) -> torch.Tensor:  # noqa: D102
         return super().get(id(p), param_version(p), lambda: p.detach().half())
 
@@ -338,17 +348,28 @@ class Block(nn.Module):
         ``xn1``: ``norm1(x)`` already computed by the previous block's combine (see ``next_norm``).  ``next_norm``: the NEXT
         block's ``norm1``; when this block's expert-parallel combine can produce that LayerNorm in the same pass
         (smoe_gather_combine_ln) the result is ``(x, norm1_next(x))`` instead of ``x``."""
-        xin = xn1 if xn1 is not None else self._norm1(x)
+        from . import dense
+        xres = x
+        if xn1 is not None:
+            xin = xn1
+        elif (dense.autocast_half_training(x) and x.requires_grad and dense.layer_norm_supported(x, self.norm1)
+              and isinstance(self.drop_path, nn.Identity)):
+            # training: LayerNorm and the bypass from one Function, so that its backward kernel also adds the bypass' gradient
+            xin, xres = dense.layer_norm_res(x, self.norm1, torch.float16)
+        else:
+            xin = self._norm1(x)
         if isinstance(self.drop_path, nn.Identity) and x.is_contiguous() and isinstance(self.attn, Attention):
-            a, added = self.attn(xin, residual=x)
-            x = a if added else x + a
+            a, added = self.attn(xin, residual=xres)
+            x = a if added else xres + a
         else:
             x = x + self.drop_path(self.attn(xin))
-        from . import dense
         if (dense.autocast_half_training(x) and dense.layer_norm_supported(x, self.norm2)
                 and getattr(self.mlp, "forward_add", None) is not None):
             # training: HIP LayerNorm (f32 rows: the router routes on them) forward and backward, then the MoE operator's
             # training path; without stochastic depth the residual add rides in the operator's combine
+            if isinstance(self.drop_path, nn.Identity) and x.requires_grad:
+                xn, xres2 = dense.layer_norm_res(x, self.norm2, torch.float32)
+                return self.mlp.forward_add(xn, xres2)
             xn = dense.layer_norm(x, self.norm2, torch.float32)
             if isinstance(self.drop_path, nn.Identity):
                 return self.mlp.forward_add(xn, x)
