@@ -194,6 +194,9 @@ int smoe_gather_combine_ln(const void* y, int y_dtype, const int64_t* inv_pos, c
  * [offsets[g], group_end[g]) and `offsets` holds G entries -- the padded [W, E_local, cap] receive buffer of a capacity
  * gate's static exchange, whose slots are only partly filled (smoe_dispatch_plan_padded); tiles past a group's end are
  * never scheduled, so the padding costs no MFMA work.
+ * out_rows = rows allocated in `out` (and `residual`): every row_map value must be below it.  0 = not stated (taken as
+ * m_rows_max without a row map); the persistent kernel then keeps flat addressing for f32 outputs instead of the
+ * buffer-addressed epilogue (whose descriptors need the bound: out_rows * N * 4 < 2 GiB).
  * Requires K*sizeof(ab) % 128 == 0 and N % 8 == 0.
  * variant: 9 = production choice (the 4 below as a PERSISTENT kernel, one workgroup per CU walking tiles, with the
  * direct-store epilogue for plain 16-bit outputs; 14 = the same with the LDS-staged epilogue everywhere, A/B reference;
@@ -206,7 +209,7 @@ int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int
                       const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
                       int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,
                       const void* residual, const int64_t* a_gather, int a_div,
-                      void* out, int out_dtype, int variant, const int32_t* group_end, void* stream);
+                      void* out, int64_t out_rows, int out_dtype, int variant, const int32_t* group_end, void* stream);
 
 /* smoe_grouped_gemm_gelu_keep: the first expert linear of the TRAINING forward (fmoe_cuda.linear_forward + the activation, whose
  * input autograd keeps): pre_out = A W^T + bias and out = gelu(pre_out), both [m_rows, N] in the operand dtype (f16 / bf16), from one

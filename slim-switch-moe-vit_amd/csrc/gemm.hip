@@ -1263,7 +1263,7 @@ template <typename AB, typename OT>
 int launch_variant(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets,
                    const int32_t* group_expert, int E, int64_t m_rows_max, int K, int N, int epilogue,
                    const int64_t* row_map, const float* row_scale, const void* residual, void* out, hipStream_t s,
-                   const int64_t* a_gather, int a_div, const int32_t* group_end) {
+                   const int64_t* a_gather, int a_div, const int32_t* group_end, int64_t out_rows) {
   if constexpr (sizeof(AB) == 2) {
     switch (variant) {
       case 1: return launch_glds<AB, OT, 128, 128, 2, 2, 2>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 8, s);
@@ -1300,11 +1300,11 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
         const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c320 = (double)((t320 + cus - 1) / cus) * 1.25;
         const bool deep = K >= 2048;
         if (c320 <= c256) {
-          if (deep) return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
-          return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
+          if (deep) return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
+          return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
         }
-        if (deep) return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
-        return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
+        if (deep) return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
+        return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
       }
       case 14: {  // as 9 with the LDS-staged epilogue everywhere (A/B reference of the direct-store epilogue)
         const int ntn = (N + 255) / 256;
@@ -1313,16 +1313,16 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
         const double c256 = (double)((t256 + cus - 1) / cus) * 1.0, c320 = (double)((t320 + cus - 1) / cus) * 1.25;
         const bool deep = K >= 2048;
         if (c320 <= c256) {
-          if (deep) return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, false);
-          return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, false);
+          if (deep) return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows, false);
+          return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows, false);
         }
-        if (deep) return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, false);
-        return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, false);
+        if (deep) return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows, false);
+        return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows, false);
       }
-      case 10: return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
-      case 11: return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
-      case 12: return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
-      case 13: return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end);
+      case 10: return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
+      case 11: return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
+      case 12: return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
+      case 13: return launch_ps<AB, OT, 5, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
       case 6: return launch_pp256<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
       case 7: return launch_pp256<AB, OT, 16, 4>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
       case 8: return launch_pp256<AB, OT, 16, 5>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div);
@@ -1345,11 +1345,11 @@ template <typename AB>
 int dispatch_out(int variant, const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert,
                  int E, int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
                  const void* residual, void* out, int out_dtype, hipStream_t s, const int64_t* a_gather, int a_div,
-                 const int32_t* group_end) {
+                 const int32_t* group_end, int64_t out_rows) {
   switch (out_dtype) {
-    case SMOE_F32: return launch_variant<AB, float>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div, group_end);
-    case SMOE_F16: return launch_variant<AB, f16>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div, group_end);
-    case SMOE_BF16: return launch_variant<AB, bf16_bits>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div, group_end);
+    case SMOE_F32: return launch_variant<AB, float>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div, group_end, out_rows);
+    case SMOE_F16: return launch_variant<AB, f16>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div, group_end, out_rows);
+    case SMOE_BF16: return launch_variant<AB, bf16_bits>(variant, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div, group_end, out_rows);
   }
   smoe_set_error("smoe_grouped_gemm: bad out_dtype %d", out_dtype);
   return 1;
@@ -1362,6 +1362,9 @@ extern "C" int smoe_diag_read_stamps(unsigned long long* host_out, size_t n) {
   const size_t cap = sizeof(unsigned long long) * 256 * 12 * 16;
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(smoe_diag_stamps), n * 8 < cap ? n * 8 : cap);
 }
+extern "C" int smoe_diag_set_flags(int flags) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(smoe_diag_flags), &flags, sizeof(flags));
+}
 extern "C" int smoe_diag_clear_stamps() {
   static unsigned long long z[256 * 12 * 16];
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(smoe_diag_stamps), z, sizeof(z));
@@ -1371,13 +1374,16 @@ extern "C" int smoe_diag_clear_stamps() {
 extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int32_t* offsets,
                                  const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
                                  int ab_dtype, int epilogue, const int64_t* row_map, const float* row_scale,
-                                 const void* residual, const int64_t* a_gather, int a_div, void* out, int out_dtype,
-                                 int variant, const int32_t* group_end, void* stream) {
+                                 const void* residual, const int64_t* a_gather, int a_div, void* out, int64_t out_rows,
+                                 int out_dtype, int variant, const int32_t* group_end, void* stream) {
   SMOE_REQUIRE(offsets && G >= 1 && G <= 65536, "smoe_grouped_gemm: bad G=%d / offsets", G);
   SMOE_REQUIRE(n_experts >= 1 && (group_expert || n_experts == G), "smoe_grouped_gemm: n_experts=%d != G=%d without a group map", n_experts, G);
   SMOE_REQUIRE(m_rows_max >= 0 && m_rows_max < (1ll << 31), "smoe_grouped_gemm: m_rows_max=%lld out of range",
                (long long)m_rows_max);
   SMOE_REQUIRE(K > 0 && N > 0, "smoe_grouped_gemm: bad K=%d N=%d", K, N);
+  SMOE_REQUIRE(out_rows >= 0 && (out_rows == 0 || row_map || out_rows >= m_rows_max),
+               "smoe_grouped_gemm: out_rows=%lld is smaller than m_rows_max=%lld", (long long)out_rows, (long long)m_rows_max);
+  if (out_rows == 0 && !row_map) out_rows = m_rows_max;   // without a row map row r is stored to out[r]
   SMOE_REQUIRE(epilogue == SMOE_EPI_NONE || epilogue == SMOE_EPI_GELU || epilogue == SMOE_EPI_GELU_GRAD,
                "smoe_grouped_gemm: bad epilogue %d", epilogue);
   SMOE_REQUIRE(epilogue != SMOE_EPI_GELU_GRAD || (residual && !row_map),
@@ -1402,9 +1408,9 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
                "operands under 4 GiB, K %% 64 == 0, at most 63 groups");
   hipStream_t s = (hipStream_t)stream;
   switch (ab_dtype) {
-    case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div, group_end);
-    case SMOE_F16: return dispatch_out<f16>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div, group_end);
-    case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div, group_end);
+    case SMOE_F32: return dispatch_out<float>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div, group_end, out_rows);
+    case SMOE_F16: return dispatch_out<f16>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div, group_end, out_rows);
+    case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div, group_end, out_rows);
   }
   return 1;
 }
@@ -1424,8 +1430,8 @@ extern "C" int smoe_grouped_gemm_gelu_keep(const void* A, const void* W, const f
   if (K % 64 != 0 || G > 63 || a_bytes >= (1ull << 32) || w_bytes >= (1ull << 32)) return -1;
   hipStream_t s = (hipStream_t)stream;
   if (ab_dtype == SMOE_F16)
-    return launch_ps<f16, f16, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1, nullptr);
-  return launch_ps<bf16_bits, bf16_bits, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1, nullptr);
+    return launch_ps<f16, f16, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1, nullptr, 0);
+  return launch_ps<bf16_bits, bf16_bits, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1, nullptr, 0);
 }
 
 // Weight gradients of a grouped linear (fmoe_cuda.linear_backward's grad_W):

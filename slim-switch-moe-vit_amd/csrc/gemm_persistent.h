@@ -18,9 +18,14 @@
 //
 // Main loop, LDS layout, fragment roles and both DMA schedules (DEEP = half-organised regions, two half-tiles in flight
 // across the tile boundary) are those of grouped_gemm_pp256; results are bit-identical to it (same accumulation order).
+#ifndef PS_STORE_AUX
+#define PS_STORE_AUX 0   // cache-policy bits of the direct epilogue's stores (diagnostic builds: -DPS_STORE_AUX=2 = nt)
+#endif
 #ifdef SMOE_DIAG
 // diagnostic build only: s_memtime stamps of wave 0 / lane 0 of every workgroup, 16 stamps per tile, first 12 tiles
 __device__ unsigned long long smoe_diag_stamps[256 * 12 * 16];
+__device__ int smoe_diag_flags;   // bit 0: the main loop issues no operand DMA (garbage results: what do MFMA + LDS reads alone cost?)
+#define PS_NODMA (diag_nodma)
 #define PS_STAMP(i)                                                                                              \
   do {                                                                                                           \
     if (wave == 0 && lane == 0 && tile_no < 12 && blockIdx.x < 256)                                              \
@@ -28,6 +33,7 @@ __device__ unsigned long long smoe_diag_stamps[256 * 12 * 16];
   } while (0)
 #else
 #define PS_STAMP(i) do {} while (0)
+#define PS_NODMA false
 #endif
 
 // KEEP (training forward of the first expert linear): the epilogue stores BOTH the pre-activation H = A W^T + b and gelu(H) --
@@ -46,7 +52,7 @@ __device__ unsigned long long smoe_diag_stamps[256 * 12 * 16];
 // (num_records = the rows of this tile that exist), so every wave issues the same number of stores and the wait that
 // publishes K-tile 0 can be a counted one (the stores are younger than the operand pieces).  Same arithmetic per element
 // as the staged epilogue: bit-identical results.
-template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false, bool DIRECT = false>
+template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false, bool DIRECT = false, bool BUF = false>
 __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
@@ -66,6 +72,9 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   const int wr = wave >> 2, wc = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
   const int nk = K / 64;
+#ifdef SMOE_DIAG
+  const bool diag_nodma = (__builtin_amdgcn_readfirstlane(smoe_diag_flags) & 1) != 0;
+#endif
 
   // ---- tile enumeration ------------------------------------------------------------------------------------------------
   // Row-group table in two registers (E <= 63 groups, the launcher checks): lane l holds offsets[l] and the number of
@@ -90,15 +99,29 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     if (group_expert && lane < E) t_ge = group_expert[lane];
   }
   const int total_mt = __builtin_amdgcn_readlane(t_tb, 63);
-  const int per_group = group_m * n_tiles_n;
-  const int n_tiles = ((total_mt + group_m - 1) / group_m) * per_group;
+  // Tile order.  group_m > 0: tiles are numbered in groups of group_m m-tiles x all n-tiles; in a round the 8 XCDs take 8
+  // neighbouring runs of per_xcd tiles and the whole grid moves on by G.
+  // group_m < 0 (-(quad | n_block << 8)): n-block-major numbering -- for each block of n_block n-tiles, for each quad of m-tiles,
+  // quad x n_block tiles -- and every XCD owns ONE CONTIGUOUS eighth of that order, walked per_xcd tiles at a time: round after
+  // round its workgroups meet the same n_block weight panels (until the expert changes) and only the A panels move on.
+  const bool xcd_runs = group_m < 0;
+  const int gm = xcd_runs ? ((-group_m) & 0xff) : group_m;
+  const int n_block = xcd_runs ? ((-group_m) >> 8) : n_tiles_n;          // the launcher makes it a divisor of n_tiles_n
+  const int per_group = gm * n_block;
+  const int tiles_per_nb = ((total_mt + gm - 1) / gm) * per_group;
+  const int n_tiles = tiles_per_nb * (n_tiles_n / n_block);
   const int G = gridDim.x, per_xcd = G >> 3;     // the launcher keeps G a multiple of 8
-  int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int xcd_share = (n_tiles + 7) >> 3;
+  const int t_step = xcd_runs ? per_xcd : G;
+  const int xcd_end = ((int)(blockIdx.x & 7) + 1) * xcd_share;
+  const int t_last = xcd_runs ? (xcd_end < n_tiles ? xcd_end : n_tiles) : n_tiles;
+  int tile = (blockIdx.x & 7) * (xcd_runs ? xcd_share : per_xcd) + (blockIdx.x >> 3);
   int e = 0, m0 = 0, m_end = 0, n0 = 0;          // the tile whose operands are being set up / streamed
   auto advance = [&]() -> bool {                 // first existing tile at or after `tile` on this workgroup's stride
-    while (tile < n_tiles) {
-      const int g = tile / per_group, rem = tile % per_group;
-      const int mt = g * group_m + rem % group_m;
+    while (tile < t_last) {
+      const int nb = tile / tiles_per_nb, r = tile % tiles_per_nb;
+      const int g = r / per_group, rem = r % per_group;
+      const int mt = g * gm + rem % gm;
       if (mt < total_mt) {
         // groups in front of or holding m-tile mt form a lane prefix; the owner is its last lane (an empty group has the
         // same prefix count as its successor, so it is never last)
@@ -107,10 +130,10 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
         m0 = __builtin_amdgcn_readlane(t_off, gi) + (mt - __builtin_amdgcn_readlane(t_tb, gi)) * TBM;
         m_end = __builtin_amdgcn_readlane(t_end, gi);
         e = __builtin_amdgcn_readlane(t_ge, gi);
-        n0 = (rem / group_m) * TBN;
+        n0 = (nb * n_block + rem / gm) * TBN;
         return true;
       }
-      tile += G;
+      tile += t_step;
     }
     return false;
   };
@@ -177,8 +200,11 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     }
   };
 #define PS_DMA(SRC, DST)                                                                             \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),             \
-                                   (__attribute__((address_space(3))) void*)(DST), 16, 0, 0)
+  do {                                                                                               \
+    if (!PS_NODMA)                                                                                   \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(SRC),         \
+                                       (__attribute__((address_space(3))) void*)(DST), 16, 0, 0);    \
+  } while (0)
   // non-DEEP pieces: "lo" (s0 == 0) = slots 0,1 (tile rows 0-127, read by wave group 0 only), "hi" = the rest
   auto dma_a = [&](int kt, int buf, int s0) {
     char* sa = smem + buf * STAGE;
@@ -338,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     PS_STAMP(0);
     // ---- look ahead: where this workgroup goes next; that tile's gather rows start streaming into LDS now ----------------
     const int ce = e, cm0 = m0, cm_end = m_end, cn0 = n0;   // the tile computed in this iteration
-    tile += G;
+    tile += t_step;
     const bool more = advance();                            // (e, m0, m_end, n0) = the next tile from here on
     if (more) prefetch_rows();
 #pragma unroll
@@ -480,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
           const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
           const u32x4 v = u32x4{s0[0], s1[0], s0[1], s1[1]};
           const uint32_t off = off0 + (uint32_t)(q * 64);
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)((q ? ok1 : ok0) ? off : OOR), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)((q ? ok1 : ok0) ? off : OOR), 0, PS_STORE_AUX);
         }
         off0 += row16;
       }
@@ -530,6 +556,16 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       omap[tid_e] = o;
       oscl[tid_e] = sc;
     }
+    // BUF: `out` / `residual` as raw buffers over the first 2 GiB (the launcher checks that every output row ends below that).
+    // Built per tile from opaque copies of the pointers: hoisted out of the tile loop, the two descriptors would sit in 8
+    // scalar registers through the main loop, which has none to spare -- the spills reach the vector registers.
+    constexpr uint32_t BUF_OOR = 0x80000000u;
+    OT* out_t = out;
+    const OT* res_t = resid ? resid : out;
+    if constexpr (BUF) asm volatile("" : "+s"(out_t), "+s"(res_t));
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_t, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<OT*>(res_t), 0, 0x7FFFFFFF, 0x00020000);
+    (void)rs_out; (void)rs_res; (void)BUF_OOR;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
       // (1) resolve this pass's output rows (32-bit: a row index, not an address) and their combine scales
@@ -556,6 +592,96 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
           orow[it] = omap[tr];
           oscale[it] = oscl[tr];
         }
+      }
+      if constexpr (BUF) {
+        // ---- buffer-addressed sweep: every residual load and output store is issued unconditionally (rows past the group
+        // and columns past N get an offset beyond num_records, which the hardware drops), so hipcc's wait counts are exact:
+        // the residual of a whole pass travels under the staging arithmetic and no use of it waits for a store.  With flat
+        // accesses under `if (row valid)` the counts collapse to vmcnt(0) -- every row iteration then waited for the previous
+        // iteration's stores to be acknowledged.  GEMM-2's tile boundary: 52.5 k -> 47.2 k cycles
+        // (profiles/r03_gemm2_tile_stamps.txt); the rest is the CU's store path (~10 B/clk, profiles/r03_mainloop_floor.txt).
+        uint32_t boff[ITS];
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) boff[it] = BUF_OOR;   // (defined on every path: see `res`)
+        auto resolve_off = [&]() {
+#pragma unroll
+          for (int it = 0; it < ITS; ++it)
+            boff[it] = orow[it] >= 0 ? (uint32_t)((orow[it] * N + cn0 + tcol * (16 / OB)) * OB) : BUF_OOR;
+        };
+        auto off_of = [&](int it, int j) -> int {
+          const int ncol = cn0 + (tcol + j * TPR) * (16 / OB);
+          return (int)(ncol < N ? boff[it] + (uint32_t)(j * TPR * 16) : BUF_OOR);
+        };
+        // The residual loads are issued whether there is a residual or not (without one: out of range, answered with zeros
+        // by the address unit): a branch around them would leave hipcc two paths to merge and its counts conservative again.
+        // Zero-initialised: left undefined on some path, the registers count as live around the whole tile loop and spill.
+        u32x4 res[ITS][CPT];
+#pragma unroll
+        for (int it = 0; it < ITS; ++it)
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) res[it][j] = u32x4{0u, 0u, 0u, 0u};
+        auto fetch = [&](int it0, int it1) {
+#pragma unroll
+          for (int it = it0; it < it1; ++it)
+#pragma unroll
+            for (int j = 0; j < CPT; ++j)
+              res[it][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         rs_res, resid ? off_of(it, j) : (int)BUF_OOR, 0, 0));
+        };
+        const bool rows_known = !(use_omap && p == 0);
+        if (rows_known) resolve_off();
+        // registers: the accumulators of the passes already stored are dead, 16 more per staged fragment row.  From pass 2
+        // on the whole pass's residual is requested before the staging arithmetic; pass 1 has room for the first row
+        // iteration only, pass 0 for none (the rest follows behind the staging, still in front of the barrier)
+        const int n_early = p >= 2 ? ITS : (p == 1 ? 1 : 0);   // rows_known whenever p > 0
+        fetch(0, n_early);
+#pragma unroll
+        for (int mm = 0; mm < MPP; ++mm) {
+          const int mi = p * MPP + mm;
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            f32x4 v = acc[mi][ni] + bv[ni];
+            const int nl = wc * TN + ni * 16 + fq * 4;
+            if (epilogue == SMOE_EPI_GELU) v = gelu_fast4(v);
+            OutPack<OT>::write4(cst + (wr * HALF + mm * 16 + fr) * C_STRIDE + nl * OB, v);
+          }
+        }
+        if (rows_known) fetch(n_early, ITS);
+        if (p == 0) PS_STAMP(5);
+        if (p == NPASS - 1) PS_STAMP(8);
+        if (p == NPASS - 1 && more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (p == NPASS - 1) PS_STAMP(9);
+        PP_BARRIER();
+        if (p == 0) PS_STAMP(6);
+        if (!rows_known) {
+#pragma unroll
+          for (int it = 0; it < ITS; ++it) {
+            const int r = trow + it * ROWS_PER_IT;
+            const int tr = (r / HALF) * TM + p * HALF + (r % HALF);
+            orow[it] = omap[tr];
+            oscale[it] = oscl[tr];
+          }
+          resolve_off();
+          fetch(0, ITS);
+        }
+        if (p == NPASS - 1) PS_STAMP(10);
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+          const int r = trow + it * ROWS_PER_IT;
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) {
+            u32x4 v = *reinterpret_cast<const u32x4*>(cst + r * C_STRIDE + (tcol + j * TPR) * 16);
+            if (row_map && row_scale) v = scale16<OT>(v, oscale[it]);
+            if (resid) v = add16<OT>(res[it][j], v);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, off_of(it, j), 0, 0);
+          }
+        }
+        if (p == 0) PS_STAMP(7);
+        if (p == NPASS - 1) PS_STAMP(11);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        continue;
       }
       auto res_fetch = [&](int it, u32x4 (&dst)[CPT]) {
 #pragma unroll
@@ -658,16 +784,31 @@ template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false>
 int launch_ps(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert, int E,
               int64_t m_rows_max, int K, int N, int epilogue, const int64_t* row_map, const float* row_scale,
               const void* residual, void* out, int group_m, hipStream_t s, const int64_t* a_gather, int a_div,
-              const int32_t* group_end, bool allow_direct = true) {
+              const int32_t* group_end, int64_t out_rows, bool allow_direct = true) {
   constexpr int TBM = 64 * AFR, TBN = 256;
   const int n_tiles_n = (N + TBN - 1) / TBN;
   const int64_t max_tiles = ((m_rows_max + TBM - 1) / TBM + E) * n_tiles_n;
   int grid = smoe_num_cus() & ~7;                 // one workgroup per CU (the LDS is full); a multiple of 8 (XCD slots)
   if (grid < 8) grid = 8;
   if (max_tiles < grid) grid = (int)((max_tiles + 7) & ~(int64_t)7);
+  // tile order (see the kernel): XCD-contiguous runs over blocks of n_block n-tiles.  Measured on the bench model's shapes
+  // (profiles/r03_tile_order_ab.txt back to back / r03_tile_order_ab_cold.txt behind a 512-MB write; strided order = 1.00):
+  // GEMM-1 (12 n-tiles) blocks of 4: 0.937 / 0.958, 6: 0.953 / 0.953, 12: 0.953 / 0.956, 3: 0.988 / 0.988; GEMM-2 (3 n-tiles)
+  // 3: 1.00 / 0.983; attention projection (3 n-tiles) 3: 0.979 / 1.00; qkv (9 n-tiles) 3: 1.005 / 1.023, 9: 1.008 / -.
+  // The L2 counters do not move (TCC hit 71.7 % under every order, profiles/r03_pmc_grouped_gemm.txt): the gain is in the
+  // main loop's operand latency (38.3 k cycles per GEMM-1 tile against 42.3 k), not in fetched bytes.
+  // Hence: all n-tiles when there are at most 4, else blocks of 4, 6 or 5 when they divide the n-tiles, else the strided order.
+  int n_block = 0;
+  if (n_tiles_n <= 4) n_block = n_tiles_n;
+  else if (n_tiles_n % 4 == 0) n_block = 4;
+  else if (n_tiles_n % 6 == 0) n_block = 6;
+  else if (n_tiles_n % 5 == 0) n_block = 5;
 #ifdef SMOE_DIAG
   if (const char* gcap = getenv("SMOE_PS_GRID")) grid = atoi(gcap) & ~7;   // diagnostic: fewer CUs (is a phase chip- or CU-bound?)
+  if (const char* ord = getenv("SMOE_PS_NBLOCK")) n_block = atoi(ord);    // diagnostic: 0 = the strided order, else the n-block width
+  if (n_block && n_tiles_n % n_block) n_block = 0;
 #endif
+  if (n_block) group_m = -(group_m | (n_block << 8));
   if constexpr (!KEEP && sizeof(OT) == 2) {
     // plain 16-bit outputs (GEMM-1, qkv, patch embedding): the epilogue that stores from the registers
     if (allow_direct && !row_map && !residual && (epilogue == SMOE_EPI_NONE || epilogue == SMOE_EPI_GELU) && (int64_t)N * TBM * 2 < (1ll << 31)) {
@@ -676,6 +817,18 @@ int launch_ps(const void* A, const void* W, const float* bias, const int32_t* of
                          (const AB*)W, bias, offsets, group_expert, E, K, N, epilogue, row_map, row_scale, (const OT*)residual,
                          (OT*)out, n_tiles_n, group_m, a_gather, a_div, (int)m_rows_max, group_end);
       SMOE_CHECK_LAUNCH("smoe_grouped_gemm/persistent-direct");
+      return 0;
+    }
+  }
+  if constexpr (!KEEP && sizeof(OT) == 4) {
+    // f32 outputs (GEMM-2 with the fused combine + residual, the attention projection): the staged epilogue whose residual
+    // loads and output stores go through buffer descriptors; every output row must end inside their 2 GiB
+    if (allow_direct && epilogue != SMOE_EPI_GELU_GRAD && out_rows > 0 && out_rows * (int64_t)N * 4 < (1ll << 31)) {
+      SMOE_ENSURE_SMEM(grouped_gemm_ps<AB, OT, AFR, DEEP, false, false, true>);
+      hipLaunchKernelGGL((grouped_gemm_ps<AB, OT, AFR, DEEP, false, false, true>), dim3(grid), dim3(512), 160 * 1024, s,
+                         (const AB*)A, (const AB*)W, bias, offsets, group_expert, E, K, N, epilogue, row_map, row_scale,
+                         (const OT*)residual, (OT*)out, n_tiles_n, group_m, a_gather, a_div, (int)m_rows_max, group_end);
+      SMOE_CHECK_LAUNCH("smoe_grouped_gemm/persistent-buffer");
       return 0;
     }
   }

@@ -521,8 +521,8 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     with _timed(prof_name, {"flops": 2.0 * rows * K * N, "K": K, "N": N, "epilogue": epilogue}, A):
         rc = lib.smoe_grouped_gemm(_ptr(A), _ptr(W), _ptr(bias), _ptr(offsets), _ptr(group_expert), G, E, M, K, N,
                                    dtype_code(A.dtype), epilogue, _ptr(row_map), _ptr(row_scale), _ptr(residual),
-                                   _ptr(a_gather), a_div, _ptr(out), dtype_code(out_dtype), variant, _ptr(group_end),
-                                   _stream(A))
+                                   _ptr(a_gather), a_div, _ptr(out), out.shape[0], dtype_code(out_dtype), variant,
+                                   _ptr(group_end), _stream(A))
     _lib.check(rc, "smoe_grouped_gemm")
     return out
 

@@ -45,7 +45,7 @@ def test_argument_validation_errors_come_back_as_messages():
     # null pointers / bad sizes are rejected before any launch (safe without a GPU)
     rc = lib.smoe_router_topk(None, 0, None, None, None, 4, 12, 2, 1, 0, None, None, None, None, None, 0, None)
     assert rc != 0 and b"null" in lib.smoe_last_error()
-    rc = lib.smoe_grouped_gemm(None, None, None, None, None, 0, 0, 8, 64, 64, 1, 0, None, None, None, None, 1, None, 1, 0, None, None)
+    rc = lib.smoe_grouped_gemm(None, None, None, None, None, 0, 0, 8, 64, 64, 1, 0, None, None, None, None, 1, None, 0, 1, 0, None, None)
     assert rc != 0 and lib.smoe_last_error()
     with pytest.raises(_lib.SlimMoEError):
         _lib.check(rc, "smoe_grouped_gemm")

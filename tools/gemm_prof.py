@@ -8,7 +8,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from slim_switch_moe_vit_amd import ops  # noqa: E402
+from slim_switch_moe_vit_amd import ops, _lib  # noqa: E402
+if os.environ.get("SMOE_LIB"):
+    _lib.LIB_PATH = os.environ["SMOE_LIB"]          # a diagnostic build (make DIAG=-DSMOE_DIAG): SMOE_PS_NBLOCK / SMOE_PS_GRID apply
 
 
 def main():

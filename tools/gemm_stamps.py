@@ -42,6 +42,10 @@ def main():
     lib = _lib.load()
     rd = lib.__getattr__("smoe_diag_read_stamps"); rd.restype = ctypes.c_int; rd.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     clr = lib.__getattr__("smoe_diag_clear_stamps"); clr.restype = ctypes.c_int; clr.argtypes = []
+    if os.environ.get("SMOE_DIAG_FLAGS"):   # bit 0: no operand DMA in the main loop (MFMA + LDS reads alone; results are garbage)
+        sf = lib.__getattr__("smoe_diag_set_flags"); sf.restype = ctypes.c_int; sf.argtypes = [ctypes.c_int]
+        assert sf(int(os.environ["SMOE_DIAG_FLAGS"])) == 0
+        print("SMOE_DIAG_FLAGS =", os.environ["SMOE_DIAG_FLAGS"])
     for _ in range(200):   # let the clock settle under load
         run()
     torch.cuda.synchronize()
