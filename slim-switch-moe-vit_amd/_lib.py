@@ -10,7 +10,9 @@ import os
 import torch  # noqa: F401  (must be imported first: the library resolves libamdhip64.so.7 to torch's runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslimmoe_hip.so")
+# SLIMMOE_LIB: another build of the same sources (a diagnostic build, `make DIAG=-DSMOE_DIAG`, whose environment switches the
+# tools under tools/ use); the ABI and symbol checks below apply to it all the same
+LIB_PATH = os.environ.get("SLIMMOE_LIB") or os.path.join(_HERE, "libslimmoe_hip.so")
 ABI_VERSION = 20
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t

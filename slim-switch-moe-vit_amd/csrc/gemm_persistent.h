@@ -791,18 +791,15 @@ int launch_ps(const void* A, const void* W, const float* bias, const int32_t* of
   int grid = smoe_num_cus() & ~7;                 // one workgroup per CU (the LDS is full); a multiple of 8 (XCD slots)
   if (grid < 8) grid = 8;
   if (max_tiles < grid) grid = (int)((max_tiles + 7) & ~(int64_t)7);
-  // tile order (see the kernel): XCD-contiguous runs over blocks of n_block n-tiles.  Measured on the bench model's shapes
-  // (profiles/r03_tile_order_ab.txt back to back / r03_tile_order_ab_cold.txt behind a 512-MB write; strided order = 1.00):
-  // GEMM-1 (12 n-tiles) blocks of 4: 0.937 / 0.958, 6: 0.953 / 0.953, 12: 0.953 / 0.956, 3: 0.988 / 0.988; GEMM-2 (3 n-tiles)
-  // 3: 1.00 / 0.983; attention projection (3 n-tiles) 3: 0.979 / 1.00; qkv (9 n-tiles) 3: 1.005 / 1.023, 9: 1.008 / -.
-  // The L2 counters do not move (TCC hit 71.7 % under every order, profiles/r03_pmc_grouped_gemm.txt): the gain is in the
-  // main loop's operand latency (38.3 k cycles per GEMM-1 tile against 42.3 k), not in fetched bytes.
-  // Hence: all n-tiles when there are at most 4, else blocks of 4, 6 or 5 when they divide the n-tiles, else the strided order.
-  int n_block = 0;
-  if (n_tiles_n <= 4) n_block = n_tiles_n;
-  else if (n_tiles_n % 4 == 0) n_block = 4;
-  else if (n_tiles_n % 6 == 0) n_block = 6;
-  else if (n_tiles_n % 5 == 0) n_block = 5;
+  // tile order (see the kernel): XCD-contiguous runs over blocks of n_block n-tiles.  Measured on the bench model's shapes,
+  // strided order = 1.00.  Alone, back to back / behind a 512-MB write (profiles/r03_tile_order_ab.txt, _cold.txt): GEMM-1
+  // (12 n-tiles) blocks of 4: 0.937 / 0.958, 6: 0.953 / 0.953, 12: 0.953 / 0.956; GEMM-2 (3 n-tiles) 3: 1.00 / 0.983;
+  // attention projection (3 n-tiles) 3: 0.979 / 1.00; qkv (9 n-tiles) 3: 1.005 / 1.023.  INSIDE the model (bench.py's
+  // per-kernel times, both orders on one box, profiles/r03_bench_order_ab.txt): projection 0.969, GEMM-2 0.993, but GEMM-1
+  // 1.012 -- its A rows were written by the LayerNorm + router kernel a moment ago and come from the Infinity Cache either
+  // way; what the isolated runs measured was the cold A stream.  The L2 counters do not move under any order (TCC hit
+  // 71.7 %, profiles/r03_pmc_grouped_gemm.txt).  Hence: one block of all n-tiles when there are at most 4, else strided.
+  int n_block = n_tiles_n <= 4 ? n_tiles_n : 0;
 #ifdef SMOE_DIAG
   if (const char* gcap = getenv("SMOE_PS_GRID")) grid = atoi(gcap) & ~7;   // diagnostic: fewer CUs (is a phase chip- or CU-bound?)
   if (const char* ord = getenv("SMOE_PS_NBLOCK")) n_block = atoi(ord);    // diagnostic: 0 = the strided order, else the n-block width

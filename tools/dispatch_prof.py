@@ -23,6 +23,7 @@ def main():
     g, b = torch.ones(d, device=dev), torch.zeros(d, device=dev)
     gw, gb, thr = torch.randn(1, d, device=dev) * 0.05, torch.zeros(1, device=dev), torch.tensor(0.6, device=dev)
     cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    dl = torch.randn(T, E, device=dev)
     for _ in range(iters):
         idx, score, _, _ = ops.router_topk(x, wg, bg, 1)
         xn16, _, idx, score, _, _ = ops.ln_router_topk(x, g, b, 1e-6, wg, bg, 1)
@@ -37,6 +38,13 @@ def main():
         ops.gate_ln_router(x, gw, gb, thr, ln=(g, b, 1e-6), wg=wg, bg=bg, k=1, xn16_dtype=torch.float16, want_xn32=True,
                            skip_count=cnt)
         ops.layernorm(x, g, b, 1e-6, torch.float16)
+        # round 3: combine + residual + the next LayerNorm in one pass (expert-parallel return path), the padded plan of the
+        # static exchange, the backward-side streaming kernels
+        ops.gather_combine_ln(buf, inv_pos, score, T, 1, x, g, b, 1e-6, torch.float16)
+        ops.dispatch_plan_padded(idx, E, T // E + 64)
+        dy16 = buf if buf.shape[0] == T else buf[:T]
+        ops.layernorm_bwd(x, dy16, g, 1e-6, dres=x)
+        ops.gate_dgrad(dl, wg, torch.float32)
     torch.cuda.synchronize()
     print("done", float(out.sum()), float(out2.sum()))
 
