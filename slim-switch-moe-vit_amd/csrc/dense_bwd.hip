@@ -123,20 +123,26 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const float*
 // 128-byte segment of every partial row); thread (column c, slice r of 8) adds rows r, r + 8, ... in order, the eight slices meet
 // in LDS in slice order: deterministic, and the 6-MB table is read at streaming rate (the first version gave every column to one
 // thread walking all 1,024 rows: 226 us per call, 10 % of the training step).
+// Two stages (LNB_STAGE1 = 16 row groups, then one): with the whole table behind 48 workgroups the second version still took 38 us
+// per call -- 128 dependent-latency trips per thread on a fifth of the chip (profiles/r03_dispatch_kernels.md).
+constexpr int LNB_STAGE1 = 16;
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ partial, int n_rows, int two_d,
-                                                                   float* __restrict__ out) {
+                                                                   int rows_per_block, float* __restrict__ out) {
   __shared__ float red[8][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
+  const int row0 = blockIdx.y * rows_per_block;
+  int row1 = row0 + rows_per_block;
+  if (row1 > n_rows) row1 = n_rows;
   float s = 0.f;
   if (c < two_d)
-    for (int row = r; row < n_rows; row += 8) s += partial[(int64_t)row * two_d + c];
+    for (int row = row0 + r; row < row1; row += 8) s += partial[(int64_t)row * two_d + c];
   red[r][threadIdx.x & 31] = s;
   __syncthreads();
   if (r == 0 && c < two_d) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t += red[i][threadIdx.x & 31];
-    out[c] = t;
+    out[(int64_t)blockIdx.y * two_d + c] = t;
   }
 }
 
@@ -162,7 +168,12 @@ int lnb_launch(const float* x, const void* dy, const float* gamma, const float* 
   }
 #undef LNB
   SMOE_CHECK_LAUNCH("smoe_layernorm_bwd");
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * d + 31) / 32), dim3(256), 0, s, partial, grid, 2 * d, dgamma_dbeta);
+  float* stage1 = partial + (size_t)grid * 2 * d;        // [LNB_STAGE1][2 d] behind the per-workgroup rows
+  const int rpb = (grid + LNB_STAGE1 - 1) / LNB_STAGE1;
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * d + 31) / 32, LNB_STAGE1), dim3(256), 0, s, partial, grid, 2 * d, rpb,
+                     stage1);
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * d + 31) / 32, 1), dim3(256), 0, s, stage1, LNB_STAGE1, 2 * d, LNB_STAGE1,
+                     dgamma_dbeta);
   SMOE_CHECK_LAUNCH("smoe_layernorm_bwd/reduce");
   return 0;
 }
@@ -171,32 +182,74 @@ int lnb_launch(const float* x, const void* dy, const float* gamma, const float* 
 // The backward of the gate's nn.Linear w.r.t. its input (models/resmoe_flop_hook.py:7 names that layer): K = E <= 64 is far too
 // thin for a matrix-core GEMM -- the kernel is the [T, d] store.  One thread = 4 consecutive columns of one row; the E weights of
 // those columns come from L1 (W is E x d floats, shared by every row), the row's E gradients are wave-broadcast loads.
-template <typename OT>
+template <typename OT> __device__ __forceinline__ void gd_store4(OT* dst, const f32x4& acc) {
+  if constexpr (std::is_same<OT, float>::value) {
+    *reinterpret_cast<f32x4*>(dst) = acc;
+  } else if constexpr (std::is_same<OT, f16>::value) {
+    f16x4 v; v[0] = (f16)acc[0]; v[1] = (f16)acc[1]; v[2] = (f16)acc[2]; v[3] = (f16)acc[3];
+    *reinterpret_cast<f16x4*>(dst) = v;
+  } else {
+    s16x4 v; v[0] = (short)f32_to_bf16(acc[0]); v[1] = (short)f32_to_bf16(acc[1]); v[2] = (short)f32_to_bf16(acc[2]); v[3] = (short)f32_to_bf16(acc[3]);
+    *reinterpret_cast<s16x4*>(dst) = v;
+  }
+}
+// A thread owns 4 columns and keeps their EB weights in registers; the workgroup walks rows, so a row's gradients are
+// workgroup-uniform (scalar loads) and the loop body is EB x 4 FMAs and one 16-byte store: the kernel is its [T, d] store.
+// (The first version re-read the weights from L1 for every row -- 8 vector loads per store, 69 us for the 155-MB store at
+// ViT-B -- and paid a 64-bit division per element; profiles/r03_dispatch_kernels.md.)
+template <typename OT, int EB>
 __global__ __launch_bounds__(256) void gate_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w, int64_t T, int E,
                                                           int d, OT* __restrict__ out) {
   const int nchunk = d >> 2;
-  const int64_t total = T * (int64_t)nchunk;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t t = i / nchunk;
-    const int c = (int)(i - t * nchunk) * 4;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* dr = dl + t * E;
-    for (int e = 0; e < E; ++e) {
-      const float g = dr[e];
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (int64_t)e * d + c);
-      acc[0] = fmaf(g, wv[0], acc[0]); acc[1] = fmaf(g, wv[1], acc[1]); acc[2] = fmaf(g, wv[2], acc[2]); acc[3] = fmaf(g, wv[3], acc[3]);
-    }
-    OT* dst = out + t * (int64_t)d + c;
-    if constexpr (std::is_same<OT, float>::value) {
-      *reinterpret_cast<f32x4*>(dst) = acc;
-    } else if constexpr (std::is_same<OT, f16>::value) {
-      f16x4 v; v[0] = (f16)acc[0]; v[1] = (f16)acc[1]; v[2] = (f16)acc[2]; v[3] = (f16)acc[3];
-      *reinterpret_cast<f16x4*>(dst) = v;
-    } else {
-      s16x4 v; v[0] = (short)f32_to_bf16(acc[0]); v[1] = (short)f32_to_bf16(acc[1]); v[2] = (short)f32_to_bf16(acc[2]); v[3] = (short)f32_to_bf16(acc[3]);
-      *reinterpret_cast<s16x4*>(dst) = v;
+  for (int cb = 0; cb < nchunk; cb += blockDim.x) {        // (one trip for d <= 1024)
+    const int c = (cb + (int)threadIdx.x) * 4;
+    const bool live = c < d;
+    f32x4 wv[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e)
+      wv[e] = (live && e < E) ? *reinterpret_cast<const f32x4*>(w + (int64_t)e * d + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
+      const float* dr = dl + t * E;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        const float g = e < E ? dr[e] : 0.f;
+        acc[0] = fmaf(g, wv[e][0], acc[0]); acc[1] = fmaf(g, wv[e][1], acc[1]);
+        acc[2] = fmaf(g, wv[e][2], acc[2]); acc[3] = fmaf(g, wv[e][3], acc[3]);
+      }
+      if (live) gd_store4<OT>(out + t * (int64_t)d + c, acc);
     }
   }
+}
+// any E: weights from L1 per row (rows per workgroup as above, no per-element division)
+template <typename OT>
+__global__ __launch_bounds__(256) void gate_dgrad_any_kernel(const float* __restrict__ dl, const float* __restrict__ w, int64_t T,
+                                                              int E, int d, OT* __restrict__ out) {
+  const int nchunk = d >> 2;
+  for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
+    const float* dr = dl + t * E;
+    for (int ci = threadIdx.x; ci < nchunk; ci += blockDim.x) {
+      const int c = ci * 4;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < E; ++e) {
+        const float g = dr[e];
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (int64_t)e * d + c);
+        acc[0] = fmaf(g, wv[0], acc[0]); acc[1] = fmaf(g, wv[1], acc[1]); acc[2] = fmaf(g, wv[2], acc[2]); acc[3] = fmaf(g, wv[3], acc[3]);
+      }
+      gd_store4<OT>(out + t * (int64_t)d + c, acc);
+    }
+  }
+}
+
+template <typename OT>
+void gate_dgrad_launch(const float* dl, const float* w, int64_t T, int E, int d, OT* out, hipStream_t s) {
+  const int nchunk = d / 4;
+  int threads = ((nchunk < 256 ? nchunk : 256) + 63) / 64 * 64;
+  int64_t blocks = (int64_t)smoe_num_cus() * 16;          // rows are walked with this stride: plenty of stores in flight per CU
+  if (blocks > T) blocks = T;
+  if (E <= 8) hipLaunchKernelGGL((gate_dgrad_kernel<OT, 8>), dim3((int)blocks), dim3(threads), 0, s, dl, w, T, E, d, out);
+  else if (E <= 16) hipLaunchKernelGGL((gate_dgrad_kernel<OT, 16>), dim3((int)blocks), dim3(threads), 0, s, dl, w, T, E, d, out);
+  else hipLaunchKernelGGL((gate_dgrad_any_kernel<OT>), dim3((int)blocks), dim3(threads), 0, s, dl, w, T, E, d, out);
 }
 
 }  // namespace
@@ -206,12 +259,10 @@ extern "C" int smoe_gate_dgrad(const float* dl, const float* w, int64_t T, int E
   if (T == 0) return 0;
   SMOE_REQUIRE(dl && w && out && smoe_dtype_ok(out_dtype), "smoe_gate_dgrad: null pointer / bad dtype");
   hipStream_t s = (hipStream_t)stream;
-  int64_t blocks = (T * (d / 4) + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
   switch (out_dtype) {
-    case SMOE_F32: hipLaunchKernelGGL(gate_dgrad_kernel<float>, dim3((int)blocks), dim3(256), 0, s, dl, w, T, E, d, (float*)out); break;
-    case SMOE_F16: hipLaunchKernelGGL(gate_dgrad_kernel<f16>, dim3((int)blocks), dim3(256), 0, s, dl, w, T, E, d, (f16*)out); break;
-    default: hipLaunchKernelGGL(gate_dgrad_kernel<bf16_bits>, dim3((int)blocks), dim3(256), 0, s, dl, w, T, E, d, (bf16_bits*)out); break;
+    case SMOE_F32: gate_dgrad_launch<float>(dl, w, T, E, d, (float*)out, s); break;
+    case SMOE_F16: gate_dgrad_launch<f16>(dl, w, T, E, d, (f16*)out, s); break;
+    default: gate_dgrad_launch<bf16_bits>(dl, w, T, E, d, (bf16_bits*)out, s); break;
   }
   SMOE_CHECK_LAUNCH("smoe_gate_dgrad");
   return 0;
@@ -219,7 +270,7 @@ extern "C" int smoe_gate_dgrad(const float* dl, const float* w, int64_t T, int E
 
 extern "C" size_t smoe_layernorm_bwd_workspace_bytes(int64_t T, int d) {
   if (T < 0 || d <= 0) return 0;
-  return (size_t)lnb_grid(T) * 2 * (size_t)d * sizeof(float);
+  return ((size_t)lnb_grid(T) + LNB_STAGE1) * 2 * (size_t)d * sizeof(float);
 }
 
 extern "C" int smoe_layernorm_bwd(const float* x, const void* dy, int dy_dtype, const float* gamma, const float* dres, float eps,
