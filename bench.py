@@ -328,15 +328,16 @@ def main():
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                     "flops_per_launch": a["flops"] / a["launches"]}
-        # the same launches under the names rocprofv3 --stats gives them (profiles/r02_bench_kernel_stats.csv):
-        # grouped_gemm_ps<operand, out, AFR, DEEP, KEEP> (AFR 5 = 320-row tile; DEEP = the half-tile prefetch schedule picked for
-        # K >= 2048); with --gemm-variant 4: grouped_gemm_pp256<operand, out, ABL, MODE, AFR>
+        # the same launches under the names rocprofv3 --stats gives them (profiles/r03_bench_kernel_stats.csv):
+        # grouped_gemm_ps<operand, out, AFR, DEEP, KEEP, DIRECT, BUF> (AFR 5 = 320-row tile; DEEP = the half-tile prefetch schedule
+        # picked for K >= 2048; DIRECT = 16-bit outputs stored from the registers; BUF = f32 outputs through the buffer-addressed
+        # staged epilogue); with --gemm-variant 4: grouped_gemm_pp256<operand, out, ABL, MODE, AFR>
         pers = (args.gemm_variant or ops.DEFAULT_GEMM_VARIANT) == 9
-        names = ({"grouped_gemm_fc1": "grouped_gemm_ps<f16,f16,5,false,false> = GEMM-1 (K 768, gathered rows, bias + GELU)",
-                  "grouped_gemm_fc2": "grouped_gemm_ps<f16,f32,5,true,false> = GEMM-2 (K 3072, combine + residual)",
-                  "attn_proj_gemm": "grouped_gemm_ps<f16,f32,5,false,false> = attention projection (K 768, + residual)",
-                  "qkv_gemm": "grouped_gemm_ps<f16,f16,4,false,false> = qkv projection (K 768, N 2304; 256-row tiles)",
-                  "patch_embed_gemm": "grouped_gemm_ps<f16,f16,5,false,false> (the GEMM-1 instantiation: its rocprof average "
+        names = ({"grouped_gemm_fc1": "grouped_gemm_ps<f16,f16,5,false,false,true,false> = GEMM-1 (K 768, gathered rows, bias + GELU)",
+                  "grouped_gemm_fc2": "grouped_gemm_ps<f16,f32,5,true,false,false,true> = GEMM-2 (K 3072, combine + residual)",
+                  "attn_proj_gemm": "grouped_gemm_ps<f16,f32,5,false,false,false,true> = attention projection (K 768, + residual)",
+                  "qkv_gemm": "grouped_gemm_ps<f16,f16,4,false,false,true,false> = qkv projection (K 768, N 2304; 256-row tiles)",
+                  "patch_embed_gemm": "grouped_gemm_ps<f16,f16,5,false,false,true,false> (the GEMM-1 instantiation: its rocprof average "
                                       "includes these launches) = patch embedding (K 768, N 768)"}
                  if pers else
                  {"grouped_gemm_fc1": "grouped_gemm_pp256<f16,f16,0,0,5> = GEMM-1 (K 768, GELU)",
