@@ -796,6 +796,41 @@ def test_persistent_gemm_equals_one_workgroup_per_tile_kernel_bitwise(variant):
         assert torch.equal(o_ps, o_ref)
 
 
+@pytest.mark.parametrize("N", [256, 512, 768, 1024, 1280])
+@pytest.mark.parametrize("K", [256, 2048])
+def test_persistent_gemm_f32_epilogue_and_tile_orders_bitwise(N, K):
+    """The f32-output forms of the persistent kernel (round 3): the buffer-addressed staged epilogue (every load / store issued,
+    invalid ones out of the descriptors' range) and the XCD-contiguous tile order it runs under for N <= 1024 (1-4 n-tiles; 5
+    n-tiles keep the strided order), on the plain (K 256) and the deep (K 2048) schedule: bit for bit the one-workgroup-per-tile
+    kernel -- row-mapped + scaled + in-place residual, plain with a separate residual, plain without one, ragged / empty groups,
+    an output with more rows than dispatched rows."""
+    counts = [1900, 0, 333, 2101, 64, 700, 1, 960]
+    E = len(counts)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device=DEV)
+    M = int(offsets[-1])
+    T = M + 500                                            # token rows: some tokens were not dispatched
+    g = _gen(N + K)
+    a = torch.randn(M, K, generator=g).half().to(DEV)
+    w = (torch.randn(E, N, K, generator=g) * 0.05).half().to(DEV)
+    bias = (torch.randn(E, N, generator=g) * 0.1).to(DEV)
+    pos = torch.randperm(T, generator=g)[:M].to(DEV)       # row_map: dispatch row -> token row (values up to T - 1 >= M)
+    score = torch.rand(T, generator=g).to(DEV)
+    res = torch.randn(T, N, generator=g).to(DEV)
+    outs = {}
+    for v in (4, 9, 14):
+        o = res.clone()
+        ops.grouped_gemm(a, w, bias, offsets, ops.EPI_NONE, torch.float32, row_map=pos, row_scale=score, out=o, variant=v, residual=o)
+        p_res = ops.grouped_gemm(a, w, bias, offsets, ops.EPI_NONE, torch.float32, variant=v, residual=res[:M].contiguous())
+        p_gelu = ops.grouped_gemm(a, w, bias, offsets, ops.EPI_GELU, torch.float32, variant=v)
+        outs[v] = (o, p_res, p_gelu)
+    for v in (9, 14):
+        for got, ref in zip(outs[v], outs[4]):
+            assert torch.equal(got, ref), f"variant {v}"
+    untouched = torch.ones(T, dtype=torch.bool, device=DEV)
+    untouched[pos] = False
+    assert torch.equal(outs[9][0][untouched], res[untouched]), "token rows that were not dispatched keep the residual"
+
+
 def test_cabi_exchange_context_world_of_one_and_ep_transport():
     """include/slimmoe.h smoe_ctx_* / smoe_a2a_*: RCCL communicator from a unique-id blob, dedicated communication
     stream, event fences.  One GPU = a world of one rank (what hardware this box has): counts and rows come back

@@ -49,6 +49,10 @@ def test_argument_validation_errors_come_back_as_messages():
     assert rc != 0 and lib.smoe_last_error()
     with pytest.raises(_lib.SlimMoEError):
         _lib.check(rc, "smoe_grouped_gemm")
+    # out_rows (ABI 20): without a row map the output cannot have fewer rows than are dispatched -- refused before any launch
+    fake = 4096                                            # never dereferenced: the argument checks come first
+    rc = lib.smoe_grouped_gemm(fake, fake, None, fake, None, 1, 1, 8, 64, 64, 1, 0, None, None, None, None, 1, fake, 4, 1, 9, None, None)
+    assert rc != 0 and b"out_rows" in lib.smoe_last_error()
 
 
 def test_product_path_refuses_cpu_tensors():
