@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (library built with `make DIAG=-DSMOE_DIAG`): per-tile phase times of the persistent grouped GEMM from
-s_memtime stamps (wave 0 / lane 0 of every workgroup).  usage: gemm_stamps.py <variant 9..13> <fc1|fc2>"""
+s_memtime stamps (wave 0 / lane 0 of every workgroup).  usage: gemm_stamps.py <variant 9..13> <fc1|fc2|qkv>"""
 import ctypes
 import os
 import sys
@@ -32,8 +32,15 @@ def main():
     out = torch.zeros(T, d, device=dev)
     res = torch.randn(T, d, device=dev)
 
+    one = torch.tensor([0, T], dtype=torch.int32, device=dev)
+    wq = (torch.randn(1, 3 * d, d, device=dev) * 0.02).half()
+    bq = torch.randn(1, 3 * d, device=dev) * 0.02
+    qkv = torch.empty(T, 3 * d, device=dev, dtype=torch.float16)
+
     def run():
-        if shape == "fc1":
+        if shape == "qkv":      # one group, N 2304, f16 out: the 256-row direct-store instantiation
+            ops.grouped_gemm(x16, wq, bq, one, ops.EPI_NONE, torch.float16, variant=variant, out=qkv)
+        elif shape == "fc1":
             ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_NONE if os.environ.get("SMOE_EPI") == "none" else ops.EPI_GELU,
                              torch.float16, variant=variant, a_gather=pos, out=hbuf)
         else:
@@ -61,7 +68,7 @@ def main():
              (4, 5): "pass0: rows + GELU + LDS write", (5, 6): "pass0: wait + barrier", (6, 7): "pass0: LDS read + stores",
              (8, 9): "last pass: vmcnt(0)", (9, 10): "last pass: barrier", (10, 11): "last pass: stores", (11, 12): "last barrier",
              (0, 12): "whole tile", (1, 12): "tile boundary (everything but the main loop)"}
-    if shape == "fc1" and variant != 14:   # the direct-store epilogue (16-bit output, no row map): stamps 5 and 12 only
+    if shape in ("fc1", "qkv") and variant != 14:   # the direct-store epilogue (16-bit output, no row map): stamps 5 and 12 only
         names = {(0, 1): "main loop", (1, 2): "advance", (2, 3): "setup (gather addresses)", (3, 4): "issue kt0 + kt1",
                  (4, 5): "direct epilogue: bias + GELU + pack + swaps + 20 stores issued", (5, 12): "wait for K-tile 0 + barrier",
                  (0, 12): "whole tile", (1, 12): "tile boundary (everything but the main loop)"}
