@@ -26,6 +26,8 @@
 __device__ unsigned long long smoe_diag_stamps[256 * 12 * 16];
 __device__ int smoe_diag_flags;   // bit 0: the main loop issues no operand DMA (garbage results: what do MFMA + LDS reads alone cost?)
 #define PS_NODMA (diag_nodma)
+// bit 1: the main loop's interval barriers are skipped (garbage results: what do the ping-pong hand-overs cost?)
+#define PS_IBAR() do { if (!diag_nobar) PP_BARRIER(); } while (0)
 #define PS_STAMP(i)                                                                                              \
   do {                                                                                                           \
     if (wave == 0 && lane == 0 && tile_no < 12 && blockIdx.x < 256)                                              \
@@ -34,6 +36,7 @@ __device__ int smoe_diag_flags;   // bit 0: the main loop issues no operand DMA 
 #else
 #define PS_STAMP(i) do {} while (0)
 #define PS_NODMA false
+#define PS_IBAR() PP_BARRIER()
 #endif
 
 // KEEP (training forward of the first expert linear): the epilogue stores BOTH the pre-activation H = A W^T + b and gelu(H) --
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   const int nk = K / 64;
 #ifdef SMOE_DIAG
   const bool diag_nodma = (__builtin_amdgcn_readfirstlane(smoe_diag_flags) & 1) != 0;
+  const bool diag_nobar = (__builtin_amdgcn_readfirstlane(smoe_diag_flags) & 2) != 0;
 #endif
 
   // ---- tile enumeration ------------------------------------------------------------------------------------------------
@@ -381,32 +385,32 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
         __builtin_amdgcn_sched_barrier(0);
         read_a(cur, 0);
         if (n1) dma_ah(t + 1, nxt, 1);
-        PP_BARRIER();
+        PS_IBAR();
         PS_MFMA(0, 0);
-        PP_BARRIER();
+        PS_IBAR();
         read_b(cur, 1);
         if (n1) dma_wh(t + 1, nxt, 0);
-        PP_BARRIER();
+        PS_IBAR();
         PS_MFMA(0, 1);
-        PP_BARRIER();
+        PS_IBAR();
         read_a(cur, 1);
         if (n2) dma_ah(t + 2, cur, 0);
-        PP_BARRIER();
+        PS_IBAR();
         PS_MFMA(1, 1);
-        PP_BARRIER();
+        PS_IBAR();
         read_b(cur, 0);
         if (n2) dma_wh(t + 2, cur, 1);
         if (wr == 1) {  // group 1: its program interval 6 is global interval 8t+7, the last one of tile t
           if (n2) wait_keep2();
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        PP_BARRIER();
+        PS_IBAR();
         PS_MFMA(1, 0);
         if (wr == 0) {  // group 0: program interval 7 = global 8t+7
           if (n2) wait_keep2();
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        PP_BARRIER();
+        PS_IBAR();
       }
     } else {
       // R1(t): A rows 128.. of tile t+1   R2(t): W rows 0-127 of t+1   R3(t): W rows 128-255 of t+1
@@ -419,32 +423,32 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
         __builtin_amdgcn_sched_barrier(0);
         read_a(cur, 0);
         if (pre1) dma_a(t + 1, nxt, 2);
-        PP_BARRIER();
+        PS_IBAR();
         PS_MFMA(0, 0);
-        PP_BARRIER();
+        PS_IBAR();
         read_b(cur, 1);
         if (pre1) dma_w(t + 1, nxt, 0);
-        PP_BARRIER();
+        PS_IBAR();
         PS_MFMA(0, 1);
-        PP_BARRIER();
+        PS_IBAR();
         read_a(cur, 1);
         if (pre1) dma_w(t + 1, nxt, 2);
-        PP_BARRIER();
+        PS_IBAR();
         PS_MFMA(1, 1);
-        PP_BARRIER();
+        PS_IBAR();
         read_b(cur, 0);
         if (pre2) dma_a(t + 2, cur, 0);
         if (wr == 1) {
           if (pre2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        PP_BARRIER();
+        PS_IBAR();
         PS_MFMA(1, 0);
         if (wr == 0) {
           if (pre2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        PP_BARRIER();
+        PS_IBAR();
       }
     }
     if (wr == 0) PP_BARRIER();  // equalise barrier counts; after it every wave is done with the operand buffers
