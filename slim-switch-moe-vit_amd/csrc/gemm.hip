@@ -1212,7 +1212,6 @@ int launch_pp256(const void* A, const void* W, const float* bias, const int32_t*
 }
 
 #include "gemm_persistent.h"
-#include "gemm_w2.h"
 
 template <typename AB>
 int launch_wgrad(const void* PT, const void* QT, const int32_t* offsets_pad, int E, int R1, int R2, int Lp, float* out,
@@ -1320,14 +1319,6 @@ int launch_variant(int variant, const void* A, const void* W, const float* bias,
         if (deep) return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows, false);
         return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows, false);
       }
-      case 15: {  // two workgroups per CU, 128 x 256 tiles, one tile per workgroup (plain 16-bit outputs; else as 9)
-        if constexpr (sizeof(OT) == 2) {
-          if (!row_map && !residual && !group_end && K % 32 == 0 && (epilogue == SMOE_EPI_NONE || epilogue == SMOE_EPI_GELU) &&
-              (int64_t)N * 128 * 2 < (1ll << 31))
-            return launch_w2<AB, OT>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, out, s, a_gather, a_div);
-        }
-        return launch_variant<AB, OT>(9, A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, s, a_gather, a_div, group_end, out_rows);
-      }
       case 10: return launch_ps<AB, OT, 5, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
       case 11: return launch_ps<AB, OT, 4, false>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
       case 12: return launch_ps<AB, OT, 4, true>(A, W, bias, offsets, group_expert, E, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, 4, s, a_gather, a_div, group_end, out_rows);
@@ -1404,15 +1395,15 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   if (m_rows_max == 0) return 0;
   SMOE_REQUIRE(A && W && out, "smoe_grouped_gemm: null pointer");
   if (K % 64 != 0 || smoe_dtype_size(ab_dtype) != 2) variant = 0;
-  SMOE_REQUIRE(!a_gather || (variant >= 4 && variant <= 15 && a_div >= 1),
-               "smoe_grouped_gemm: a_gather needs variant 4-15 (16-bit operands, K %% 64 == 0)");
+  SMOE_REQUIRE(!a_gather || (variant >= 4 && variant <= 14 && a_div >= 1),
+               "smoe_grouped_gemm: a_gather needs variant 4-14 (16-bit operands, K %% 64 == 0)");
   if (variant >= 9 && variant <= 14) {
     // the persistent kernel addresses both operands with 32-bit byte offsets; operands of 4 GiB and more take the
     // one-workgroup-per-tile kernel of the same tile height / schedule (9, 14 -> 4, 10 -> 5, 11 -> 6, 12 -> 7, 13 -> 8)
     const uint64_t a_bytes = (uint64_t)m_rows_max * (uint64_t)K * 2u, w_bytes = (uint64_t)n_experts * (uint64_t)N * (uint64_t)K * 2u;
     if (a_bytes >= (1ull << 32) || w_bytes >= (1ull << 32) || G > 63) variant = variant == 14 ? 4 : variant - 5;   // (its group table: 64 lanes)
   }
-  SMOE_REQUIRE(!group_end || (variant >= 9 && variant <= 15),
+  SMOE_REQUIRE(!group_end || (variant >= 9 && variant <= 14),
                "smoe_grouped_gemm: group_end (separate row ranges per group) needs the persistent kernel: variant 9-14, 16-bit "
                "operands under 4 GiB, K %% 64 == 0, at most 63 groups");
   hipStream_t s = (hipStream_t)stream;

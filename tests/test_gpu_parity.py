@@ -761,7 +761,7 @@ def test_expert_parallel_data_path_simulated_ranks(W_ranks, E_local, k, d, h):
         _float_bar(got, ref, 1e-3)
 
 
-@pytest.mark.parametrize("variant", [9, 10, 11, 12, 13, 14, 15])
+@pytest.mark.parametrize("variant", [9, 10, 11, 12, 13, 14])
 def test_persistent_gemm_equals_one_workgroup_per_tile_kernel_bitwise(variant):
     """grouped_gemm_ps (one workgroup per CU walking tiles, the next tile's operands streaming under the epilogue) must
     reproduce grouped_gemm_pp256 bit for bit in every fused form it is used in: gathered A rows + bias + GELU (GEMM-1),
@@ -779,8 +779,7 @@ def test_persistent_gemm_equals_one_workgroup_per_tile_kernel_bitwise(variant):
     b2 = (torch.randn(E, d, generator=g) * 0.1).to(DEV)
     score = torch.rand(M, generator=g).to(DEV)
     res = torch.randn(M, d, generator=g).to(DEV)
-    # the same tile height / schedule, one workgroup per tile (15: the two-workgroups-per-CU kernel, 128 x 256 tiles of its own)
-    base = {9: 4, 10: 5, 11: 6, 12: 7, 13: 8, 14: 4, 15: 4}[variant]
+    base = {9: 4, 10: 5, 11: 6, 12: 7, 13: 8, 14: 4}[variant]     # the same tile height / schedule, one workgroup per tile
     for _ in range(3):
         h_ref = ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_GELU, torch.float16, variant=base, a_gather=pos)
         h_ps = ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_GELU, torch.float16, variant=variant, a_gather=pos)
