@@ -239,9 +239,10 @@ def _route_train(mod, x):
     return score, counts, offsets, pos, inv_pos
 
 
-def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
+def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row_scale: torch.Tensor = None) -> torch.Tensor:
     """FMoETransformerMLP.forward with autograd: single rank, or expert parallel (one exchange each way); ``residual``
-    (inp's shape and dtype) is added in the combine's store."""
+    (inp's shape and dtype) is added in the combine's store; ``row_scale`` (f32 [T], no gradient) multiplies every token's
+    combined expert output (stochastic depth) -- folded into the combine weights, so the backward sees it as part of them."""
     if mod._generic_act is not None or not mod._fused_gelu:
         raise NotImplementedError("training path supports the reference's GELU(+Dropout) activation only")
     cd = mod.compute_dtype or _default_cd()
@@ -280,5 +281,7 @@ def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None) -> 
     else:
         back = Y
     res = residual.reshape(-1, d) if residual is not None else None
+    if row_scale is not None:
+        score = score * row_scale.reshape(T, 1).to(score.dtype)
     out = _Combine.apply(back, score, pos, inv_pos, k, x.dtype, res)
     return out.reshape(shape)

@@ -89,32 +89,78 @@ def layer_norm_supported(x: torch.Tensor, norm) -> bool:
             and x.is_contiguous() and x.shape[-1] in ops.LN_DIMS and tuple(norm.normalized_shape) == (x.shape[-1],))
 
 
-class LinearFn(torch.autograd.Function):
-    """``x16 [M, K] @ weight[N, K]^T + bias`` (+ residual, f32) with f16 operands; ``cache`` is the module's _HalfCache."""
+class _Cast16Fn(torch.autograd.Function):
+    """f32 -> f16 rows (the cast autocast inserts in front of a GEMM); backward: the f16 gradient back in f32."""
 
     @staticmethod
-    def forward(ctx, x16, weight, bias, residual, cache, out_dtype, name):
+    def forward(ctx, x):
+        return ops.cast(x.contiguous(), torch.float16)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.cast(dy.contiguous(), torch.float32)
+
+
+def cast16(x: torch.Tensor) -> torch.Tensor:
+    return _Cast16Fn.apply(x)
+
+
+def _pad64(n: int) -> int:
+    return -(-n // 64) * 64
+
+
+class LinearFn(torch.autograd.Function):
+    """``x16 [M, K] @ weight[N, K]^T + bias`` (+ residual, f32) with f16 operands; ``cache`` is the module's _HalfCache.
+
+    ``row_scale`` (f32 [M], no gradient; needs ``residual``): ``residual + row_scale[r] * (x16 W^T + bias)[r]`` -- stochastic
+    depth's per-sample ``mask / keep`` (timm DropPath, models/vision_transformer.py:308,320) riding on the GEMM's combine scale;
+    the backward scales dY by it in the pass that casts dY to 16 bit.
+
+    N % 64 != 0 (the 1000-class head, models/vision_transformer.py:847): the backward's two GEMMs contract over N / write N
+    rows, so they run on zero-padded images (weight rows / dY columns up to the next multiple of 64) and the padding is dropped
+    from dW; the forward pads N to a multiple of 8 as the inference path does."""
+
+    @staticmethod
+    def forward(ctx, x16, weight, bias, residual, cache, out_dtype, name, row_scale=None):
         from .vit import _linear16
-        out = _linear16(cache, x16, weight, bias, out_dtype, residual=residual, name=name)
+        if row_scale is not None and residual is None:
+            raise RuntimeError(f"{name}: row_scale rides on the fused residual store; pass the residual")
+        out = _linear16(cache, x16, weight, bias, out_dtype, residual=residual, name=name, row_scale=row_scale)
         if out is None:
             raise RuntimeError(f"{name}: shape {tuple(x16.shape)} x {tuple(weight.shape)} is outside the GEMM kernel's reach "
                                "(check linear_supported first)")
         ctx.cache, ctx.has_bias, ctx.has_res, ctx.name = cache, bias is not None, residual is not None, name
-        ctx.save_for_backward(x16, weight)
+        ctx.save_for_backward(x16, weight, row_scale if row_scale is not None else torch.empty(0, device=x16.device))
+        ctx.has_scale = row_scale is not None
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x16, weight = ctx.saved_tensors
+        x16, weight, row_scale = ctx.saved_tensors
         N, K = weight.shape[0], x16.shape[1]
         M = x16.shape[0]
+        dy = dy.contiguous()
         dres = dy if ctx.has_res else None                   # the residual's gradient is the output's
-        dy16 = dy if dy.dtype == torch.float16 else dy.to(torch.float16)
-        dy16 = dy16.contiguous()
+        Np = _pad64(N)
+        if ctx.has_scale:
+            # d(branch) = row_scale * dY, cast to 16 bit in the same pass (smoe_scatter_rows under the identity map)
+            dy16 = ops.scatter_rows(dy, ctx.cache.identity_rows(M, dy.device), 1, torch.float16, scale=row_scale)
+        elif dy.dtype == torch.float16:
+            dy16 = dy
+        else:
+            dy16 = ops.cast(dy, torch.float16)
         offs = ctx.cache.offsets(M, x16.device)
+        if Np != N:                                          # zero columns up to a multiple of 64 (a handful of rows: the head)
+            pad = torch.zeros((M, Np), dtype=torch.float16, device=dy16.device)
+            pad[:, :N].copy_(dy16)
+            dy16 = pad
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.group_colsum(dy16, offs)[0][:N]
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = ctx.cache.get_t(weight)                     # [1, K, N] f16: the dgrad GEMM contracts over N
+            # [1, K, Np] f16: the dgrad GEMM contracts over N
+            wt = ctx.cache.get_t(weight) if Np == N else ctx.cache.get_t_padded(weight, Np)
             dx = ops.grouped_gemm(dy16, wt, None, offs, ops.EPI_NONE, torch.float16, variant=ops.DEFAULT_GEMM_VARIANT,
                                   prof_name=ctx.name + "_dgrad")
         dw = None
@@ -122,15 +168,14 @@ class LinearFn(torch.autograd.Function):
             # dW = dY^T X contracts over the M rows: with ONE row group the wgrad kernel's grid is only (N / 256) x (K / 256)
             # tiles (27 for the qkv projection: a tenth of the chip, 700 us at ViT-B).  The rows are cut into S pseudo-groups
             # so that S x tiles fill the CUs once; the S partial [N, K] products are summed in group order (deterministic).
-            S = _wgrad_splits(M, N, K, x16.device)
+            S = _wgrad_splits(M, Np, K, x16.device)
             if S > 1:
                 offs_s = ctx.cache.split_offsets(M, S, x16.device)
                 dw = ops.grouped_wgrad_rows(dy16, x16, offs_s).sum(0)
             else:
                 dw = ops.grouped_wgrad_rows(dy16, x16, offs)[0]
-            dw = dw.reshape(weight.shape).to(weight.dtype)
-        db = ops.group_colsum(dy16, offs)[0] if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, dres, None, None, None
+            dw = dw[:N].reshape(weight.shape).to(weight.dtype)
+        return dx, dw, db, dres, None, None, None, None
 
 
 def _wgrad_splits(M: int, N: int, K: int, device) -> int:
@@ -141,10 +186,11 @@ def _wgrad_splits(M: int, N: int, K: int, device) -> int:
 
 
 def linear_supported(x16: torch.Tensor, weight: torch.Tensor) -> bool:
-    """Forward and backward GEMMs take these shapes (K and N multiples of 64: both are contraction lengths once)."""
+    """Forward and backward GEMMs take these shapes: K a multiple of 64 (the forward's contraction length and the dgrad's
+    output width); any N >= 1 (the backward pads it to a multiple of 64, the forward to a multiple of 8)."""
     M, K = x16.shape
     N = weight.shape[0]
-    return (x16.is_cuda and x16.dtype == torch.float16 and x16.is_contiguous() and M > 0 and K % 64 == 0 and N % 64 == 0
+    return (x16.is_cuda and x16.dtype == torch.float16 and x16.is_contiguous() and M > 0 and K % 64 == 0 and N >= 1
             and weight.dim() >= 2 and weight.numel() == N * K)
 
 

@@ -161,7 +161,7 @@ def _fused_ok(blk, x) -> bool:
     from .vit import _autocast_half_inference, Attention
     d = x.shape[-1]
     return (x.is_cuda and x.dim() == 3 and x.dtype == th.float32 and x.is_contiguous() and not blk.training
-            and isinstance(blk.drop_path, nn.Identity) and _autocast_half_inference(x)
+            and blk.stochastic_depth_inactive() and _autocast_half_inference(x)
             and isinstance(blk.attn, Attention) and isinstance(blk.dense_gate, Gate) and isinstance(blk.moe_gate, Gate)
             and all(isinstance(n, nn.LayerNorm) and n.elementwise_affine and tuple(n.normalized_shape) == (d,)
                     for n in (blk.norm1, blk.norm2))
@@ -201,6 +201,10 @@ def forward_residule_moe(self, x):
     185-186)."""
     if _fused_ok(self, x):
         return _residual_block_fused(self, x)
+    if x.is_cuda and th.is_autocast_enabled():
+        from .vit import _warn_fallback
+        _warn_fallback("residual-MoE block", "config: composed from torch modules (needs fp16-autocast inference, f32 contiguous "
+                       "activations, inactive stochastic depth, the naive gate on one rank)", x.shape)
     return _residual_block_composed(self, x)
 
 

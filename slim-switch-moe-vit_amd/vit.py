@@ -119,6 +119,10 @@ class _HalfCache(StreamCache):
             return torch.tensor(cuts, dtype=torch.int32, device=device)
         return super().get(("split", rows, parts, str(device)), 0, make)
 
+    def identity_rows(self, rows: int, device) -> torch.Tensor:
+        """int64 [rows] = 0 .. rows-1: the row map under which the GEMM's per-row combine scale applies to plain rows."""
+        return super().get(("ident", rows, str(device)), 0, lambda: torch.arange(rows, dtype=torch.int64, device=device))
+
     def get(self, p: torch.Tensor) -> torch.Tensor:  # noqa: D102
         return super().get(id(p), param_version(p), lambda: p.detach().half())
 
@@ -139,6 +143,17 @@ class _HalfCache(StreamCache):
         N = p.shape[0]
         return super().get(("t", id(p)), param_version(p),
                             lambda: ops.transpose_cast(p.detach().float().reshape(1, N, -1).contiguous(), torch.float16))
+
+    def get_t_padded(self, p: torch.Tensor, rows: int) -> torch.Tensor:
+        """``get_t`` of ``p [N, K]`` with zero rows appended up to ``rows`` (a multiple of 64): ``[1, K, rows]`` fp16 -- the
+        dgrad operand of a classifier head whose class count is not a multiple of 64."""
+        from . import ops
+
+        def make():
+            t = torch.zeros((1, rows, p.shape[1]), dtype=torch.float32, device=p.device)
+            t[0, : p.shape[0]].copy_(p.detach().reshape(p.shape[0], -1))
+            return ops.transpose_cast(t, torch.float16)
+        return super().get(("tpad", id(p), rows), param_version(p), make)
 
     def get_f32(self, p: torch.Tensor) -> torch.Tensor:
         """f32 view of a (bias) parameter: the parameter itself unless it is stored in another dtype."""
@@ -190,12 +205,14 @@ def _linear16_reason(x16: torch.Tensor, weight: torch.Tensor):
 
 
 def _linear16(hc: "_HalfCache", x16: torch.Tensor, weight: torch.Tensor, bias, out_dtype=torch.float16, residual=None,
-              name: str = "dense_gemm"):
+              name: str = "dense_gemm", row_scale=None):
     """``x16 @ weight^T + bias`` (+ residual) for fp16 rows ``x16 [M, K]`` on the hand-written grouped MFMA GEMM with a
     single row group -- the dense projections around the MoE (qkv, attention output, patch embedding, classifier head:
     models/vision_transformer.py:262-266, 276, 819, 847) -- returning ``[M, N]`` in ``out_dtype``.  Same arithmetic as
     the fp16 GEMM autocast would run (f16 operands, f32 accumulate, one rounding).  An N that is not a multiple of 8 (a
-    10-class head) is padded with zero weight rows and the extra columns dropped.  Returns None, after a
+    10-class head) is padded with zero weight rows and the extra columns dropped.  ``row_scale`` (f32 [M]): row r of the
+    product is multiplied by ``row_scale[r]`` before the residual is added (stochastic depth's per-sample ``mask / keep``,
+    models/vision_transformer.py:320: it rides on the GEMM's fused-combine scale under an identity row map).  Returns None, after a
     SlimMoEFallbackWarning, when the shape is not the kernel's (K % 64), so the caller can fall back to ``F.linear``."""
     from . import ops
     M, K = x16.shape
@@ -207,7 +224,7 @@ def _linear16(hc: "_HalfCache", x16: torch.Tensor, weight: torch.Tensor, bias, o
         _warn_fallback(name, why, (M, K, N))
         return None
     if N % 8:
-        assert residual is None
+        assert residual is None and row_scale is None
         Np = (N + 7) // 8 * 8
         w = hc.get_padded(weight, Np, torch.float16)[None]
         b = hc.get_padded(bias, Np, torch.float32)[None] if bias is not None else None
@@ -218,6 +235,11 @@ def _linear16(hc: "_HalfCache", x16: torch.Tensor, weight: torch.Tensor, bias, o
     b = hc.get_f32(bias)[None] if bias is not None else None
     # a handful of rows (the classifier head sees one row per image): 128 x 128 tiles spread the few output tiles over
     # more CUs than the 320 x 256 tile of the big GEMMs would
+    if row_scale is not None:
+        out = torch.empty((M, N), dtype=out_dtype, device=x16.device)
+        return ops.grouped_gemm(x16, w, b, hc.offsets(M, x16.device), ops.EPI_NONE, out_dtype, residual=residual,
+                                row_map=hc.identity_rows(M, x16.device), row_scale=row_scale, out=out,
+                                variant=ops.DEFAULT_GEMM_VARIANT, prof_name=name)
     variant = 1 if M <= 1024 else ops.DEFAULT_GEMM_VARIANT
     return ops.grouped_gemm(x16, w, b, hc.offsets(M, x16.device), ops.EPI_NONE, out_dtype, residual=residual,
                             variant=variant, prof_name=name)
@@ -235,69 +257,93 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def forward(self, x, residual=None):
-        """``residual`` (optional, inference fast path only): returns (residual + attn(x), True) when the add was
-        fused into the projection, else (attn(x), False)."""
+    def forward(self, x, residual=None, row_scale=None):
+        """``attn(x)``; with ``residual`` the pair ``(out, added)``: ``(residual + s * attn(x), True)`` when the add (and the
+        optional per-row factor ``s`` = ``row_scale`` f32 [B*N], stochastic depth's ``mask / keep``) was fused into the
+        projection GEMM's store, else ``(attn(x), False)`` -- unscaled; the caller scales and adds.
+
+        Under fp16 autocast -- inference or training -- every piece runs on the library's kernels whether or not a residual is
+        handed in (a block whose stochastic depth is merely *inactive* calls without one); anything else goes to
+        ``_forward`` = ``nn.Linear`` + ``F.scaled_dot_product_attention`` and says so once (SlimMoEFallbackWarning)."""
         B, N, C = x.shape
-        tr = self._forward_train(x, residual)
+        tr = self._forward_train(x, residual, row_scale)
         if tr is not None:
             return tr if residual is not None else tr[0]
-        if residual is None:
-            return self._forward(x)
-        if x.dtype == torch.float16 and _autocast_half_inference(x):
-            # same arithmetic as autocast (fp16 GEMM operands), without re-casting the weights on every call
-            hc = _half_cache(self)
-            qkv = _linear16(hc, x.reshape(B * N, C), self.qkv.weight, self.qkv.bias, name="qkv_gemm")
-            if qkv is None:
-                qkv = F.linear(x, hc.get(self.qkv.weight), hc.get(self.qkv.bias) if self.qkv.bias is not None else None)
-            from . import ops
-            hd = C // self.num_heads
-            if ops.attention_supported(N, hd) and qkv.is_contiguous():
-                # hand-written attention on the fused qkv layout [B,N,3,H,hd] (no q/k/v transposes)
-                o = ops.attention(qkv, B, N, self.num_heads, hd, self.scale).reshape(B * N, C)
-            else:
-                _warn_fallback("attention", "kernel covers head_dim 64, N <= 640" if qkv.is_contiguous() else "qkv not contiguous",
-                               (N, hd))
-                q, k, v = qkv.reshape(B, N, 3, self.num_heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
-                o = F.scaled_dot_product_attention(q, k, v, scale=self.scale).transpose(1, 2).reshape(B * N, C)
-            if residual is not None and C % 64 == 0 and residual.dtype == torch.float32 and residual.is_contiguous():
+        if _autocast_half_inference(x) and x.dtype in (torch.float16, torch.float32) and not (
+                self.training and (self.attn_drop.p > 0 or self.proj_drop.p > 0)):
+            out, added = self._forward_infer16(x, residual, row_scale)
+            return (out, added) if residual is not None else out
+        if x.is_cuda and torch.is_autocast_enabled():
+            _warn_fallback("attention", "config: needs fp16 autocast without attention / projection dropout in training", (B, N, C))
+        return (self._forward(x), False) if residual is not None else self._forward(x)
+
+    def _forward_infer16(self, x, residual, row_scale):
+        """fp16-autocast inference on the own kernels: the arithmetic autocast runs (fp16 GEMM operands, f32 accumulate, one
+        rounding), without re-casting the weights on every call.  -> (out, added)."""
+        from . import ops
+        B, N, C = x.shape
+        hc = _half_cache(self)
+        x2 = x.reshape(B * N, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        if x2.dtype != torch.float16:
+            x2 = ops.cast(x2, torch.float16)      # the cast autocast puts in front of the qkv GEMM
+        qkv = _linear16(hc, x2, self.qkv.weight, self.qkv.bias, name="qkv_gemm")
+        if qkv is None:
+            qkv = F.linear(x2, hc.get(self.qkv.weight), hc.get(self.qkv.bias) if self.qkv.bias is not None else None)
+        hd = C // self.num_heads
+        if ops.attention_supported(N, hd) and qkv.is_contiguous():
+            # hand-written attention on the fused qkv layout [B,N,3,H,hd] (no q/k/v transposes)
+            o = ops.attention(qkv, B, N, self.num_heads, hd, self.scale).reshape(B * N, C)
+        else:
+            _warn_fallback("attention", "kernel covers head_dim 64, N <= 640" if qkv.is_contiguous() else "qkv not contiguous",
+                           (N, hd))
+            q, k, v = qkv.reshape(B, N, 3, self.num_heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
+            o = F.scaled_dot_product_attention(q, k, v, scale=self.scale).transpose(1, 2).reshape(B * N, C)
+        if residual is not None:
+            if C % 64 == 0 and residual.dtype == torch.float32 and residual.is_contiguous():
                 # projection + bias + residual add in one launch of the grouped MFMA GEMM (a single group):
                 # residual + proj(o), f32 out -- the same arithmetic as the unfused `x + attn(...)`
                 out = _linear16(hc, o, self.proj.weight, self.proj.bias, torch.float32,
-                                residual=residual.reshape(B * N, C), name="attn_proj_gemm")
+                                residual=residual.reshape(B * N, C), row_scale=row_scale, name="attn_proj_gemm")
                 if out is not None:
                     return out.reshape(B, N, C), True
             else:
                 _warn_fallback("attn_proj_gemm", "residual must be contiguous f32 and C % 64 == 0", (B * N, C, C))
-            return F.linear(o, hc.get(self.proj.weight), hc.get(self.proj.bias)).reshape(B, N, C), False
-        return self._forward(x), False
+        out = _linear16(hc, o, self.proj.weight, self.proj.bias, name="attn_proj_gemm")
+        if out is None:
+            out = F.linear(o, hc.get(self.proj.weight), hc.get(self.proj.bias) if self.proj.bias is not None else None)
+        return out.reshape(B, N, C), False
 
-    def _forward_train(self, x, residual):
+    def _forward_train(self, x, residual, row_scale=None):
         """The training step's attention half on the library's kernels, forward AND backward (dense.py): fp16 rows from the
-        HIP LayerNorm -> qkv GEMM -> attention -> projection GEMM (+ the f32 residual in its store).  None when a
-        precondition does not hold (the caller then takes torch's path): fp16 autocast with gradients, no attention /
-        projection dropout (the reference's defaults, main.py --drop 0.0), shapes the kernels cover."""
+        HIP LayerNorm -> qkv GEMM -> attention -> projection GEMM (+ the f32 residual, and stochastic depth's per-row factor, in
+        its store).  None when a precondition does not hold (the caller then takes torch's path, loudly): fp16 autocast with
+        gradients, no attention / projection dropout (the reference's defaults, main.py --drop 0.0), shapes the kernels cover."""
         from . import dense, ops
-        if not (x.dtype == torch.float16 and dense.autocast_half_training(x) and x.is_contiguous()):
-            return None
-        if self.training and (self.attn_drop.p > 0 or self.proj_drop.p > 0):
+        if not (dense.autocast_half_training(x) and x.dtype in (torch.float16, torch.float32)):
             return None
         B, N, C = x.shape
+        if self.training and (self.attn_drop.p > 0 or self.proj_drop.p > 0):
+            _warn_fallback("attention (training)", "config: attention / projection dropout > 0", (B, N, C))
+            return None
         hd = C // self.num_heads
+        if x.dtype == torch.float32:
+            x = dense.cast16(x)                      # the cast autocast puts in front of the qkv GEMM (backward: cast back)
         x2 = x.reshape(B * N, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
         if not (dense.linear_supported(x2, self.qkv.weight) and dense.linear_supported(x2, self.proj.weight)
                 and ops.attention_supported(N, hd) and ops.attention_bwd_supported(N, hd) and DENSE_GEMM == "own"):
             _warn_fallback("attention (training)", "shape outside the backward kernels' reach (N <= 256, head dim 64, C % 64 == 0)",
                            (B, N, C, self.num_heads))
             return None
-        if residual is not None and not (residual.dtype == torch.float32 and residual.is_contiguous()):
-            return None
         hc = _half_cache(self)
         qkv = dense.LinearFn.apply(x2, self.qkv.weight, self.qkv.bias, None, hc, torch.float16, "qkv_gemm")
         o = dense.AttentionFn.apply(qkv, B, N, self.num_heads, hd, self.scale).reshape(B * N, C)
-        if residual is not None:
+        if residual is not None and residual.dtype == torch.float32 and residual.is_contiguous():
             out = dense.LinearFn.apply(o, self.proj.weight, self.proj.bias, residual.reshape(B * N, C), hc, torch.float32,
-                                       "attn_proj_gemm")
+                                       "attn_proj_gemm", row_scale)
             return out.reshape(B, N, C), True
         out = dense.LinearFn.apply(o, self.proj.weight, self.proj.bias, None, hc, torch.float16, "attn_proj_gemm")
         return out.reshape(B, N, C), False
@@ -341,40 +387,72 @@ class Block(nn.Module):
         from .ep import drain
         return drain(self.forward_steps(x))
 
+    def stochastic_depth_inactive(self) -> bool:
+        """``drop_path`` is the identity right now: the module IS ``nn.Identity`` (rate 0: models/vision_transformer.py:308), or
+        it is a ``DropPath`` in eval mode or with probability 0 (timm's DropPath returns its input then).  The fast paths below
+        are gated on THIS, not on the module's type: the reference's default is ``--drop-path 0.1`` (main.py:74-79), and such a
+        model evaluates exactly like a rate-0 one."""
+        dp = self.drop_path
+        if isinstance(dp, nn.Identity):
+            return True
+        return isinstance(dp, DropPath) and (dp.drop_prob == 0.0 or not dp.training)
+
+    def _depth_scale(self, x):
+        """One draw of stochastic depth for a [B, N, d] branch: (per-sample factor f32 [B] = bernoulli(keep) / keep, the same per
+        row f32 [B * N]); (None, None) when inactive.  None as well for a foreign ``drop_path`` module (the caller then
+        applies the module itself)."""
+        dp = self.drop_path
+        if self.stochastic_depth_inactive() or not isinstance(dp, DropPath):
+            return None, None
+        keep = 1.0 - dp.drop_prob
+        f = torch.empty(x.shape[0], dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
+        return f, f.repeat_interleave(x.shape[1])
+
     def forward_steps(self, x, xn1=None, next_norm=None):
         """The block as a generator (result = return value): it yields only inside an expert-parallel MoE ``mlp``, at
         the points where this micro-batch waits for the host or an all-to-all (ep.ep_forward_steps).
 
         ``xn1``: ``norm1(x)`` already computed by the previous block's combine (see ``next_norm``).  ``next_norm``: the NEXT
         block's ``norm1``; when this block's expert-parallel combine can produce that LayerNorm in the same pass
-        (smoe_gather_combine_ln) the result is ``(x, norm1_next(x))`` instead of ``x``."""
+        (smoe_gather_combine_ln) the result is ``(x, norm1_next(x))`` instead of ``x``.
+
+        Stochastic depth (``x + drop_path(f(norm(x)))``, models/vision_transformer.py:319-322): inactive = the plain fused paths;
+        active (training) = the per-sample ``mask / keep`` factor travels as a per-row scale into the stores that add the
+        residual (projection GEMM / MoE combine) -- the add stays fused, forward and backward."""
         from . import dense
+        inactive = self.stochastic_depth_inactive()
+        own_dp = inactive or isinstance(self.drop_path, DropPath)
+        train = dense.autocast_half_training(x)
         xres = x
         if xn1 is not None:
             xin = xn1
-        elif (dense.autocast_half_training(x) and x.requires_grad and dense.layer_norm_supported(x, self.norm1)
-              and isinstance(self.drop_path, nn.Identity)):
+        elif train and x.requires_grad and dense.layer_norm_supported(x, self.norm1) and own_dp:
             # training: LayerNorm and the bypass from one Function, so that its backward kernel also adds the bypass' gradient
             xin, xres = dense.layer_norm_res(x, self.norm1, torch.float16)
         else:
             xin = self._norm1(x)
-        if isinstance(self.drop_path, nn.Identity) and x.is_contiguous() and isinstance(self.attn, Attention):
-            a, added = self.attn(xin, residual=xres)
-            x = a if added else xres + a
+        if own_dp and x.is_contiguous() and isinstance(self.attn, Attention):
+            f_b, f_rows = self._depth_scale(x)
+            a, added = self.attn(xin, residual=xres, row_scale=f_rows)
+            if added:
+                x = a
+            else:
+                x = xres + (a if f_b is None else a * f_b.view(-1, 1, 1).to(a.dtype))
         else:
+            if x.is_cuda and torch.is_autocast_enabled():
+                _warn_fallback("block (attention half)", "config: foreign drop_path / attention module or non-contiguous input",
+                               x.shape)
             x = x + self.drop_path(self.attn(xin))
-        if (dense.autocast_half_training(x) and dense.layer_norm_supported(x, self.norm2)
-                and getattr(self.mlp, "forward_add", None) is not None):
+        if train and dense.layer_norm_supported(x, self.norm2) and getattr(self.mlp, "forward_add", None) is not None and own_dp:
             # training: HIP LayerNorm (f32 rows: the router routes on them) forward and backward, then the MoE operator's
-            # training path; without stochastic depth the residual add rides in the operator's combine
-            if isinstance(self.drop_path, nn.Identity) and x.requires_grad:
+            # training path; the residual add (and the stochastic-depth factor) rides in the operator's combine
+            f_b, f_rows = self._depth_scale(x)
+            if x.requires_grad:
                 xn, xres2 = dense.layer_norm_res(x, self.norm2, torch.float32)
-                return self.mlp.forward_add(xn, xres2)
+                return self.mlp.forward_add(xn, xres2, row_scale=f_rows)
             xn = dense.layer_norm(x, self.norm2, torch.float32)
-            if isinstance(self.drop_path, nn.Identity):
-                return self.mlp.forward_add(xn, x)
-            return x + self.drop_path(self.mlp(xn))
-        if isinstance(self.drop_path, nn.Identity):
+            return self.mlp.forward_add(xn, x, row_scale=f_rows)
+        if inactive:
             steps = getattr(self.mlp, "forward_norm_add_steps", None)
             if steps is not None:
                 # x + mlp(norm2(x)): LN + router, scatter, combine + add all fused
@@ -384,6 +462,8 @@ class Block(nn.Module):
             fused = getattr(self.mlp, "forward_add", None)
             if fused is not None:
                 return fused(self.norm2(x), x)  # x + mlp(norm2(x)), add fused into the MoE combine store
+        elif x.is_cuda and torch.is_autocast_enabled():
+            _warn_fallback("block (MLP half)", "config: stochastic depth active outside the fp16-autocast training path", x.shape)
         x = x + self.drop_path(self.mlp(self.norm2(x)))
         return x
 
@@ -499,6 +579,12 @@ class VisionTransformer(nn.Module):
                 cls = x[:, 0].contiguous()
                 if dense.layer_norm_supported(cls, self.norm):
                     return dense.layer_norm(cls, self.norm, torch.float32)
+            if (_autocast_half_inference(x) and x.dtype == torch.float32 and self.norm.elementwise_affine
+                    and x.shape[-1] in _LN_DIMS):
+                from . import ops
+                n = self.norm
+                return ops.layernorm(x[:, 0].contiguous(), n.weight.detach(), n.bias.detach() if n.bias is not None else None,
+                                     n.eps, torch.float32)
             return self.norm(x[:, 0])
         return self.norm(x)[:, 0]
 
@@ -613,11 +699,13 @@ class VisionTransformer(nn.Module):
                             hc.get(self.head.bias) if self.head.bias is not None else None)
         from . import dense
         if isinstance(self.head, nn.Linear) and f.dim() == 2 and dense.autocast_half_training(f) and DENSE_GEMM == "own":
-            f16 = f.to(torch.float16)
+            f16 = dense.cast16(f) if f.dtype == torch.float32 else f.contiguous()
             if dense.linear_supported(f16, self.head.weight):
                 return dense.LinearFn.apply(f16, self.head.weight, self.head.bias, None, _half_cache(self), torch.float16,
                                             "head_gemm")
-            _warn_fallback("head_gemm (training)", "the backward GEMMs need N % 64 == 0", (f.shape[0], f.shape[1], self.head.weight.shape[0]))
+            _warn_fallback("head_gemm (training)", "K % 64 != 0", (f.shape[0], f.shape[1], self.head.weight.shape[0]))
+        elif isinstance(self.head, nn.Linear) and f.is_cuda and torch.is_autocast_enabled():
+            _warn_fallback("head_gemm", "config: needs fp16 autocast and a [B, d] feature matrix", tuple(f.shape))
         return self.head(f)
 
 

@@ -1,0 +1,253 @@
+"""The reference's OWN default flags must land on the HIP path: main.py:74-79 `--drop-path 0.1` (DropPath in every block but the
+first, models/vision_transformer.py:308), ImageNet's 1000 classes (main.py:520-530, models/vision_transformer.py:847).  A model
+built that way evaluates bit for bit like the `drop_path_rate=0` model, trains with stochastic depth folded into the fused residual
+stores, and neither mode launches a vendor GEMM / attention / LayerNorm kernel or raises a SlimMoEFallbackWarning; configurations
+that DO leave the own kernels say so."""
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import slim_switch_moe_vit_amd as sm  # noqa: E402
+from slim_switch_moe_vit_amd import dense, vit  # noqa: E402
+from slim_switch_moe_vit_amd.vit import _HalfCache  # noqa: E402
+
+DEV = "cuda:0"
+AOTRITON = {"bwd_kernel_dk_dv", "bwd_kernel_dq", "bwd_preprocess", "attn_fwd"}           # exact symbol names
+TORCH_LN = ("layer_norm_grad_input_kernel", "cuComputePartGradGammaBeta", "vectorized_layer_norm_kernel")
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _rel(got, ref):
+    return float((got.double().cpu() - ref.double().cpu()).norm() / ref.double().cpu().norm().clamp(min=1e-30))
+
+
+def _vendor_symbols(names):
+    return [n for n in names if n.startswith("Cijk_") or n.startswith("Custom_Cijk") or n in AOTRITON
+            or any(v in n for v in TORCH_LN)]
+
+
+def _profiled(fn):
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        out = fn()
+        torch.cuda.synchronize()
+    return out, {e.key for e in prof.key_averages()}
+
+
+def _randomise(model, seed):
+    """Every parameter gets signal (the reference zero-initialises biases and the head: a zero head hides everything)."""
+    g = _gen(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("norm1.weight") or n.endswith("norm2.weight") or n == "norm.weight":
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+            elif "dense_gate" in n or "moe_gate" in n:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.5 if p.dim() > 1 else 0.1))
+            elif p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    return model
+
+
+def _pair(name, depth, **kw):
+    """(model with the reference's default stochastic depth, the same weights with rate 0)."""
+    torch.manual_seed(0)
+    a = _randomise(sm.create_model(name, depth=depth, drop_path_rate=0.1, num_classes=1000, **kw), 5)
+    b = sm.create_model(name, depth=depth, drop_path_rate=0.0, num_classes=1000, **kw)
+    b.load_state_dict(a.state_dict())
+    assert any(isinstance(blk.drop_path, vit.DropPath) for blk in a.blocks), "rate 0.1 builds DropPath modules"
+    assert all(isinstance(blk.drop_path, torch.nn.Identity) for blk in b.blocks)
+    return a.to(DEV), b.to(DEV)
+
+
+@pytest.mark.parametrize("name,kw", [("moe_base_patch16_224_expert8_top1", {}),
+                                     ("resmoe_base_patch16_224_expert8_top1", dict(starting_threshold=0.55, target_threshold=0.5)),
+                                     ("resmoe_tiny_patch16_224_expert8", dict(starting_threshold=0.55, target_threshold=0.5))])
+def test_default_drop_path_and_1000_classes_eval_on_own_kernels(name, kw):
+    a, b = _pair(name, 3, **kw)
+    a.eval(); b.eval()
+    images = torch.randn(4, 3, 224, 224, generator=_gen(9)).to(DEV)
+    vit._fallbacks_seen.clear()
+
+    def run(m):
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return m(images)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", vit.SlimMoEFallbackWarning)
+        out_b = run(b)
+        out_a, names = _profiled(lambda: run(a))
+    assert out_a.shape == (4, 1000)
+    assert torch.equal(out_a, out_b), "inactive stochastic depth must not change a bit"
+    assert not _vendor_symbols(names), _vendor_symbols(names)
+    assert any("attn_fwd_kernel" in n for n in names) and any("grouped_gemm" in n for n in names), names
+
+
+class _NaiveDropPath(torch.nn.Module):
+    """Stochastic depth the way timm's DropPath applies it (a FOREIGN module for the block: it takes the composed path), drawing
+    its per-sample mask exactly as Block._depth_scale does -- same generator, same order, same shape / dtype -- so a seeded
+    run of the fused path and of this one see the same masks."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        keep = 1.0 - self.p
+        f = torch.empty(x.shape[0], dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
+        return x * f.view(-1, *([1] * (x.dim() - 1))).to(x.dtype)
+
+
+def _train_step(model, images, target, backend="own", seed=123):
+    dense.TRAIN_BACKEND = backend
+    try:
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(seed)
+        with torch.autocast("cuda", dtype=torch.float16):
+            out = model(images)
+            loss = torch.nn.functional.cross_entropy(out.float(), target)
+        loss.backward()
+        return float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    finally:
+        dense.TRAIN_BACKEND = "own"
+
+
+def test_training_with_stochastic_depth_and_1000_classes_on_own_kernels():
+    """fwd + bwd under fp16 autocast (engine.py:52-74) of the default-flag model: the per-sample mask / keep factor rides on the
+    projection GEMM's and the MoE combine's row scale; loss and gradients equal the composed form (torch autocast ops + a DropPath
+    applied the naive way) under the same masks; no vendor kernel, no fallback warning; the 1000-class head trains on the own
+    GEMMs (N padded to 1024 in the backward)."""
+    import copy
+    a, _ = _pair("moe_base_patch16_224_expert8_top1", 3)
+    a.train()
+    ref = copy.deepcopy(a)
+    for blk in ref.blocks:
+        if isinstance(blk.drop_path, vit.DropPath):
+            blk.drop_path = _NaiveDropPath(0.5)
+    for blk in a.blocks:
+        if isinstance(blk.drop_path, vit.DropPath):
+            blk.drop_path.drop_prob = 0.5           # B = 6: make sure some samples ARE dropped
+    B = 6
+    images = torch.randn(B, 3, 224, 224, generator=_gen(11)).to(DEV)
+    target = torch.randint(0, 1000, (B,), generator=_gen(12)).to(DEV)
+    vit._fallbacks_seen.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", vit.SlimMoEFallbackWarning)
+        (l_own, g_own), names = _profiled(lambda: _train_step(a, images, target, "own"))
+    assert not _vendor_symbols(names), _vendor_symbols(names)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", vit.SlimMoEFallbackWarning)
+        l_ref, g_ref = _train_step(ref, images, target, "torch")
+    # the masks really dropped something, and both runs saw the same ones
+    torch.manual_seed(123)
+    draws = [torch.empty(B, device=DEV).bernoulli_(0.5) for _ in range(4)]
+    assert any(float(d.min()) == 0.0 for d in draws)
+    assert abs(l_own - l_ref) <= 2e-3 * max(1.0, abs(l_ref)), (l_own, l_ref)
+    assert set(g_own) == set(g_ref)
+    worst = max((_rel(g_own[n], g_ref[n]), n) for n in g_ref if float(g_ref[n].abs().max()) > 0)
+    print(f"stochastic depth: loss {l_own:.5f} vs {l_ref:.5f}; worst relative L2 gradient difference {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] <= 3e-2, worst
+    assert a.head.weight.grad.shape == (1000, 768) and float(a.head.weight.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("M,K,N", [(777, 768, 768), (256, 192, 192)])
+def test_linear_function_row_scale_forward_and_backward(M, K, N):
+    """residual + s[r] * (x W^T + b)[r] against float64 autograd; s = 0 rows reproduce the residual exactly."""
+    g = _gen(M + N)
+    x = torch.randn(M, K, generator=g).half()
+    w, b = torch.randn(N, K, generator=g) * 0.03, torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g)
+    s = (torch.rand(M, generator=g) < 0.6).float() / 0.6
+    dy = torch.randn(M, N, generator=g) * 0.05
+    xr, wr, br = x.double().requires_grad_(True), w.half().double().requires_grad_(True), b.double().requires_grad_(True)
+    rr = r.double().requires_grad_(True)
+    yr = rr + s.double()[:, None] * torch.nn.functional.linear(xr, wr, br)
+    yr.backward(dy.double())
+    lin = torch.nn.Linear(K, N).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    xg, rg = x.to(DEV).requires_grad_(True), r.to(DEV).requires_grad_(True)
+    y = dense.LinearFn.apply(xg, lin.weight, lin.bias, rg, _HalfCache(), torch.float32, "test_gemm", s.to(DEV))
+    assert _rel(y, yr.detach()) <= 1e-3
+    dropped = (s == 0).to(DEV)
+    assert torch.equal(y[dropped], rg.detach()[dropped]), "a dropped sample's rows are the residual, bit for bit"
+    y.backward(dy.to(DEV))
+    assert _rel(xg.grad, xr.grad) <= 2e-3 and _rel(lin.weight.grad, wr.grad) <= 2e-3 and _rel(lin.bias.grad, br.grad) <= 2e-3
+    assert torch.equal(rg.grad, dy.to(DEV))
+
+
+@pytest.mark.parametrize("N", [1000, 10, 100])
+def test_linear_function_pads_the_class_count_in_the_backward(N):
+    M, K = 96, 768
+    g = _gen(N)
+    x = torch.randn(M, K, generator=g).half()
+    w, b = torch.randn(N, K, generator=g) * 0.03, torch.randn(N, generator=g) * 0.1
+    dy = (torch.randn(M, N, generator=g) * 0.05).half()
+    xr, wr, br = x.double().requires_grad_(True), w.half().double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(dy.double())
+    lin = torch.nn.Linear(K, N).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    xg = x.to(DEV).requires_grad_(True)
+    assert dense.linear_supported(xg, lin.weight)
+    y = dense.LinearFn.apply(xg, lin.weight, lin.bias, None, _HalfCache(), torch.float16, "head_gemm")
+    assert y.shape == (M, N) and _rel(y, yr.detach()) <= 1e-3
+    y.backward(dy.to(DEV))
+    assert lin.weight.grad.shape == (N, K)
+    assert _rel(xg.grad, xr.grad) <= 2e-3 and _rel(lin.weight.grad, wr.grad) <= 2e-3 and _rel(lin.bias.grad, br.grad) <= 2e-3
+
+
+def test_moe_forward_add_row_scale_equals_the_composed_form():
+    d, h, E, T = 192, 768, 4, 999
+    torch.manual_seed(3)
+    mod = sm.CustomizedMoEMLP(d, h, E, 2, 0.0).to(DEV).train()
+    x = torch.randn(T, d, generator=_gen(1)).to(DEV)
+    res = torch.randn(T, d, generator=_gen(2)).to(DEV)
+    s = ((torch.rand(T, generator=_gen(3)) < 0.7).float() / 0.7).to(DEV)
+    dy = torch.randn(T, d, generator=_gen(4)).to(DEV)
+
+    def run(fused):
+        mod.zero_grad(set_to_none=True)
+        xg, rg = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        out = mod.forward_add(xg, rg, row_scale=s) if fused else rg + s[:, None] * mod(xg)
+        out.backward(dy)
+        return out.detach(), xg.grad, rg.grad, {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+    o1, dx1, dr1, g1 = run(True)
+    o2, dx2, dr2, g2 = run(False)
+    assert _rel(o1, o2) <= 1e-6 and _rel(dx1, dx2) <= 2e-3 and torch.equal(dr1, dr2)
+    assert set(g1) == set(g2)
+    for n in g1:
+        assert _rel(g1[n], g2[n]) <= 2e-3, n
+
+
+def test_config_fallbacks_are_loud():
+    """What still leaves the own kernels BY CONFIGURATION says so, once: a foreign drop_path module, attention dropout in
+    training, the composed residual-MoE block under autocast."""
+    torch.manual_seed(0)
+    model = sm.create_model("moe_tiny_patch16_224_expert4_top1", depth=1, num_classes=64).to(DEV).train()
+    model.blocks[0].drop_path = _NaiveDropPath(0.1)
+    images = torch.randn(2, 3, 224, 224, generator=_gen(1)).to(DEV)
+    vit._fallbacks_seen.clear()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always", vit.SlimMoEFallbackWarning)
+        with torch.autocast("cuda", dtype=torch.float16):
+            model(images).float().sum().backward()
+    msgs = [str(w.message) for w in rec if issubclass(w.category, vit.SlimMoEFallbackWarning)]
+    assert any("block (attention half)" in m for m in msgs), msgs
+    model = sm.create_model("moe_tiny_patch16_224_expert4_top1", depth=1, num_classes=64, attn_drop_rate=0.1).to(DEV).train()
+    vit._fallbacks_seen.clear()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always", vit.SlimMoEFallbackWarning)
+        with torch.autocast("cuda", dtype=torch.float16):
+            model(images).float().sum().backward()
+    msgs = [str(w.message) for w in rec if issubclass(w.category, vit.SlimMoEFallbackWarning)]
+    assert any("dropout" in m for m in msgs), msgs
