@@ -227,3 +227,123 @@ def test_resmoe_model_fused_path_matches_oracle_and_composed_path(name, heads):
         comp = model(images.to(DEV)).float().cpu()
     assert (comp - ref).abs().max().item() <= 5e-2
     assert (out - comp).abs().max().item() <= 5e-2
+
+
+# ---- against outputs of the reference's OWN code (tests/golden/make_golden_resmoe.py: models/resMoE.py:32-85, 126-145) ----------
+import os  # noqa: E402
+
+F32_EPS = float(np.finfo(np.float32).eps)
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _fixture(name):
+    return {k: v for k, v in np.load(os.path.join(GOLDEN, name)).items()}
+
+
+def _gate_from_fixture(g, is_hard=True):
+    gate = sm.Gate(192, 1.0, target_threshold=float(g["thr_eval"]), starting_threshold=float(g["thr_train"]), is_hard=is_hard)
+    with torch.no_grad():
+        gate.head[1].weight.copy_(torch.from_numpy(g["w"])); gate.head[1].bias.copy_(torch.from_numpy(g["b"]))
+    return gate.to(DEV)
+
+
+def _explained(ours_skip, ref_mask, prob_f32, thr):
+    """Tokens whose decision differs from the reference's ``sigmoid_f32(z_f32) > thr``: each within 4 f32 ulp of the threshold."""
+    ref_skip = np.rint(ref_mask[..., 0]).astype(bool).reshape(-1)
+    differ = np.nonzero(ours_skip.reshape(-1) != ref_skip)[0]
+    gaps = [(int(t), float(prob_f32.reshape(-1)[t]) - float(np.float32(thr))) for t in differ]
+    for t, gap in gaps:
+        assert abs(gap) <= 4 * F32_EPS * max(float(thr), 0.25), (t, gap)
+    return gaps
+
+
+def test_hip_gate_against_the_reference_gate_fixture():
+    """The HIP ``Gate`` (smoe_gate_ln_router) in eval and disabled mode against the reference ``Gate``'s own outputs on rows placed
+    within a few f32 ulp of the threshold: decisions equal except tokens whose f32 sigmoid is within rounding of the threshold
+    (listed; the kernel decides on the f64-accurate logit), masks exactly 0 / 1 where the reference is within one ulp of that, the
+    device counter = the number of skipped tokens."""
+    g = _fixture("ref_gate_tiny.npz")
+    x = torch.from_numpy(g["x"]).to(DEV)
+    gate = _gate_from_fixture(g).eval()
+    with torch.no_grad():
+        m = gate(x).cpu().numpy()
+    assert np.all((m == 0) | (m == 1)) and np.all(m.sum(-1) == 1)
+    flips = _explained(m[..., 0] > 0.5, g["eval_mask"], g["prob_f32"], g["thr_eval"])
+    print(f"HIP gate, eval: {int(m[..., 0].sum())} skipped (reference {g['eval_skipped']}), decisions that differ: {flips}")
+    assert len(flips) <= len(g["near_rows_eval"])
+    same = np.ones(m.shape[0] * m.shape[1], dtype=bool)
+    same[[t for t, _ in flips]] = False
+    assert np.array_equal(m.reshape(-1, 2)[same], np.rint(g["eval_mask"]).reshape(-1, 2)[same])
+    assert gate._total_tokens == int(g["eval_total"]) and gate._skipped_tokens == float(m[..., 0].sum())
+    assert abs(gate._skipped_tokens - float(g["eval_skipped"])) <= len(flips) + 1e-3
+    # the oracle takes the same decisions as the kernel (both on the f64 logit): bit for bit
+    ref_o = mo.skip_gate(torch.from_numpy(g["x"]), torch.from_numpy(g["w"]), torch.from_numpy(g["b"]), float(g["thr_eval"]))
+    assert np.array_equal(m, ref_o.numpy())
+    gate.disable = True
+    with torch.no_grad():
+        assert np.array_equal(gate(x).cpu().numpy(), g["disabled_mask"])
+
+
+def _block_from_fixture(g, compute_dtype=None):
+    """A Block wired as the reference's factory wires it (models/resMoE.py:163-186), holding the fixture's parameters; the
+    dense ``Mlp`` of the fixture is the single expert of an E = 1, top-1 ``CustomizedMoEMLP``."""
+    from slim_switch_moe_vit_amd.vit import Block
+    from slim_switch_moe_vit_amd.resmoe import forward_residule_moe
+    from functools import partial
+    d, heads = 192, int(g["num_heads"])
+    blk = Block(d, heads, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    blk.dense_gate = sm.Gate(d, 1.0, target_threshold=0.55, starting_threshold=0.6)
+    blk.moe_gate = sm.Gate(d, 1.0, target_threshold=0.55, starting_threshold=0.6)
+    kw = {"compute_dtype": compute_dtype} if compute_dtype is not None else {}
+    blk.mlp = sm.CustomizedMoEMLP(d, 4 * d, 1, 1, 0.0, **kw)
+    blk.forward = forward_residule_moe.__get__(blk, Block)
+    p = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p.")}
+    sd = {k: v for k, v in p.items() if not k.startswith("mlp.")}
+    sd["mlp.gate.gate.weight"], sd["mlp.gate.gate.bias"] = torch.zeros(1, d), torch.zeros(1)
+    sd["mlp.experts.htoh4.weight"], sd["mlp.experts.htoh4.bias"] = p["mlp.fc1.weight"][None], p["mlp.fc1.bias"][None]
+    sd["mlp.experts.h4toh.weight"], sd["mlp.experts.h4toh.bias"] = p["mlp.fc2.weight"][None], p["mlp.fc2.bias"][None]
+    missing, unexpected = blk.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    return blk.to(DEV)
+
+
+@pytest.mark.parametrize("mode", ["fused_fp16_autocast", "composed_f32"])
+def test_residual_block_against_the_reference_forward_residule_moe_fixture(mode):
+    """``forward_residule_moe`` on the HIP path against the output of the reference's own function run on reference modules
+    (models/resMoE.py:126-145; LayerNorm, layers.Attention, layers.Mlp = the E = 1 MoE, two Gates skipping 40-50 %): the fused
+    fp16-autocast inference path (``_residual_block_fused``: two LayerNorm + gate passes, qkv / attention / projection, the MoE
+    GEMMs adding into the residual image) to fp16 rounding, and the module-composed f32 path (HIP gate + f32-operand MoE operator)
+    to 1e-4; both take the reference's decision on every token."""
+    from slim_switch_moe_vit_amd import resmoe
+    g = _fixture("ref_resblock_tiny.npz")
+    x = torch.from_numpy(g["x"]).to(DEV)
+    ref = torch.from_numpy(g["eval_y"])
+    fused = mode == "fused_fp16_autocast"
+    blk = _block_from_fixture(g, None if fused else torch.float32).eval()
+    calls = {"fused": 0}
+    orig = resmoe._residual_block_fused
+
+    def spy(b, t):
+        calls["fused"] += 1
+        return orig(b, t)
+    resmoe._residual_block_fused = spy
+    try:
+        with torch.no_grad():
+            if fused:
+                with torch.autocast("cuda", dtype=torch.float16):
+                    y = blk(x)
+            else:
+                y = blk(x)
+    finally:
+        resmoe._residual_block_fused = orig
+    assert calls["fused"] == (1 if fused else 0)
+    T = x.shape[0] * x.shape[1]
+    for gt, key in ((blk.dense_gate, "eval_dense_mask"), (blk.moe_gate, "eval_moe_mask")):
+        assert gt._total_tokens == T
+        # the skip counts are the reference's: no decision differs on this fixture (none of its rows sits on the threshold)
+        assert gt._skipped_tokens == float(np.rint(g[key])[..., 0].sum()), key
+    diff = (y.float().cpu() - ref)
+    scale = max(1.0, float(ref.abs().max()))
+    tol = 6e-3 if fused else 1e-4
+    print(f"{mode}: max |y - reference| = {float(diff.abs().max()):.3e} (scale {scale:.2f}), rel L2 {float(diff.norm() / ref.norm()):.2e}")
+    assert float(diff.abs().max()) <= tol * scale and float(diff.norm() / ref.norm()) <= tol

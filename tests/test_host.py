@@ -226,6 +226,50 @@ def test_gate_threshold_schedule_and_counters_on_cpu():
     assert gate._skipped_tokens == 0
 
 
+def test_gate_module_cpu_composition_against_the_reference_gate_fixture(golden_dir):
+    """The ``Gate`` module's differentiable composition (what CPU tensors take) against outputs AND gradients of the reference's own
+    ``Gate`` (models/resMoE.py:59-85; tests/golden/make_golden_resmoe.py) in eval, train-hard (straight-through: d mask / d p = +1
+    / -1), train-soft ((1 - p, p)) and disabled mode, and the ``step`` schedule (53-57).  This path compares the f32 sigmoid as the
+    reference does: every decision is the reference's, incl. the rows engineered onto the threshold."""
+    import os
+    import numpy as np
+    g = {k: v for k, v in np.load(os.path.join(golden_dir, "ref_gate_tiny.npz")).items()}
+    x, dret = torch.from_numpy(g["x"]), torch.from_numpy(g["dret"])
+
+    def make(is_hard=True):
+        gate = sm.Gate(192, 1.0, target_threshold=float(g["thr_eval"]), starting_threshold=float(g["thr_train"]), is_hard=is_hard)
+        with torch.no_grad():
+            gate.head[1].weight.copy_(torch.from_numpy(g["w"])); gate.head[1].bias.copy_(torch.from_numpy(g["b"]))
+        return gate
+    gate = make().eval()
+    with torch.no_grad():
+        m = gate(x)
+    assert np.array_equal(m.numpy(), np.rint(g["eval_mask"])) and np.abs(m.numpy() - g["eval_mask"]).max() <= 1.2e-7
+    assert gate._total_tokens == int(g["eval_total"]) and gate._skipped_tokens == float(np.rint(g["eval_mask"])[..., 0].sum())
+    for mode, hard in (("train_hard", True), ("train_soft", False)):
+        gate = make(hard).train()
+        xg = x.clone().requires_grad_(True)
+        m = gate(xg)
+        m.backward(dret)
+        assert np.abs(m.detach().numpy() - g[f"{mode}_mask"]).max() <= 1.2e-7, mode
+        if hard:
+            assert np.array_equal(m.detach().numpy(), np.rint(g[f"{mode}_mask"]))
+        for got, key in ((xg.grad, "dx"), (gate.head[1].weight.grad, "dw"), (gate.head[1].bias.grad, "db")):
+            ref = torch.from_numpy(g[f"{mode}_{key}"])
+            assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6 * max(1.0, float(ref.abs().max()))), (mode, key)
+        assert gate._total_tokens == int(g[f"{mode}_total"])
+        assert abs(gate._skipped_tokens - float(g[f"{mode}_skipped"])) <= 1e-3 * max(1.0, float(g[f"{mode}_skipped"]))
+    gate = make()
+    gate.disable = True
+    assert np.array_equal(gate(x).detach().numpy(), g["disabled_mask"])
+    gate = make()
+    seq = []
+    for _ in range(4):
+        gate.step(torch.tensor(0.04))
+        seq.append(float(gate._threshold))
+    assert np.allclose(seq, g["step_sequence"], rtol=0, atol=1e-7), (seq, g["step_sequence"])
+
+
 def test_multi_tensor_block_table_and_wgrad_round_model():
     """Host-side tables of the round's launch-count work: the workgroup -> (tensor, 16K block) map of the multi-tensor optimizer
     kernels, and the cost model that picks the weight-gradient tile height / orientation."""
