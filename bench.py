@@ -5,6 +5,7 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...          (no launcher: starts the N ranks itself as child processes and relays rank 0's line)
 
 A step = one eval-mode forward of the whole model over one batch of synthetic images already resident in
 HBM (reference harness: engine.py:88-121 -- eval(), no_grad, fp16 autocast).  The MoE operator (router,
@@ -175,9 +176,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # started the way the N = 1 bench is started: launch the N ranks ourselves, as CHILD processes, before this process
+        # has touched the GPU (never re-exec a process that initialised it), relay their output and exit with their code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.run(cmd, env=env)
+        sys.exit(proc.returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X"

@@ -112,13 +112,20 @@ def source_build_id() -> str:
     """sha256 (first 16 hex digits) over the library's sources as they lie in the tree -- what ``smoe_build_id()`` of a
     binary built from them returns.  None if the sources are not there (a binary-only install)."""
     import hashlib
+    import re
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, "csrc")
     try:
         for name in sorted(_HASHED):   # GNU make's $(sort) and Python's sorted() agree on these ASCII names
             with open(os.path.join(csrc, name), "rb") as f:
                 h.update(f.read())
-    except OSError:
+        # the production flags line, as the Makefile expands it with its defaults (ARCH = gfx950, DIAG empty)
+        mk = open(os.path.join(csrc, "Makefile")).read()
+        flags = re.search(r"^CXXFLAGS\s*=\s*(.*)$", mk, re.M).group(1)
+        arch = re.search(r"^ARCH\s*\?=\s*(\S+)", mk, re.M).group(1)
+        flags = flags.replace("$(ARCH)", arch).replace("$(DIAG)", "")
+        h.update((" ".join(flags.split()) + "\n").encode())
+    except (OSError, AttributeError):
         return None
     return h.hexdigest()[:16]
 

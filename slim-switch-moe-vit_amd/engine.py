@@ -9,6 +9,19 @@ from typing import Iterable, Tuple
 import torch
 
 
+def _size_static_exchange(model: torch.nn.Module, data_loader) -> None:
+    """Expert-parallel capacity gates exchange through buffers sized for the largest batch (ep.static_slot_tokens): the loader
+    knows it a priori -- ``batch_size`` images x the model's tokens per image, the same on every rank -- so the harness sets it
+    before the first forward instead of letting the first batch decide (a small first batch would under-size the slots)."""
+    bs = getattr(data_loader, "batch_size", None)
+    pos = getattr(model, "pos_embed", None)
+    if bs is None or pos is None or not any(getattr(m, "ep_active", lambda: False)() for m in model.modules()
+                                            if hasattr(m, "ep_active")):
+        return
+    from .ep import set_static_tokens
+    set_static_tokens(model, int(bs) * int(pos.shape[1]))
+
+
 def accuracy(output: torch.Tensor, target: torch.Tensor, topk=(1,)):
     """timm.utils.accuracy: top-k accuracy in percent."""
     maxk = min(max(topk), output.shape[1])
@@ -23,6 +36,7 @@ def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: to
     criterion = torch.nn.CrossEntropyLoss()
     model.eval()
     dev = torch.device(device)
+    _size_static_exchange(model, data_loader)
     n, loss_sum, a1, a5 = 0, 0.0, 0.0, 0.0
     t0 = time.perf_counter()
     for images, target in data_loader:
@@ -37,6 +51,8 @@ def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: to
         loss_sum += loss.item() * bs
         a1 += acc1.item() * bs
         a5 += acc5.item() * bs
+        from .ep import check_static_overflow
+        check_static_overflow(flush=True)     # (the .item() above already waited for the batch)
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
@@ -60,7 +76,7 @@ def _criterion_takes_inputs(criterion) -> bool:
 def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]],
                     optimizer: torch.optim.Optimizer, device, epoch: int, loss_scaler, max_norm=None, model_ema=None,
                     mixup_fn=None, set_training_mode=True, args=None, *, aux_loss_weight: float = 0.0, gate_delta=None,
-                    autocast: bool = True):
+                    autocast: bool = True, check_every: int = 50):
     """The reference's training loop body (engine.py:22-85) around the HIP path, with the reference's positional
     parameters in the reference's order (main.py:825-838 calls it positionally: ``model_ema`` and ``mixup_fn`` sit in
     positions 9 and 10): autocast forward, criterion, ``loss_scaler(loss, optimizer, clip_grad=max_norm,
@@ -74,9 +90,12 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
     does after the epoch's steps); ``autocast``.
 
     The reference aborts on a non-finite loss by reading ``loss.item()`` in every step (engine.py:56-60: one host sync per
-    step).  Here the check is a device-side count read ONCE at the end of the epoch: the same abort (``SystemExit(1)``
-    after the message), an epoch late at worst, and no step of it trains on garbage meanwhile when the scaler is an
-    ``optim.NativeScaler`` (a non-finite gradient skips the update).  The metric logger is driver plumbing (out of scope).
+    step), BEFORE the optimizer step and the EMA update.  Here the check is a device-side count read every ``check_every`` steps
+    (default 50) and at the end of the epoch: the same abort (``SystemExit(1)`` after the message), at most ``check_every`` steps
+    late.  What runs meanwhile is gated: an enabled ``optim.NativeScaler`` skips the update on a non-finite gradient by itself; with any
+    other (or a disabled) scaler, or with a ``model_ema`` (whose update is a host call that cannot be skipped from the device), the loss is read
+    in EVERY step, as the reference does, so no weight, EMA or checkpoint ever absorbs a non-finite step.  The metric logger is
+    driver plumbing (out of scope).
     Returns {"loss": mean loss, "steps": n, "lr": first group's lr}."""
     from .fmoe import FMoETransformerMLP
     from .resmoe import Gate
@@ -85,6 +104,11 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
     dev = torch.device(device)
     moes = [m for m in model.modules() if isinstance(m, FMoETransformerMLP)]
     with_inputs = _criterion_takes_inputs(criterion)
+    _size_static_exchange(model, data_loader)
+    from .optim import NativeScaler as _OwnScaler
+    every_step = model_ema is not None or not (isinstance(loss_scaler, _OwnScaler) and loss_scaler.enabled)
+    if every_step:
+        check_every = 1
     bce = bool(getattr(args, "bce_loss", False)) if args is not None else False
     loss_sum, bad, n = torch.zeros((), device=dev), torch.zeros((), device=dev), 0
     for samples, targets in data_loader:
@@ -102,20 +126,28 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
                     aux = m.gate.get_loss()
                     if aux is not None:
                         loss = loss + aux_loss_weight * aux
+        lv = loss.detach().float()
+        finite = torch.isfinite(lv)
+        if every_step and not bool(finite):           # the reference's order: abort before the step and the EMA update
+            print(f"Loss is {float(lv)}, stopping training")
+            raise SystemExit(1)
         optimizer.zero_grad()
         is_second_order = hasattr(optimizer, "is_second_order") and optimizer.is_second_order
         loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=is_second_order)
         if model_ema is not None:
             model_ema.update(model)
-        lv = loss.detach().float()
-        finite = torch.isfinite(lv)
         loss_sum += torch.where(finite, lv, torch.zeros_like(lv))
         bad += (~finite).to(bad.dtype)
         n += 1
+        if check_every > 1 and n % check_every == 0 and int(bad):
+            print(f"Loss is non-finite in {int(bad)} of {n} steps, stopping training")
+            raise SystemExit(1)
     if gate_delta is not None:
         for m in model.modules():
             if isinstance(m, Gate):
                 m.step(gate_delta)
+    from .ep import check_static_overflow
+    check_static_overflow(flush=True)
     n_bad = int(bad)                          # the epoch's host read (with the mean below)
     if n_bad:
         print(f"Loss is non-finite in {n_bad} of {n} steps, stopping training")

@@ -204,52 +204,146 @@ def drain(gen):
 _starts_cache = StreamCache()
 
 
+class StaticExchangeOverflow(RuntimeError):
+    """A rank brought more rows than the static exchange buffers were agreed for.  Raised on EVERY rank of the group, at the same
+    point of the program (check_static_overflow), never by one rank alone in front of a collective."""
+
+
+def _control_tensor(values, group, device) -> torch.Tensor:
+    """A small int64 tensor for a control-plane collective on this group's transport (gloo cannot take CUDA tensors)."""
+    on_cpu = (not torch.device(device).type == "cuda") or (dist.is_initialized() and dist.get_backend(group) == "gloo")
+    return torch.tensor(values, dtype=torch.int64, device="cpu" if on_cpu else device)
+
+
 def static_slot_tokens(mod, T: int, device) -> int:
     """The row count T_slot the static exchange buffers of ``mod`` are sized for (every (source rank, expert) slot holds
-    capacity(T_slot) rows).  It must be the same on every rank, whatever each rank's own batch is, and it must be known
-    WITHOUT communication once training runs -- so it is agreed once: the first expert-parallel forward of the module
-    all-gathers the ranks' row counts and keeps the largest (every rank runs the same layers in the same order, so this
-    one collective matches); later batches must fit (a smaller batch leaves its slots emptier; a larger one raises: call
-    ``mod.ep_static_tokens = n`` on every rank before the first forward to size the buffers for the largest batch)."""
+    capacity(T_slot) rows).  It must be the same on every rank, whatever each rank's own batch is, and it must be known WITHOUT
+    communication once the job runs -- so it is agreed ONCE per module, on its first expert-parallel forward, by a collective
+    EVERY rank runs unconditionally (all ranks run the same layers in the same order, so it matches): an all-gather of
+    (preset ``ep_static_tokens`` or -1, this rank's row count).  No preset anywhere: the largest row count wins.  The same preset
+    everywhere (``set_static_tokens`` / ``mod.ep_static_tokens = n`` on every rank, e.g. from the loader's batch size): that value.
+    Presets that differ between ranks: every rank raises the same error.  Later batches must fit; one that does not is reported by
+    ``check_static_overflow`` on all ranks together (never by the overflowing rank alone: that deadlocked its peers)."""
+    st = mod.__dict__.get("_ep_static_agreed")
+    if st is not None:
+        return st
     have = getattr(mod, "ep_static_tokens", None)
-    if have is None:
-        if mod.world_size > 1:
-            group = mod.moe_group
-            mine = torch.tensor([T], dtype=torch.int64, device=device if dist.get_backend(group) != "gloo" else "cpu")
-            got = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
-            dist.all_gather(got, mine, group=group)
-            have = max(int(t) for t in got)
+    if mod.world_size > 1:
+        group = mod.moe_group
+        mine = _control_tensor([-1 if have is None else int(have), int(T)], group, device)
+        got = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(got, mine, group=group)
+        presets = sorted({int(t[0]) for t in got})
+        if presets == [-1]:
+            agreed = max(max(int(t[1]) for t in got), 1)
+        elif len(presets) == 1:
+            agreed = max(presets[0], 1)
         else:
-            have = T
-        mod.ep_static_tokens = have
-    if T > have:
-        if mod.world_size == 1:          # nobody to agree with: grow
-            mod.ep_static_tokens = have = T
-        else:
-            raise RuntimeError(f"expert-parallel static exchange: this rank brings {T} rows, the buffers were agreed for {have}; "
-                               "set `ep_static_tokens` on every rank's module to the largest local batch's row count")
-    return have
+            raise RuntimeError(f"expert-parallel static exchange: `ep_static_tokens` differs between ranks ({presets}; -1 = not set): "
+                               "set the same value on every rank's module, or on none")
+    else:
+        agreed = max(int(have) if have is not None else int(T), 1)
+    mod.ep_static_tokens = agreed
+    mod.__dict__["_ep_static_agreed"] = agreed
+    return agreed
 
 
-def static_exchange_supported(mod, T: int, cap: int, cd, device) -> bool:
-    """The capacity-padded exchange needs the padded plan (E <= 64 groups of the fused plan kernel) and the persistent GEMM's
-    separate row ranges (at most 63 row groups, 16-bit operands); SLIMMOE_EP_STATIC=0 switches it off (A/B)."""
+def set_static_tokens(model: torch.nn.Module, rows: int) -> int:
+    """Size the static exchange buffers of every expert-parallel MoE module of ``model`` for batches of up to ``rows`` token rows
+    per rank (call it with the same value on every rank BEFORE the first forward -- engine.evaluate / train_one_epoch do, from
+    the loader's batch size -- or again later, on every rank, to re-size).  Returns the number of modules touched."""
+    n = 0
+    for m in model.modules():
+        if hasattr(m, "ep_active") and hasattr(m, "gate") and hasattr(m, "experts"):
+            m.ep_static_tokens = int(rows)
+            m.__dict__.pop("_ep_static_agreed", None)
+            n += 1
+    return n
+
+
+def use_static_exchange(mod, cd) -> bool:
+    """Static (capacity-padded) or dynamic (count read-back + all-to-all-v) exchange?  The two issue DIFFERENT collectives, so the
+    choice may only depend on what all ranks share -- the module's configuration -- never on a rank's own batch: a capacity gate
+    (E <= 63 groups of the fused plan kernel and of the persistent GEMM's row ranges), 16-bit operands, the persistent GEMM,
+    the fused GELU activation without dropout.  SLIMMOE_EP_STATIC=0 switches it off (A/B; set it on every rank)."""
     if os.environ.get("SLIMMOE_EP_STATIC", "1") == "0":
         return False
-    E_tot = mod.gate.tot_expert
-    return (E_tot <= 63 and (-(-T * mod.top_k // 1024)) * E_tot <= 8192 and mod.gemm_variant in (9, 10, 11, 12, 13, 14)
+    g = mod.gate
+    return (g.capacity(1 << 20) >= 0 and g.tot_expert <= 63 and mod.gemm_variant in (9, 10, 11, 12, 13, 14)
             and cd in (torch.float16, torch.bfloat16) and mod.d_model % 64 == 0 and mod.d_hidden % 64 == 0 and mod._fused_gelu
             and not (mod._drop_p > 0 and mod.training))
 
 
-def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual, next_norm=None):
+def static_plan_fits(mod, agreed: int) -> bool:
+    """The fused padded-plan kernel's table limit, evaluated on the AGREED row count (the same on every rank)."""
+    return (-(-agreed * mod.top_k // 1024)) * mod.gate.tot_expert <= 8192
+
+
+# ---- overflow watch: every rank learns every rank's row count with the count exchange; the check is deferred so that it never
+#      makes the host wait for the GPU (the static path's point), and it is deterministic so that all ranks raise together ------
+OVERFLOW_LAG = 32          # exchanges between posting a row-count vector and reading it on the host
+_overflow_pending = []     # [(event | None, host int32 [W], agreed, module)]
+
+
+def _watch_overflow(peer_rows: torch.Tensor, agreed: int, mod) -> None:
+    if peer_rows.is_cuda:
+        host = _pinned.take(peer_rows.shape, peer_rows.dtype)
+        host.copy_(peer_rows, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _overflow_pending.append((ev, host, agreed, mod, True))
+    else:
+        _overflow_pending.append((None, peer_rows.clone(), agreed, mod, False))
+
+
+def check_static_overflow(flush: bool = False) -> None:
+    """Reads the row-count vectors posted at least OVERFLOW_LAG exchanges ago (all of them with ``flush``: the harness calls that
+    at the end of a step).  Every rank holds the SAME vectors and runs the same sequence of exchanges, so every rank raises
+    StaticExchangeOverflow at the same call -- after re-sizing the module for the largest batch seen, so that repeating the
+    step (on every rank) works.  The outputs computed since the overflowing forward are void: that rank dropped the rows
+    that did not fit its slots to keep its buffers' agreed shape."""
+    while _overflow_pending and (flush or len(_overflow_pending) > OVERFLOW_LAG):
+        ev, host, agreed, mod, pooled = _overflow_pending.pop(0)
+        if ev is not None:
+            ev.synchronize()
+        worst = int(host.max()) if host.numel() else 0
+        rows = host.tolist()
+        if pooled:
+            _pinned.give(host)
+        if worst > agreed:
+            _overflow_pending.clear()
+            mod.ep_static_tokens = worst
+            mod.__dict__["_ep_static_agreed"] = worst
+            raise StaticExchangeOverflow(
+                f"expert-parallel static exchange: the ranks brought {rows} rows, the buffers were agreed for {agreed}; the "
+                f"outputs since then are void.  The module is now sized for {worst}: repeat the step on every rank, or call "
+                "ep.set_static_tokens(model, rows) with the largest local batch's row count on every rank before the first forward")
+
+
+def exchange_counts_static(counts: torch.Tensor, T: int, W: int, group=None):
+    """The static path's count exchange, device to device: rank r sends [E_local counts for peer w | its own row count T] to
+    every peer w.  Returns (recv_counts i32 [W * E_local] in [source rank][local expert] order, peer_rows i32 [W] = every rank's
+    row count -- identical on all ranks).  Nobody on the host reads the counts; peer_rows feeds the overflow watch."""
+    E_local = counts.numel() // W
+    both = torch.empty((2, W, E_local + 1), dtype=torch.int32, device=counts.device)
+    both[0, :, :E_local].copy_(counts.view(W, E_local))
+    both[0, :, E_local].fill_(int(T))
+    _a2a(both[1], both[0], group=group)
+    return both[1, :, :E_local].reshape(-1), both[1, :, E_local]
+
+
+def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual, next_norm=None, agreed: Optional[int] = None):
     """Expert-parallel forward of a CAPACITY gate on static buffers ("cfg 5 (capacity-bounded) can use
     fixed-size padded buffers -> no host sync"; Appendix B's `cap` note).  A rank keeps at most `cap` of its rows per
     global expert, so every (source rank, expert) pair owns a fixed slot of `slot` >= `cap` rows (the capacity of the row
     count all ranks agreed on, static_slot_tokens): the send buffer is [W, E_local, slot, d], both all-to-alls have EQUAL
     splits known without looking at the routing, and nothing of the layer
     waits for the host -- the received counts stay on the device, where the grouped GEMM takes them as the end of each slot's
-    row range (group_end) and never schedules a tile over padding.  Yields at the two exchanges (micro-batch pipelining)."""
+    row range (group_end) and never schedules a tile over padding.  Yields at the two exchanges (micro-batch pipelining).
+
+    A rank with NO rows takes the same path with empty slots.  A rank with MORE rows than agreed keeps the agreed buffer shape
+    (it drops what does not fit a slot; its peers must not hang) and the violation is raised on every rank by
+    check_static_overflow -- never here, by this rank alone."""
     from . import ops
     from .fmoe import SwitchGate
 
@@ -258,16 +352,36 @@ def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual, n
     group = mod.moe_group
     T = x.shape[0]
     E_tot = g.tot_expert
-    slot = max(cap, g.capacity(static_slot_tokens(mod, T, x.device)))
-    counts, offsets, gend, pos_pad, inv_pos, pruned = ops.dispatch_plan_padded(idx, E_tot, cap, slot)
+    if agreed is None:
+        agreed = static_slot_tokens(mod, T, x.device)
+    slot = max(1, g.capacity(agreed))
+    cap_eff = min(cap, slot)
+    if T > 0 and cap_eff >= 1 and T <= agreed:
+        counts, offsets, gend, pos_pad, inv_pos, pruned = ops.dispatch_plan_padded(idx, E_tot, cap_eff, slot)
+    elif T > 0 and cap_eff >= 1:
+        # over the agreed size: the plan over the first `agreed` rows only (the fused plan kernel's table is sized for that)
+        counts, offsets, gend, pos_pad, inv_h, pruned_h = ops.dispatch_plan_padded(idx[:agreed].contiguous(), E_tot, cap_eff, slot)
+        inv_pos = torch.full((T * k,), -1, dtype=torch.int64, device=x.device)
+        inv_pos[: agreed * k].copy_(inv_h)
+        pruned = torch.full((T * k,), -1, dtype=torch.int64, device=x.device)
+        pruned[: agreed * k].copy_(pruned_h)
+    else:
+        counts = torch.zeros(E_tot, dtype=torch.int32, device=x.device)
+        offsets = torch.zeros(E_tot + 1, dtype=torch.int32, device=x.device)
+        pos_pad = torch.full((E_tot * slot,), -1, dtype=torch.int64, device=x.device)
+        inv_pos = torch.full((T * k,), -1, dtype=torch.int64, device=x.device)
+        pruned = torch.full((T * k,), -1, dtype=torch.int64, device=x.device)
     mod.last_plan = (idx, score, counts, offsets, pos_pad, inv_pos)
-    if isinstance(g, SwitchGate):
+    if isinstance(g, SwitchGate) and T > 0:
         from .autograd import switch_aux_loss
         g.set_loss(switch_aux_loss(pruned, probs, E_tot))
-    # counts travel device to device ([W, E_local] each way); nobody on the host ever reads them
-    recv_counts = torch.empty_like(counts)
-    _a2a(recv_counts.view(W, E_local), counts.view(W, E_local), group=group)
-    send = ops.scatter_rows(src, pos_pad, k, cd)                       # [E_tot * cap, d]; unused slots stay unwritten
+    # counts (and every rank's row count) travel device to device; nobody on the host reads the counts
+    recv_counts, peer_rows = exchange_counts_static(counts, T, W, group)
+    _watch_overflow(peer_rows, agreed, mod)
+    if T > 0:
+        send = ops.scatter_rows(src, pos_pad, k, cd)                   # [E_tot * slot, d]; unused slots stay unwritten
+    else:
+        send = torch.empty((E_tot * slot, d), dtype=cd, device=x.device)
     recv = torch.empty_like(send)
     work = _a2a(recv, send, group=group, async_op=True)                # equal splits: E_local * slot rows per peer
     yield                                                              # dispatch all-to-all in flight
@@ -283,6 +397,8 @@ def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual, n
     yield                                                              # return all-to-all in flight
     if work2 is not None:
         work2.wait()
+    if T == 0:
+        return torch.empty((0, d), dtype=x.dtype, device=x.device)
     return _combine_maybe_ln(back, inv_pos, score, T, k, x, residual, next_norm)
 
 
@@ -324,6 +440,7 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
     group = mod.moe_group
     T = x.shape[0]
     cap = g.capacity(T)
+    check_static_overflow()      # (deferred, deterministic: every rank reads the same row-count vectors at the same call)
     # capacity is defined over the whole local batch, so dropping gates run un-chunked
     n_chunks = 1 if cap >= 0 else max(1, int(getattr(mod, "ep_chunks", 1)))
     bounds = chunk_bounds(T, n_chunks) if T > 0 else [(0, 0)] * n_chunks
@@ -334,15 +451,23 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
     gw = g.gate.weight.detach().float().contiguous()
     gb = g.gate.bias.detach().float() if g.gate.bias is not None else None
     src = x  # rows the send buffers are gathered from
-    if norm is not None:
+    if T == 0:   # a rank without rows still takes part in every collective of the layer
+        idx = torch.empty((0, k), dtype=torch.int64, device=x.device)
+        score = torch.empty((0, k), dtype=torch.float32, device=x.device)
+        probs = torch.empty((0, g.tot_expert), dtype=torch.float32, device=x.device)
+        src = torch.empty((0, d), dtype=cd, device=x.device) if norm is not None else x
+    elif norm is not None:
         xn16, _, idx, score, _, probs = ops.ln_router_topk(
             x, norm.weight.detach().float(), norm.bias.detach().float() if norm.bias is not None else None, norm.eps,
             gw, gb, k, g.kind, noise, xn16_dtype=cd, want_probs=isinstance(g, SwitchGate))
         src = xn16
     else:
         idx, score, _, probs = ops.router_topk(x, gw, gb, k, g.kind, noise, want_probs=isinstance(g, SwitchGate))
-    if cap >= 1 and T > 0 and static_exchange_supported(mod, T, cap, cd, x.device):
-        return (yield from _ep_forward_static(mod, x, src, idx, score, probs, cap, cd, residual, next_norm))
+    if use_static_exchange(mod, cd):
+        # decided from the configuration and the AGREED row count only: every rank takes the same branch whatever its batch
+        agreed = static_slot_tokens(mod, T, x.device)
+        if static_plan_fits(mod, agreed):
+            return (yield from _ep_forward_static(mod, x, src, idx, score, probs, cap, cd, residual, next_norm, agreed))
     plans = []
     for (t0, t1) in bounds:
         plans.append(ops.dispatch_plan(idx[t0:t1], g.tot_expert, cap))

@@ -172,8 +172,24 @@ class AdamW(torch.optim.Optimizer):
         # tensor keyed on them (the 16-bit weight shadows of the expert GEMMs and of the dense projections, the zero-row
         # constants) would go on serving the OLD weights.  Bump the versions, as an in-place torch op would have.
         for items in batches.values():
-            torch._C._increment_version([it[0] for it in items])
+            _bump_versions([it[0] for it in items])
         return loss
+
+
+def _bump_versions(tensors) -> None:
+    """``torch._C._increment_version`` is private API: newer releases take a list, older ones a single tensor.  If neither form
+    works the derived-tensor caches are dropped wholesale -- slower (every shadow is re-cast on its next use), never stale."""
+    try:
+        torch._C._increment_version(tensors)
+        return
+    except (TypeError, AttributeError):
+        pass
+    try:
+        for t in tensors:
+            torch._C._increment_version(t)
+    except (TypeError, AttributeError):
+        from ._cache import invalidate_all
+        invalidate_all()
 
 
 class NativeScaler:

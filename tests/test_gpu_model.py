@@ -554,25 +554,34 @@ def _static_exchange_worker(rank, world, port, q):
             x = torch.randn(T, d, generator=torch.Generator().manual_seed(500 + rank)).to(DEV)
             res = torch.randn(T, d, generator=torch.Generator().manual_seed(600 + rank)).to(DEV)
             with torch.no_grad():
-                ref = full.forward_add(x, res)
                 got = part.forward_add(x, res)
                 ln = torch.nn.LayerNorm(d, eps=1e-6).to(DEV)
-                ref_ln, got_ln = full.forward_norm_add(x, ln), part.forward_norm_add(x, ln)
+                got_ln = part.forward_norm_add(x, ln)
+                if T == 0:                                     # a rank without rows: takes part in every collective, returns nothing
+                    return float(got.numel() + got_ln.numel()), 0.0, True, True
+                counts_part = part.last_plan[2].clone()
+                ref = full.forward_add(x, res)
+                ref_ln = full.forward_norm_add(x, ln)
             return float((got - ref).abs().max()), float((got_ln - ref_ln).abs().max()), int(full.last_plan[3][-1]) < T, \
-                bool(torch.equal(part.last_plan[2], full.last_plan[2]))
+                bool(torch.equal(counts_part, full.last_plan[2]))
 
         err, err_ln, dropped, same_counts = run(T + 13 * rank)  # ragged first batch: the slot size is agreed once (the largest)
         err_r, err_ln_r, _, same_r = run(T - 7 * rank)          # later, smaller batches use the same buffers, no communication
-        too_big = False
-        if rank == world - 1:
-            try:
-                part.ep_static_tokens = 10                      # (a batch that does not fit raises instead of mis-matching)
-                part.forward_add(torch.zeros(64, d, device=DEV), torch.zeros(64, d, device=DEV))
-            except RuntimeError:
-                too_big = True
-        else:
-            too_big = True
-        q.put((rank, max(err, err_r), max(err_ln, err_ln_r), calls["n"], int(dropped), same_counts and same_r, too_big))
+        err_0, err_ln_0, _, same_0 = run(0 if rank == world - 1 else T)      # one rank has NO rows this time
+        ep.check_static_overflow(flush=True)                    # everything fitted: silent on every rank
+        # a LARGER batch on one rank only: nobody raises alone in front of a collective (that was a deadlock); every rank raises
+        # at the same check, and the module is re-sized so that repeating the step works
+        big = T + 13 * world + 50
+        run(big if rank == 0 else T)
+        try:
+            ep.check_static_overflow(flush=True)
+            overflow = "not raised"
+        except ep.StaticExchangeOverflow:
+            overflow = "raised"
+        err_b, err_ln_b, _, same_b = run(big if rank == 0 else T)            # the repeated step fits the re-sized buffers
+        ep.check_static_overflow(flush=True)
+        q.put((rank, max(err, err_r, err_0, err_b), max(err_ln, err_ln_r, err_ln_0, err_ln_b), calls["n"], int(dropped),
+               same_counts and same_r and same_0 and same_b, overflow == "raised" and part.ep_static_tokens >= big))
     finally:
         dist.destroy_process_group()
 

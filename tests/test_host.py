@@ -331,8 +331,13 @@ def test_train_one_epoch_takes_the_reference_positional_arguments():
     st = sm.train_one_epoch(model, nn.CrossEntropyLoss(), data, opt, "cpu", 1, sm.NativeScaler(enabled=False))
     assert st["steps"] == 3 and st["loss"] == st["loss"]
     bad = [(torch.full((4, 3, 2, 2), float("nan")), torch.randint(0, 5, (4,)))]
+    before = [p.detach().clone() for p in model.parameters()]
+    ema_calls = calls["ema"]
     with pytest.raises(SystemExit):
-        sm.train_one_epoch(model, nn.CrossEntropyLoss(), bad, opt, "cpu", 2, sm.NativeScaler(enabled=False))
+        sm.train_one_epoch(model, nn.CrossEntropyLoss(), bad, opt, "cpu", 2, sm.NativeScaler(enabled=False), None, Ema())
+    # a scaler that does not skip non-finite steps by itself (disabled / foreign) or an EMA: the abort comes BEFORE the optimizer
+    # step and the EMA update, as at engine.py:56-60 -- nothing absorbed the NaN
+    assert all(torch.equal(p, b) for p, b in zip(model.parameters(), before)) and calls["ema"] == ema_calls
 
 
 def test_adamw_state_dict_carries_the_step_count_on_cpu():
