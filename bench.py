@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=128, help="images in the CPU-oracle sample")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget: 5 timed forwards if they fit ~2x this, else 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clock-seconds", type=float, default=2.0,
+                    help="seconds of back-to-back launches per expert GEMM in the clock probe (0 = skip the probe)")
     ap.add_argument("--gemm-variant", type=int, default=None,
                     help="grouped-GEMM kernel (default: ops.DEFAULT_GEMM_VARIANT = 9, the persistent kernel; 4 = one "
                          "workgroup per tile, bit-identical results)")
@@ -340,8 +342,35 @@ def main():
                 traffic = None
         roofline = {"kernel": "grouped_gemm (expert FFN, both linears)", "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_source": "profiles/roofline_traffic.json (rocprofv3 --pmc passes of an earlier run of this command, "
+                                      "FETCH / WRITE corrected as MI355X_MICROARCH.md prescribes; not a counter of THIS run)",
                     "avg_launch_ms": round(a["ms"] / a["launches"], 4),
                     "flops_per_launch": a["flops"] / a["launches"]}
+        # The data-sheet peak assumes 2.4 GHz; under an MFMA-dense kernel on random data the chip holds far less (package power).
+        # The clock-probe build of the library (two s_memtime / s_memrealtime stamps per workgroup; tools/gemm_clock.py, a child
+        # process) measures the clock held under each expert GEMM: frac_of_clocked_peak prices the kernel against the MFMA rate
+        # the chip actually offered -- what is left to the schedule -- beside `frac`, which prices it against the data sheet.
+        clock_lib = os.path.join(ROOT, "slim-switch-moe-vit_amd", "libslimmoe_hip_clock.so")
+        if (rank == 0 and world == 1 and not args.force_ep and args.clock_seconds > 0 and os.path.exists(clock_lib)
+                and args.compute_dtype in ("f16", "bf16")):
+            import subprocess
+            env = dict(os.environ, SLIMMOE_LIB=clock_lib)
+            try:
+                cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_clock.py"), str(args.clock_seconds),
+                                     str(args.batch)], env=env, capture_output=True, text=True, timeout=120)
+                clk = json.loads(cp.stdout.strip().splitlines()[-1])
+            except Exception as exc:   # the probe is a report, never a reason to lose the bench line
+                clk = {"error": f"{type(exc).__name__}: {exc}"}
+            roofline["clock_probe"] = clk
+            f1, f2 = agg.get("grouped_gemm_fc1"), agg.get("grouped_gemm_fc2")
+            if "gemm1_mhz" in clk and f1 and f2:
+                per_mhz = 1024 * 1024 * 1e6 / 1e12          # TFLOP/s per MHz: 1,024 SIMDs x 1,024 FLOP per cycle (2.4 GHz -> 2,517)
+                offered = f1["ms"] * clk["gemm1_mhz"] * per_mhz + f2["ms"] * clk["gemm2_mhz"] * per_mhz   # TFLOP/s x ms
+                roofline["clocked_peak"] = round(offered / (f1["ms"] + f2["ms"]), 1)
+                roofline["frac_of_clocked_peak"] = round(a["flops"] / 1e9 / offered, 4)
+                roofline["frac_of_clocked_peak_by_gemm"] = {
+                    "gemm1": round(f1["flops"] / 1e9 / (f1["ms"] * clk["gemm1_mhz"] * per_mhz), 4),
+                    "gemm2": round(f2["flops"] / 1e9 / (f2["ms"] * clk["gemm2_mhz"] * per_mhz), 4)}
         # the same launches under the names rocprofv3 --stats gives them (profiles/r03_bench_kernel_stats.csv):
         # grouped_gemm_ps<operand, out, AFR, DEEP, KEEP, DIRECT, BUF> (AFR 5 = 320-row tile; DEEP = the half-tile prefetch schedule
         # picked for K >= 2048; DIRECT = 16-bit outputs stored from the registers; BUF = f32 outputs through the buffer-addressed

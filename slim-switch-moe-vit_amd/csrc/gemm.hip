@@ -1370,6 +1370,14 @@ extern "C" int smoe_diag_clear_stamps() {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(smoe_diag_stamps), z, sizeof(z));
 }
 #endif
+#ifdef SMOE_CLOCK
+// clock-probe build only: [1024 workgroups][start memtime, start memrealtime, end memtime, end memrealtime] of the LAST
+// persistent-GEMM launch (every launch overwrites them)
+extern "C" int smoe_clock_read_stamps(unsigned long long* host_out, size_t n) {
+  const size_t cap = sizeof(unsigned long long) * 1024 * 4;
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(smoe_clock_stamps), n * 8 < cap ? n * 8 : cap);
+}
+#endif
 
 extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int32_t* offsets,
                                  const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,

@@ -39,6 +39,25 @@ __device__ int smoe_diag_flags;   // bit 0: the main loop issues no operand DMA 
 #define PS_IBAR() PP_BARRIER()
 #endif
 
+#ifdef SMOE_CLOCK
+// clock-probe build only (libslimmoe_hip_clock.so, `make clock`; MI355X_MICROARCH.md 'DVFS give-back' item 6): wave 0 / lane 0 of
+// every workgroup stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) once before its first tile and once behind its
+// last; the clock the chip held over the launch is d(memtime) / d(memrealtime) x 100 MHz.  The stamps go to a buffer of their own
+// that nothing else reads; no output depends on them.  The production library executes no stamp.
+__device__ unsigned long long smoe_clock_stamps[1024 * 4];
+#define PS_CLOCK(i)                                                                                             \
+  do {                                                                                                          \
+    if (wave == 0 && lane == 0 && blockIdx.x < 1024) {                                                          \
+      unsigned long long t_sh, t_rt;                                                                            \
+      asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_sh), "=s"(t_rt)::"memory"); \
+      smoe_clock_stamps[blockIdx.x * 4 + (i)] = t_sh;                                                           \
+      smoe_clock_stamps[blockIdx.x * 4 + (i) + 1] = t_rt;                                                       \
+    }                                                                                                           \
+  } while (0)
+#else
+#define PS_CLOCK(i) do {} while (0)
+#endif
+
 // KEEP (training forward of the first expert linear): the epilogue stores BOTH the pre-activation H = A W^T + b and gelu(H) --
 // the backward needs H for gelu' and gelu(H) as the operand of the second linear's weight gradient; a separate GELU pass over
 // H was 620 MB of HBM traffic (110 us at ViT-B).  `residual` carries the address that RECEIVES H; no row map / residual fusion.
@@ -344,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   };
 
   if (!advance()) return;
+  PS_CLOCK(0);
   {
     int oz = 0;
     asm volatile("" : "+v"(oz));
@@ -780,6 +800,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     if (!more) break;
     issue_kt1();   // into buffer 1 = the staging region just released; lands during the first K-tile's 8 intervals
   }
+  PS_CLOCK(2);
 #undef PS_MFMA
 #undef PS_DMA
 }
