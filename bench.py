@@ -253,7 +253,7 @@ def main():
     # Per-launch HIP events inside the timed region: the roofline kernel only (two event records around each of the
     # ~110 other launches of a step cost ~0.5 ms per step).  The other kernels' table comes from a few extra,
     # untimed steps below.
-    ops.profile_begin({"grouped_gemm"})
+    ops.profile_begin({"grouped_gemm", "expert_ffn"})
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times (median reported)
     t0 = time.perf_counter()
     marks[0].record()
@@ -271,7 +271,7 @@ def main():
         for _ in range(side_steps):
             step()
         fence()
-        prof = prof + [(n, m2, ms) for n, m2, ms in ops.profile_end() if n != "grouped_gemm"]
+        prof = prof + [(n, m2, ms) for n, m2, ms in ops.profile_end() if n not in ("grouped_gemm", "expert_ffn")]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -309,6 +309,11 @@ def main():
     # ---- per-kernel accounting from the HIP events recorded inside the timed region --------------------
     agg = {}
     for name, meta, ms in prof:
+        if name == "expert_ffn":    # smoe_expert_ffn: both expert GEMMs in one persistent launch = the roofline kernel
+            for nm in ("grouped_gemm", "expert_ffn"):
+                a = agg.setdefault(nm, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                a["launches"] += 1; a["ms"] += ms; a["flops"] += meta.get("flops", 0.0)
+            continue
         if name == "grouped_gemm":
             for nm in ("grouped_gemm", "grouped_gemm_fc1" if meta.get("epilogue") == ops.EPI_GELU else "grouped_gemm_fc2"):
                 a = agg.setdefault(nm, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
@@ -321,7 +326,7 @@ def main():
         a["bytes"] += meta.get("bytes", 0.0)
     kernels = {}
     for name, a in agg.items():
-        per = args.steps if name.startswith("grouped_gemm") else max(1, side_steps)
+        per = args.steps if (name.startswith("grouped_gemm") or name == "expert_ffn") else max(1, side_steps)
         ent = {"launches_per_step": a["launches"] / per, "avg_ms": a["ms"] / a["launches"]}
         if a["flops"]:
             ent["tflops"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
@@ -340,7 +345,8 @@ def main():
                 traffic = json.load(open(tpath)).get("grouped_gemm_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "grouped_gemm (expert FFN, both linears)", "bound": "mfma", "achieved": round(achieved, 2),
+        roofline = {"kernel": "expert FFN grouped GEMMs (both linears" + ("; one fused persistent launch per layer)" if "expert_ffn" in agg else "; two launches per layer)"),
+                    "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_source": "profiles/roofline_traffic.json (rocprofv3 --pmc passes of an earlier run of this command, "
                                       "FETCH / WRITE corrected as MI355X_MICROARCH.md prescribes; not a counter of THIS run)",
@@ -362,9 +368,12 @@ def main():
             except Exception as exc:   # the probe is a report, never a reason to lose the bench line
                 clk = {"error": f"{type(exc).__name__}: {exc}"}
             roofline["clock_probe"] = clk
-            f1, f2 = agg.get("grouped_gemm_fc1"), agg.get("grouped_gemm_fc2")
-            if "gemm1_mhz" in clk and f1 and f2:
-                per_mhz = 1024 * 1024 * 1e6 / 1e12          # TFLOP/s per MHz: 1,024 SIMDs x 1,024 FLOP per cycle (2.4 GHz -> 2,517)
+            per_mhz = 1024 * 1024 * 1e6 / 1e12          # TFLOP/s per MHz: 1,024 SIMDs x 1,024 FLOP per cycle (2.4 GHz -> 2,517)
+            f1, f2, ff = agg.get("grouped_gemm_fc1"), agg.get("grouped_gemm_fc2"), agg.get("expert_ffn")
+            if "fused_mhz" in clk and ff:             # the fused launch (both GEMMs in one kernel) is what the step ran
+                roofline["clocked_peak"] = round(clk["fused_mhz"] * per_mhz, 1)
+                roofline["frac_of_clocked_peak"] = round(achieved / (clk["fused_mhz"] * per_mhz), 4)
+            elif "gemm1_mhz" in clk and f1 and f2:
                 offered = f1["ms"] * clk["gemm1_mhz"] * per_mhz + f2["ms"] * clk["gemm2_mhz"] * per_mhz   # TFLOP/s x ms
                 roofline["clocked_peak"] = round(offered / (f1["ms"] + f2["ms"]), 1)
                 roofline["frac_of_clocked_peak"] = round(a["flops"] / 1e9 / offered, 4)
@@ -376,7 +385,8 @@ def main():
         # picked for K >= 2048; DIRECT = 16-bit outputs stored from the registers; BUF = f32 outputs through the buffer-addressed
         # staged epilogue); with --gemm-variant 4: grouped_gemm_pp256<operand, out, ABL, MODE, AFR>
         pers = (args.gemm_variant or ops.DEFAULT_GEMM_VARIANT) == 9
-        names = ({"grouped_gemm_fc1": "grouped_gemm_ps<f16,f16,5,false,false,true,false> = GEMM-1 (K 768, gathered rows, bias + GELU)",
+        names = ({"expert_ffn": "expert_ffn_fused<f16> = GEMM-1 + GEMM-2 of a layer in one persistent launch (smoe_expert_ffn)",
+                  "grouped_gemm_fc1": "grouped_gemm_ps<f16,f16,5,false,false,true,false> = GEMM-1 (K 768, gathered rows, bias + GELU)",
                   "grouped_gemm_fc2": "grouped_gemm_ps<f16,f32,5,true,false,false,true> = GEMM-2 (K 3072, combine + residual)",
                   "attn_proj_gemm": "grouped_gemm_ps<f16,f32,5,false,false,false,true> = attention projection (K 768, + residual)",
                   "qkv_gemm": "grouped_gemm_ps<f16,f16,4,false,false,true,false> = qkv projection (K 768, N 2304; 256-row tiles)",
@@ -390,7 +400,7 @@ def main():
         for key, label in names.items():
             a2 = agg.get(key)
             if a2:
-                sym[label] = {"launches_per_step": a2["launches"] / (args.steps if key.startswith("grouped_gemm") else max(1, side_steps)),
+                sym[label] = {"launches_per_step": a2["launches"] / (args.steps if (key.startswith("grouped_gemm") or key == "expert_ffn") else max(1, side_steps)),
                               "avg_launch_ms": round(a2["ms"] / a2["launches"], 4)}
         if world == 1 and not args.force_ep:  # (under expert parallelism both GEMMs are the f16-out instantiation)
             roofline["by_rocprof_symbol"] = sym
@@ -419,7 +429,7 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
-        hot = ("router", "ln_router", "plan", "scatter", "combine", "grouped_gemm")  # the MoE operator's own kernels
+        hot = ("router", "ln_router", "plan", "scatter", "combine", "grouped_gemm")  # the MoE operator's own kernels ("grouped_gemm" includes the fused launches)
         moe_ms = sum(a["ms"] / (args.steps if n.startswith("grouped_gemm") else max(1, side_steps))
                      for n, a in agg.items() if n in hot)
         out["hot_path"] = {"moe_kernels_ms_per_step": round(moe_ms, 3),

@@ -211,6 +211,25 @@ int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int
                       const void* residual, const int64_t* a_gather, int a_div,
                       void* out, int64_t out_rows, int out_dtype, int variant, const int32_t* group_end, void* stream);
 
+/* smoe_expert_ffn: the whole expert FFN of one MoE layer with the top-1 combine -- fmoe_cuda.linear_forward x 2 with the activation
+ * between them, MOEGather and the combine (models/resMoE.py:143 -> FastMoE `_Expert.forward`) -- as ONE persistent
+ * launch:   H[r]   = gelu(X[a_gather[r] / a_div] W1[e]^T + b1[e])                      (16-bit, [m_rows_max, d_hidden]; caller's buffer)
+ *           out[row_map[r]] = residual[row_map[r]] + row_scale[row_map[r]] (H[r] W2[e]^T + b2[e])       (f32, [out_rows, d_out])
+ * for r in row group g's range [offsets[g], offsets[g+1]), e = group_expert[g] (or g).  Every number is computed exactly as by the
+ * two smoe_grouped_gemm launches (variant 9: 320-row tiles, same accumulation order): bit-identical results.  What the single
+ * launch buys: the workgroups draw tiles of BOTH GEMMs from one list (a GEMM-2 tile starts when the GEMM-1 tiles of its rows
+ * have stored, counted per m-tile in `workspace`), so neither GEMM ends in a partly filled round of workgroups.
+ * a_gather / row_map / row_scale / residual / b1 / b2 / group_expert may be NULL.  `workspace`: smoe_expert_ffn_workspace_bytes
+ * bytes, ZERO before the first launch; every launch leaves it zero again (word 17 = error flag: set if a wait on a row counter ran
+ * out -- never in a healthy launch).  Returns -1 (no error set) for shapes outside this launch's reach (operands not f16 / bf16,
+ * out not f32, d_in or d_hidden % 64, > 63 groups, operands >= 4 GiB, out >= 2 GiB): issue the two smoe_grouped_gemm then. */
+size_t smoe_expert_ffn_workspace_bytes(int64_t m_rows_max, int G);
+int smoe_expert_ffn(const void* X, const int64_t* a_gather, int a_div, const void* W1, const float* b1, void* H, const void* W2,
+                    const float* b2, const int32_t* offsets, const int32_t* group_expert, int G, int n_experts,
+                    int64_t m_rows_max, int d_in, int d_hidden, int d_out, int ab_dtype, const int64_t* row_map,
+                    const float* row_scale, const void* residual, void* out, int64_t out_rows, int out_dtype, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* smoe_grouped_gemm_gelu_keep: the first expert linear of the TRAINING forward (fmoe_cuda.linear_forward + the activation, whose
  * input autograd keeps): pre_out = A W^T + bias and out = gelu(pre_out), both [m_rows, N] in the operand dtype (f16 / bf16), from one
  * epilogue.  Returns -1 (no error set) for shapes outside the persistent kernel's reach (K % 64 != 0, operands >= 4 GiB, G > 63):

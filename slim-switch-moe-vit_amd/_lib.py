@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SLIMMOE_LIB: another build of the same sources (a diagnostic build, `make DIAG=-DSMOE_DIAG`, whose environment switches the
 # tools under tools/ use); the ABI and symbol checks below apply to it all the same
 LIB_PATH = os.environ.get("SLIMMOE_LIB") or os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -53,6 +53,10 @@ SIGNATURES = {
     "smoe_grouped_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
                                   c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int,
                                   c_int, c_void_p, c_void_p]),
+    "smoe_expert_ffn_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "smoe_expert_ffn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                c_int, c_void_p, c_size_t, c_void_p]),
     "smoe_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.c_float, c_int64, c_int, c_void_p, c_int, c_void_p]),
     "smoe_gate_dgrad": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "smoe_layernorm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),

@@ -1371,11 +1371,15 @@ extern "C" int smoe_diag_clear_stamps() {
 }
 #endif
 #ifdef SMOE_CLOCK
-// clock-probe build only: [1024 workgroups][start memtime, start memrealtime, end memtime, end memrealtime] of the LAST
-// persistent-GEMM launch (every launch overwrites them)
+// clock-probe build only: [1024 workgroups][start memtime, start memrealtime, end memtime, end memrealtime, fused: spins, GEMM-1
+// tiles, GEMM-2 tiles, -] of the LAST persistent-GEMM launch (the stamps are overwritten, the counts accumulate until cleared)
 extern "C" int smoe_clock_read_stamps(unsigned long long* host_out, size_t n) {
-  const size_t cap = sizeof(unsigned long long) * 1024 * 4;
+  const size_t cap = sizeof(unsigned long long) * 1024 * 8;
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(smoe_clock_stamps), n * 8 < cap ? n * 8 : cap);
+}
+extern "C" int smoe_clock_clear_stamps() {
+  static unsigned long long z[1024 * 8];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(smoe_clock_stamps), z, sizeof(z));
 }
 #endif
 
@@ -1421,6 +1425,57 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
     case SMOE_BF16: return dispatch_out<bf16_bits>(variant, A, W, bias, offsets, group_expert, G, m_rows_max, K, N, epilogue, row_map, row_scale, residual, out, out_dtype, s, a_gather, a_div, group_end, out_rows);
   }
   return 1;
+}
+
+// The expert FFN of one MoE layer (top-1 combine fused) as ONE persistent launch: see expert_ffn_fused in gemm_persistent.h.
+// Returns -1 (no error set) for what that launch does not cover -- the caller then issues the two smoe_grouped_gemm launches.
+extern "C" size_t smoe_expert_ffn_workspace_bytes(int64_t m_rows_max, int G) {
+  return sizeof(int32_t) * (size_t)(FUSED_WS_HDR + (m_rows_max + 319) / 320 + (G > 0 ? G : 0) + 8);   // tickets, counters
+}
+extern "C" int smoe_expert_ffn(const void* X, const int64_t* a_gather, int a_div, const void* W1, const float* b1, void* H,
+                               const void* W2, const float* b2, const int32_t* offsets, const int32_t* group_expert, int G,
+                               int n_experts, int64_t m_rows_max, int d_in, int d_hidden, int d_out, int ab_dtype,
+                               const int64_t* row_map, const float* row_scale, const void* residual, void* out, int64_t out_rows,
+                               int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  SMOE_REQUIRE(offsets && G >= 1 && n_experts >= 1 && (group_expert || n_experts == G), "smoe_expert_ffn: bad groups");
+  SMOE_REQUIRE(m_rows_max >= 0 && m_rows_max < (1ll << 31) && d_in > 0 && d_hidden > 0 && d_out > 0, "smoe_expert_ffn: bad sizes");
+  SMOE_REQUIRE(a_div >= 1, "smoe_expert_ffn: a_div must be >= 1");
+  if (m_rows_max == 0) return 0;
+  SMOE_REQUIRE(X && W1 && H && W2 && out && workspace, "smoe_expert_ffn: null pointer");
+  SMOE_REQUIRE(workspace_bytes >= smoe_expert_ffn_workspace_bytes(m_rows_max, G), "smoe_expert_ffn: workspace too small");
+  if ((ab_dtype != SMOE_F16 && ab_dtype != SMOE_BF16) || out_dtype != SMOE_F32) return -1;
+  if (d_in % 64 || d_hidden % 64 || d_out % 8 || G > 63) return -1;
+  const uint64_t x_bytes = (uint64_t)m_rows_max * (uint64_t)(d_in > d_hidden ? d_in : d_hidden) * 2u;
+  const uint64_t w_bytes = (uint64_t)n_experts * (uint64_t)d_hidden * (uint64_t)(d_in > d_out ? d_in : d_out) * 2u;
+  if (x_bytes >= (1ull << 32) || w_bytes >= (1ull << 32)) return -1;            // 32-bit operand offsets
+  if (out_rows <= 0 || out_rows * (int64_t)d_out * 4 >= (1ll << 31)) return -1;   // the buffer-addressed f32 epilogue's 2 GiB
+  if ((int64_t)d_hidden * 320 * 2 >= (1ll << 31)) return -1;
+  const int ntn1 = (d_hidden + 255) / 256, ntn2 = (d_out + 255) / 256;
+  const int64_t max_mt = (m_rows_max + 319) / 320 + G;
+  int grid = smoe_num_cus() & ~7;
+  if (grid < 8) grid = 8;
+  if (max_mt * ntn1 < grid) grid = (int)((max_mt * ntn1 + 7) & ~(int64_t)7);
+  // tile costs in half K-tiles (main loop = 2 per K-tile) + the tile boundary as measured (profiles/r03_gemm*_tile_stamps.txt:
+  // 14.7 k of 55.2 k cycles for the direct 16-bit epilogue, 47 k of 203 k for the f32 residual epilogue)
+  static const int c1_env = getenv("SMOE_FUSED_C1") ? atoi(getenv("SMOE_FUSED_C1")) : 0;
+  static const int c2_env = getenv("SMOE_FUSED_C2") ? atoi(getenv("SMOE_FUSED_C2")) : 0;
+  // (SMOE_FUSED_C1=-1: the serial order, every GEMM-1 tile in front of every GEMM-2 tile, for A/B)
+  const int c1 = c1_env != 0 ? c1_env : 2 * (d_in / 64) + 10, c2 = c2_env > 0 ? c2_env : 2 * (d_hidden / 64) + 29;
+  hipStream_t s = (hipStream_t)stream;
+  if (ab_dtype == SMOE_F16) {
+    SMOE_ENSURE_SMEM(expert_ffn_fused<f16>);
+    hipLaunchKernelGGL((expert_ffn_fused<f16>), dim3(grid), dim3(512), 160 * 1024, s, (const f16*)X, a_gather, a_div, (int)m_rows_max,
+                       (const f16*)W1, b1, (f16*)H, (const f16*)W2, b2, offsets, group_expert, G, d_in, d_hidden, d_out, row_map,
+                       row_scale, (const float*)residual, (float*)out, ntn1, ntn2, 4, c1, c2, (int32_t*)workspace);
+  } else {
+    SMOE_ENSURE_SMEM(expert_ffn_fused<bf16_bits>);
+    hipLaunchKernelGGL((expert_ffn_fused<bf16_bits>), dim3(grid), dim3(512), 160 * 1024, s, (const bf16_bits*)X, a_gather, a_div,
+                       (int)m_rows_max, (const bf16_bits*)W1, b1, (bf16_bits*)H, (const bf16_bits*)W2, b2, offsets, group_expert, G,
+                       d_in, d_hidden, d_out, row_map, row_scale, (const float*)residual, (float*)out, ntn1, ntn2, 4, c1, c2,
+                       (int32_t*)workspace);
+  }
+  SMOE_CHECK_LAUNCH("smoe_expert_ffn");
+  return 0;
 }
 
 // First expert linear of the TRAINING forward: pre_out = A W^T + bias (kept for gelu' in the backward) and out = gelu(pre_out),

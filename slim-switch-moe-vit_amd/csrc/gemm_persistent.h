@@ -44,18 +44,23 @@ __device__ int smoe_diag_flags;   // bit 0: the main loop issues no operand DMA 
 // every workgroup stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) once before its first tile and once behind its
 // last; the clock the chip held over the launch is d(memtime) / d(memrealtime) x 100 MHz.  The stamps go to a buffer of their own
 // that nothing else reads; no output depends on them.  The production library executes no stamp.
-__device__ unsigned long long smoe_clock_stamps[1024 * 4];
+__device__ unsigned long long smoe_clock_stamps[1024 * 8];   // per workgroup: 4 stamps + (fused launch) spins, GEMM-1 / GEMM-2 tiles, cycles in GEMM-2 runs
 #define PS_CLOCK(i)                                                                                             \
   do {                                                                                                          \
     if (wave == 0 && lane == 0 && blockIdx.x < 1024) {                                                          \
       unsigned long long t_sh, t_rt;                                                                            \
       asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_sh), "=s"(t_rt)::"memory"); \
-      smoe_clock_stamps[blockIdx.x * 4 + (i)] = t_sh;                                                           \
-      smoe_clock_stamps[blockIdx.x * 4 + (i) + 1] = t_rt;                                                       \
+      smoe_clock_stamps[blockIdx.x * 8 + (i)] = t_sh;                                                           \
+      smoe_clock_stamps[blockIdx.x * 8 + (i) + 1] = t_rt;                                                       \
     }                                                                                                           \
+  } while (0)
+#define PS_COUNT(slot, n)                                                                                       \
+  do {                                                                                                          \
+    if (wave == 0 && lane == 0 && blockIdx.x < 1024) smoe_clock_stamps[blockIdx.x * 8 + (slot)] += (n);          \
   } while (0)
 #else
 #define PS_CLOCK(i) do {} while (0)
+#define PS_COUNT(slot, n) do {} while (0)
 #endif
 
 // KEEP (training forward of the first expert linear): the epilogue stores BOTH the pre-activation H = A W^T + b and gelu(H) --
@@ -74,13 +79,76 @@ __device__ unsigned long long smoe_clock_stamps[1024 * 4];
 // (num_records = the rows of this tile that exist), so every wave issues the same number of stores and the wait that
 // publishes K-tile 0 can be a counted one (the stores are younger than the operand pieces).  Same arithmetic per element
 // as the staged epilogue: bit-identical results.
-template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false, bool DIRECT = false, bool BUF = false>
-__global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
+// ---- the fused expert-FFN launch (expert_ffn_fused below): GEMM-1 and GEMM-2 tiles of one MoE layer in ONE persistent launch ----
+// Separate launches end in a partly filled round of workgroups each (ViT-B, 256 images: 1,920 GEMM-1 tiles = 7.5 rounds on 256
+// CUs, 480 GEMM-2 tiles = 1.9 rounds: ~7 % of both kernels is tail).  Here every workgroup computes tiles of BOTH GEMMs; a
+// GEMM-2 tile (m-tile i, any n) may start once the 12 (= h / 256) GEMM-1 tiles of m-tile i have stored their rows of H, which a
+// per-m-tile counter says.
+// ONE LIST PER XCD: the workgroups with blockIdx % 8 == k (they share an XCD: an affinity label, nothing depends on it) own the
+// m-tiles [total_mt k / 8, total_mt (k + 1) / 8) -- their GEMM-1 AND GEMM-2 tiles -- so tiles that share operand panels meet in
+// ONE L2 and H is consumed on the XCD that produced it.  The list is cut into SLOTS, two per workgroup, each a STATIC tile sequence
+// (closed form of slot number and list geometry, fused_plan):
+//   stage 1, slot w:  GEMM-1 tiles  w, w + G, ..., w + (x - 1) G              (G = workgroups per list; x G = A tiles)
+//   stage 2, slot w:  w <  B2: GEMM-2 tile w (the early batch: its producers lie in [0, A)),
+//                     w >= B2: the GEMM-1 tiles left over, (w - B2) + j (G - B2) behind A;
+//                     then the remaining GEMM-2 tiles  B2 + w + j G.
+// x balances the two kinds of stage-2 slots (x c1 + (q2 + 1) c2 against y c1 + q2 c2): every CU ends within about one GEMM-1
+// tile of the others, and neither GEMM has a partly filled round of its own.
+// Slots are CLAIMED through two tickets per list (one atomic each per workgroup and stage -- not per tile: a per-tile ticket put
+// an atomic's latency into the in-order vmcnt queue in front of every tile's first operand wait, +4 us per GEMM-1 tile, and bound
+// tiles to workgroups two tiles ahead of time; profiles/r04_fused_ffn.md).  Stage-2 slots are claimed light-first (the slots
+// with GEMM-1 work), and a workgroup starts a stage-2 slot only after it has seen the stage-1 ticket exhausted (it computes any
+// stage-1 slot it still gets).  No deadlock, whatever the number of resident workgroups: a GEMM-2 tile waits only for GEMM-1
+// tiles of slots that were claimed before its own slot could start -- claimed by RUNNING workgroups, which reach those tiles
+// without waiting for anything; workgroups that start late (another launch holds their CU) find the slots nobody claimed.
+// A bounded spin (FUSED_SPIN_LIMIT polls) turns a broken counter into a wrong result plus an error word, not a hung GPU.
+// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility / cdna_hip_programming.md G16): the producer stores H
+// write-through (sc1), every storing wave drains vmcnt(0), a workgroup barrier, then ONE lane adds to the m-tile's counter
+// (agent scope); the consumer polls the counter with sc1 loads, then an agent-scope acquire (buffer_inv sc1), then its
+// plain LDS-DMA loads -- every wave for itself, so no further barrier is needed.  Co-location is never relied on.
+constexpr int FUSED_WS_HDR = 32;            // ws[k] / ws[8 + k]: stage-1 / stage-2 ticket of list k, [16] workgroups that left, [17] error word
+constexpr int FUSED_WS_LEFT = 16, FUSED_WS_ERR = 17;
+constexpr int FUSED_SPIN_LIMIT = 1 << 22;   // x s_sleep(16) ~ 1 k cycles each: seconds, far beyond any legitimate wait
+struct FusedCtl {
+  int32_t* ws;          // tickets, [FUSED_WS_HDR + mt] = GEMM-1 tiles of m-tile mt done
+  int mt_lo, cnt;       // this workgroup's list: m-tiles [mt_lo, mt_lo + cnt)
+  int n1, n2, A, B2, G; // its GEMM-1 / GEMM-2 tile counts, the plan (A = x G), workgroups per list
+  int ntn1, ntn2, gm;   // n-tiles of the two GEMMs (ntn1 = the counter value that releases an m-tile), m-tiles per numbering group
+  int stage, slot, j;   // the slot being walked: 1 = stage 1; 2 = stage 2, first part; 3 = stage 2, remaining GEMM-2 tiles
+  int nk, nid;          // the next unprocessed tile: kind (1 = GEMM-1, 2 = GEMM-2, 0 = the slot is finished), index in its GEMM's order
+};
+// advance (nk, nid) to the tile behind the current one of the slot
+__device__ __forceinline__ void fused_advance(FusedCtl& fc) {
+  if (fc.stage == 1) {
+    const int id = fc.slot + fc.G * fc.j;
+    if (id < fc.A) { fc.nk = 1; fc.nid = id; ++fc.j; return; }
+    fc.nk = 0;
+    return;
+  }
+  if (fc.stage == 2) {
+    if (fc.slot < fc.B2) {
+      if (fc.j == 0) { fc.nk = 2; fc.nid = fc.slot; fc.j = 1; return; }
+    } else {
+      const int id = fc.A + (fc.slot - fc.B2) + (fc.G - fc.B2) * fc.j;
+      if (id < fc.n1) { fc.nk = 1; fc.nid = id; ++fc.j; return; }
+    }
+    fc.stage = 3;
+    fc.j = 0;
+  }
+  const int f = fc.B2 + fc.slot + fc.G * fc.j;
+  if (f < fc.n2) { fc.nk = 2; fc.nid = f; ++fc.j; return; }
+  fc.nk = 0;
+}
+
+template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP, bool DIRECT, bool BUF, int FUSED>
+__device__ __forceinline__ void ps_body(
     const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
     const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* residual, OT* out, int n_tiles_n,
-    int group_m, const int64_t* __restrict__ a_gather, int a_div, int gather_len, const int32_t* __restrict__ group_end) {
+    int group_m, const int64_t* __restrict__ a_gather, int a_div, int gather_len, const int32_t* __restrict__ group_end,
+    FusedCtl* fc) {
   static_assert(sizeof(AB) == 2, "16-bit operands");
+  static_assert(FUSED == 0 || (!KEEP && ((FUSED == 1 && DIRECT) || (FUSED == 2 && BUF))), "fused roles: 1 = producer (direct 16-bit stores), 2 = consumer");
   static_assert(!DIRECT || (sizeof(OT) == 2 && !KEEP), "the direct epilogue stores 16-bit outputs, one output per tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TBM = 64 * AFR, TBN = 256, NT = 512, NW = 8;
@@ -127,8 +195,10 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   // group_m < 0 (-(quad | n_block << 8)): n-block-major numbering -- for each block of n_block n-tiles, for each quad of m-tiles,
   // quad x n_block tiles -- and every XCD owns ONE CONTIGUOUS eighth of that order, walked per_xcd tiles at a time: round after
   // round its workgroups meet the same n_block weight panels (until the expert changes) and only the A panels move on.
+  // FUSED: the tile comes from the launch's list (FusedCtl); numbering = groups of gm m-tiles x all n-tiles without padding (the
+  // last group holds the m-tiles that are left), so that the list positions are exactly the tiles that exist.
   const bool xcd_runs = group_m < 0;
-  const int gm = xcd_runs ? ((-group_m) & 0xff) : group_m;
+  const int gm = FUSED ? fc->gm : (xcd_runs ? ((-group_m) & 0xff) : group_m);
   const int n_block = xcd_runs ? ((-group_m) >> 8) : n_tiles_n;          // the launcher makes it a divisor of n_tiles_n
   const int per_group = gm * n_block;
   const int tiles_per_nb = ((total_mt + gm - 1) / gm) * per_group;
@@ -140,25 +210,66 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
   const int t_last = xcd_runs ? (xcd_end < n_tiles ? xcd_end : n_tiles) : n_tiles;
   int tile = (blockIdx.x & 7) * (xcd_runs ? xcd_share : per_xcd) + (blockIdx.x >> 3);
   int e = 0, m0 = 0, m_end = 0, n0 = 0;          // the tile whose operands are being set up / streamed
+  int mt_next = 0;                               // FUSED: its m-tile (the index of its ready counter)
+  auto locate = [&](int mt) {                    // (e, m0, m_end) of m-tile mt
+    // groups in front of or holding m-tile mt form a lane prefix; the owner is its last lane (an empty group has the
+    // same prefix count as its successor, so it is never last)
+    const unsigned long long msk = __ballot(lane < E && t_tb <= mt);
+    const int gi = 63 - __builtin_clzll(msk);
+    m0 = __builtin_amdgcn_readlane(t_off, gi) + (mt - __builtin_amdgcn_readlane(t_tb, gi)) * TBM;
+    m_end = __builtin_amdgcn_readlane(t_end, gi);
+    e = __builtin_amdgcn_readlane(t_ge, gi);
+  };
+  auto locate_fused = [&](int id) {              // tile `id` of THIS GEMM's order within the list -> (e, m0, m_end, n0, mt_next)
+    const int g = id / per_group, rem = id % per_group;   // numbering: groups of gm m-tiles x all n-tiles, no padding
+    int gme = fc->cnt - g * gm;
+    if (gme > gm) gme = gm;
+    const int mt = fc->mt_lo + g * gm + rem % gme;
+    locate(mt);
+    n0 = (rem / gme) * TBN;
+    mt_next = mt;
+  };
   auto advance = [&]() -> bool {                 // first existing tile at or after `tile` on this workgroup's stride
     while (tile < t_last) {
       const int nb = tile / tiles_per_nb, r = tile % tiles_per_nb;
       const int g = r / per_group, rem = r % per_group;
       const int mt = g * gm + rem % gm;
       if (mt < total_mt) {
-        // groups in front of or holding m-tile mt form a lane prefix; the owner is its last lane (an empty group has the
-        // same prefix count as its successor, so it is never last)
-        const unsigned long long msk = __ballot(lane < E && t_tb <= mt);
-        const int gi = 63 - __builtin_clzll(msk);
-        m0 = __builtin_amdgcn_readlane(t_off, gi) + (mt - __builtin_amdgcn_readlane(t_tb, gi)) * TBM;
-        m_end = __builtin_amdgcn_readlane(t_end, gi);
-        e = __builtin_amdgcn_readlane(t_ge, gi);
+        locate(mt);
         n0 = (nb * n_block + rem / gm) * TBN;
         return true;
       }
       tile += t_step;
     }
     return false;
+  };
+  // ---- fused launch: readiness, completion --------------------------------------------------------------------------------
+  int polled = 0;         // consumer: the next tile's ready counter as read at the top of the current tile
+  int mt_done = -1;       // producer: m-tile of the tile whose stores are still draining (signalled one tile later)
+  auto fused_signal = [&](int mt) {   // every wave has drained its stores of that tile and passed a barrier since
+    if constexpr (FUSED == 1) {
+      if (wave == 0 && lane == 0)
+        __hip_atomic_fetch_add(fc->ws + FUSED_WS_HDR + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto fused_poll = [&](int mt) -> int {
+    return __hip_atomic_load(fc->ws + FUSED_WS_HDR + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto fused_wait = [&](int mt, int seen) {   // until all GEMM-1 tiles of m-tile mt have stored; then this wave may load H
+    if constexpr (FUSED == 2) {
+      int v = __builtin_amdgcn_readfirstlane(seen);
+      int spins = 0;
+      while (v < fc->ntn1) {
+        __builtin_amdgcn_s_sleep(16);
+        v = __builtin_amdgcn_readfirstlane(fused_poll(mt));
+        if (++spins > FUSED_SPIN_LIMIT) {        // never in a healthy launch: report, then go on (wrong rows, no hang)
+          if (lane == 0) fc->ws[FUSED_WS_ERR] = 1;
+          break;
+        }
+      }
+      PS_COUNT(4, spins);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
   };
 
   // ---- operand source pointers of the current (e, m0, m_end, n0) -----------------------------------------------------
@@ -362,8 +473,13 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     }
   };
 
-  if (!advance()) return;
-  PS_CLOCK(0);
+  if constexpr (FUSED == 0) {
+    if (!advance()) return;
+  } else {
+    locate_fused(fc->nid);                                              // the caller made sure (nk, nid) is a tile of this GEMM
+    if constexpr (FUSED == 2) fused_wait(mt_next, fused_poll(mt_next));   // before the first operand fetch from H
+  }
+  if constexpr (FUSED == 0) PS_CLOCK(0);
   {
     int oz = 0;
     asm volatile("" : "+v"(oz));
@@ -384,12 +500,25 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
 
   int tile_no = 0;
   (void)tile_no;
+  int cmt = 0;                                              // FUSED: m-tile of the tile computed in this iteration
   for (;; ++tile_no) {
     PS_STAMP(0);
     // ---- look ahead: where this workgroup goes next; that tile's gather rows start streaming into LDS now ----------------
     const int ce = e, cm0 = m0, cm_end = m_end, cn0 = n0;   // the tile computed in this iteration
-    tile += t_step;
-    const bool more = advance();                            // (e, m0, m_end, n0) = the next tile from here on
+    cmt = mt_next;
+    if constexpr (FUSED != 0) PS_COUNT(4 + FUSED, 1);
+    bool more;
+    if constexpr (FUSED == 0) {
+      tile += t_step;
+      more = advance();                                     // (e, m0, m_end, n0) = the next tile from here on
+    } else {
+      fused_advance(*fc);      // (nk, nid) = the slot's tile behind the one computed in this iteration
+      more = fc->nk == FUSED;  // a tile of the other GEMM, or the end of the slot, ends this run
+      if (more) {
+        locate_fused(fc->nid);
+        if constexpr (FUSED == 2) polled = fused_poll(mt_next);   // usually released long ago: checked at the tile boundary
+      }
+    }
     if (more) prefetch_rows();
 #pragma unroll
     for (int i = 0; i < 2 * AFR; ++i)
@@ -473,6 +602,11 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     }
     if (wr == 0) PP_BARRIER();  // equalise barrier counts; after it every wave is done with the operand buffers
     PS_STAMP(1);
+    if constexpr (FUSED != 0) {
+      // every wave drained its vector-memory queue at the last K-tile (vmcnt(0)) and passed a barrier since: the PREVIOUS tile's
+      // write-through stores of H are complete -> release its m-tile's count
+      if (mt_done >= 0) fused_signal(mt_done);
+    }
 
     // ---- tile boundary: the next tile's operands start streaming, then this tile's epilogue -----------------------------
     PS_STAMP(2);
@@ -480,6 +614,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     asm volatile("" : "+v"(oz));          // per-tile opaque zero (see setup)
     const int tid_e = tid + oz, lane_e = tid_e & 63;
     if (more) {
+      if constexpr (FUSED == 2) fused_wait(mt_next, polled);   // H rows of the next tile: all 12 producer tiles have stored
       rows_in_lds = a_gather != nullptr;
       setup(lane_e);  // the next tile's row numbers (from LDS) and operand offsets
       issue_bias(bias_par ^ 1);
@@ -530,7 +665,12 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
           const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
           const u32x4 v = u32x4{s0[0], s1[0], s0[1], s1[1]};
           const uint32_t off = off0 + (uint32_t)(q * 64);
+          // FUSED producer: write-through (sc1 = aux 16), so that the consumer's XCD finds the rows in memory
+#ifdef FUSED_EXP_PLAIN_STORES   // timing experiment only (clock build): H stored like the two-launch kernel stores it
           __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)((q ? ok1 : ok0) ? off : OOR), 0, PS_STORE_AUX);
+#else
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)((q ? ok1 : ok0) ? off : OOR), 0, FUSED == 1 ? 16 : PS_STORE_AUX);
+#endif
         }
         off0 += row16;
       }
@@ -553,6 +693,7 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
       }
       PP_BARRIER();
       PS_STAMP(12);
+      if constexpr (FUSED == 1) mt_done = cmt;   // its stores drain under the next tile's main loop
       continue;
     }
 
@@ -800,9 +941,160 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
     if (!more) break;
     issue_kt1();   // into buffer 1 = the staging region just released; lands during the first K-tile's 8 intervals
   }
-  PS_CLOCK(2);
+  if constexpr (FUSED == 0) PS_CLOCK(2);
+  if constexpr (FUSED != 0) {
+    // end of this run (the next position is a tile of the other GEMM, or the list is exhausted): drain this run's last stores,
+    // release its m-tile, hand the two known positions back to the caller; behind the barrier the LDS is free for the other body
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    if constexpr (FUSED == 1) fused_signal(cmt);
+  }
 #undef PS_MFMA
 #undef PS_DMA
+}
+
+template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false, bool DIRECT = false, bool BUF = false>
+__global__ __launch_bounds__(512, 2) void grouped_gemm_ps(
+    const AB* __restrict__ A, const AB* __restrict__ W, const float* __restrict__ bias,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K, int N, int epilogue,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const OT* residual, OT* out, int n_tiles_n,
+    int group_m, const int64_t* __restrict__ a_gather, int a_div, int gather_len, const int32_t* __restrict__ group_end) {
+  ps_body<AB, OT, AFR, DEEP, KEEP, DIRECT, BUF, 0>(A, W, bias, offsets, group_expert, E, K, N, epilogue, row_map, row_scale, residual,
+                                                   out, n_tiles_n, group_m, a_gather, a_div, gather_len, group_end, nullptr);
+}
+
+// ---- the fused expert FFN: H = gelu(X[gather] W1^T + b1) (16-bit, write-through) and out[row_map] = residual + scale (H W2^T + b2)
+//      (f32) from one persistent launch; both GEMMs on 320-row tiles (shared m-tiles), GEMM-1 = the direct-store body, GEMM-2 = the
+//      deep-schedule body with the buffer-addressed f32 epilogue -- the same code, tile for tile, as the two separate launches ------
+struct FusedPlan { int A, B2; };
+// Closed-form balance for a list of `cnt` m-tiles drawn by G workgroups (every workgroup computes it the same way): q2 = n2 / G
+// GEMM-2 tiles for every CU and one more for rem2 of them ("heavy").  All CUs first compute x GEMM-1 tiles (A = x G), then the
+// heavy ones start their extra GEMM-2 tile while the light ones take the GEMM-1 tiles that are left (y each); x minimises
+// max(x c1 + (q2 + 1) c2, y c1 + q2 c2).  The early GEMM-2 batch may only hold tiles whose producers lie in [0, A): whole
+// numbering groups of gm m-tiles.
+__device__ __forceinline__ FusedPlan fused_plan(int cnt, int ntn1, int ntn2, int G, int gm, int c1, int c2) {
+  FusedPlan p;
+  const int n1 = cnt * ntn1, n2 = cnt * ntn2;
+  const int q2 = n2 / G, rem2 = n2 % G;
+  p.A = n1;
+  p.B2 = 0;
+  if (c1 > 0 && rem2 > 0 && rem2 < G) {      // (c1 <= 0: every GEMM-1 tile in front of every GEMM-2 tile, for A/B)
+    int best_x = -1, best_cost = 0x7fffffff;
+    const int x_hi = n1 / G;
+    for (int x = x_hi; x >= 0 && x >= x_hi - 8; --x) {
+      const int left = n1 - x * G;                                     // GEMM-1 tiles for the light CUs after the common part
+      const int y = x + (left + (G - rem2) - 1) / (G - rem2);
+      const int heavy = x * c1 + (q2 + 1) * c2, light = y * c1 + q2 * c2;
+      const int cost = heavy > light ? heavy : light;
+      if (cost < best_cost) { best_cost = cost; best_x = x; }
+    }
+    const int A = best_x * G;
+    const int early_cap = (A / (gm * ntn1)) * gm * ntn2;               // GEMM-2 tiles whose m-tiles are complete within [0, A)
+    const int B2 = rem2 < early_cap ? rem2 : early_cap;
+    if (A < n1 && B2 > 0) { p.A = A; p.B2 = B2; }
+  }
+  return p;
+}
+
+template <typename AB>
+__global__ __launch_bounds__(512, 2) void expert_ffn_fused(
+    const AB* __restrict__ X, const int64_t* __restrict__ a_gather, int a_div, int gather_len, const AB* __restrict__ W1,
+    const float* __restrict__ b1, AB* H, const AB* __restrict__ W2, const float* __restrict__ b2,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ group_expert, int E, int K1, int N1, int N2,
+    const int64_t* __restrict__ row_map, const float* __restrict__ row_scale, const float* residual, float* out, int ntn1, int ntn2,
+    int gm, int c1, int c2, int32_t* ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TBM = 320;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // m-tiles of all row groups (the bodies build the same table again; it is a load and a wave scan)
+  int total_mt;
+  {
+    const int li = lane < E ? lane : E;
+    const int off = offsets[li], end = offsets[li < E ? li + 1 : E];
+    int cnt = lane < E ? (end - off + TBM - 1) / TBM : 0;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const int up = __shfl_up(cnt, sft, 64);
+      if (lane >= sft) cnt += up;
+    }
+    total_mt = __builtin_amdgcn_readlane(cnt, 63);
+  }
+  const int wave = tid >> 6;
+  (void)wave;
+  PS_CLOCK(0);
+  const int home = (int)blockIdx.x & 7;               // the list of this workgroup (blocks b and b + 8 share an XCD)
+  FusedCtl fc;
+  fc.ws = ws;
+  fc.G = (int)gridDim.x >> 3;                         // workgroups per list (the launcher keeps the grid a multiple of 8)
+  fc.mt_lo = (total_mt * home) >> 3;
+  fc.cnt = ((total_mt * (home + 1)) >> 3) - fc.mt_lo;
+  fc.n1 = fc.cnt * ntn1;
+  fc.n2 = fc.cnt * ntn2;
+  {
+    const FusedPlan pl = fused_plan(fc.cnt, ntn1, ntn2, fc.G, gm, c1, c2);
+    fc.A = pl.A;
+    fc.B2 = pl.B2;
+  }
+  fc.ntn1 = ntn1; fc.ntn2 = ntn2;
+  fc.gm = gm;
+  int* const slot2 = reinterpret_cast<int*>(smem);
+  // one ticket of each stage, drawn together (lane 0 / lane 1 of one instruction: one round trip).  The stage-2 ticket is kept
+  // until this workgroup has seen stage 1 exhausted.
+  if (tid < 2) slot2[tid] = __hip_atomic_fetch_add(ws + home + 8 * tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  int t1 = __builtin_amdgcn_readfirstlane(slot2[0]);
+  const int t2 = __builtin_amdgcn_readfirstlane(slot2[1]);
+  __syncthreads();
+  auto run_slot = [&]() {   // walk the slot (fc.stage, fc.slot): runs of GEMM-1 / GEMM-2 tiles alternate between the two bodies
+    fc.j = 0;
+    fused_advance(fc);
+    while (fc.nk != 0) {
+      if (fc.nk == 1) {
+        ps_body<AB, AB, 5, false, false, true, false, 1>(X, W1, b1, offsets, group_expert, E, K1, N1, SMOE_EPI_GELU, nullptr, nullptr,
+                                                         nullptr, H, ntn1, gm, a_gather, a_div, gather_len, nullptr, &fc);
+      } else {
+#ifdef SMOE_CLOCK
+        const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+#endif
+        ps_body<AB, float, 5, true, false, false, true, 2>(H, W2, b2, offsets, group_expert, E, N1, N2, SMOE_EPI_NONE, row_map, row_scale,
+                                                           residual, out, ntn2, gm, nullptr, 1, gather_len, nullptr, &fc);
+#ifdef SMOE_CLOCK
+        PS_COUNT(7, __builtin_amdgcn_s_memtime() - t_in);
+#endif
+      }
+    }
+  };
+  // ---- stage 1: the slot drawn, then any slot nobody else has drawn (only when fewer workgroups run than the grid holds) -------
+  while (t1 < fc.G) {
+    fc.stage = 1;
+    fc.slot = t1;
+    run_slot();
+    if (tid == 0) slot2[0] = __hip_atomic_fetch_add(ws + home, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    t1 = __builtin_amdgcn_readfirstlane(slot2[0]);
+    __syncthreads();
+  }
+  // ---- stage 2 (every stage-1 slot of this list has been drawn by a running workgroup): light slots first ---------------------
+  if (t2 < fc.G) {
+    const int L = fc.G - fc.B2;
+    fc.stage = 2;
+    fc.slot = t2 < L ? fc.B2 + t2 : t2 - L;
+    run_slot();
+  }
+  PS_CLOCK(2);
+  // the last workgroup to leave puts the workspace back to zero for the next launch (kept-zero workspace, as the router's).
+  // This workgroup's own counter adds (issued by thread 0) must have been performed before its leave-count is: they go to other
+  // addresses, and an add that landed after the zeroing would release an m-tile of the NEXT launch early.
+  __syncthreads();
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    slot2[0] = __hip_atomic_fetch_add(ws + FUSED_WS_LEFT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (slot2[0] == (int)gridDim.x - 1) {
+    for (int i = tid; i < FUSED_WS_HDR + total_mt; i += 512)
+      if (i != FUSED_WS_ERR) __hip_atomic_store(ws + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the error word stays)
+  }
 }
 
 template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false>

@@ -327,12 +327,18 @@ class FMoETransformerMLP(nn.Module):
         w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
         b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
         b2 = ex.h4toh.bias.detach().float() if ex.h4toh.bias is not None else None
-        h = ops.grouped_gemm(xn16, w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant, a_gather=pos, a_div=k)
         if k == 1:
             out = x2.clone() if cap >= 0 else torch.empty_like(x2)
-            ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, x2.dtype, row_map=pos, row_scale=score.reshape(-1),
-                             out=out, variant=self.gemm_variant, residual=x2)
+            # both expert GEMMs (scatter folded into GEMM-1's operand fetch, combine + residual into GEMM-2's store) as ONE persistent
+            # launch; same arithmetic tile for tile as the two launches below, which remain for the shapes it does not cover
+            if not (ops.FFN_FUSED and self.gemm_variant == 9 and x2.dtype == torch.float32 and ops.expert_ffn(
+                    xn16, w1, b1, w2, b2, offsets, out, a_gather=pos, a_div=k, row_map=pos, row_scale=score.reshape(-1),
+                    residual=x2) is not None):
+                h = ops.grouped_gemm(xn16, w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant, a_gather=pos, a_div=k)
+                ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, x2.dtype, row_map=pos, row_scale=score.reshape(-1),
+                                 out=out, variant=self.gemm_variant, residual=x2)
         else:
+            h = ops.grouped_gemm(xn16, w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant, a_gather=pos, a_div=k)
             y = ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, cd, variant=self.gemm_variant)
             out = ops.gather_combine(y, inv_pos, score, T, k, x2.dtype, residual=x2)
         return out.reshape(shape)
@@ -397,11 +403,15 @@ class FMoETransformerMLP(nn.Module):
         w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
         b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
         b2 = ex.h4toh.bias.detach().float() if ex.h4toh.bias is not None else None
-        h = ops.grouped_gemm(r["xn16"], w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant, a_gather=pos, a_div=k)
         if k == 1:
-            ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, torch.float32, row_map=pos, row_scale=score.reshape(-1),
-                             out=out, variant=self.gemm_variant, residual=out)
+            if not (ops.FFN_FUSED and self.gemm_variant == 9 and ops.expert_ffn(
+                    r["xn16"], w1, b1, w2, b2, offsets, out, a_gather=pos, a_div=k, row_map=pos, row_scale=score.reshape(-1),
+                    residual=out) is not None):
+                h = ops.grouped_gemm(r["xn16"], w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant, a_gather=pos, a_div=k)
+                ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, torch.float32, row_map=pos, row_scale=score.reshape(-1),
+                                 out=out, variant=self.gemm_variant, residual=out)
         else:
+            h = ops.grouped_gemm(r["xn16"], w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant, a_gather=pos, a_div=k)
             y = ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, cd, variant=self.gemm_variant)
             ops.gather_combine(y, inv_pos, score, T, k, torch.float32, residual=out, out=out)
         return out.reshape(shape)

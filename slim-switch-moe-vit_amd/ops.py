@@ -527,6 +527,91 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+# SLIMMOE_FFN_FUSED=1: one persistent launch for both expert GEMMs of a layer (smoe_expert_ffn).  Bit-identical to the two launches
+# and OFF by default: measured 0.530-0.545 ms against 0.50-0.51 ms for the two launches at ViT-B / 256 images -- what the shared
+# tile list saves in partly filled rounds (~30 us) goes into the switches between the two GEMM bodies, the write-through stores
+# of H and the waits on late m-tiles (profiles/r04_fused_ffn.md).
+FFN_FUSED = _os.environ.get("SLIMMOE_FFN_FUSED", "0") == "1"
+_ffn_ws = {}   # (device index, stream) -> the fused launch's kept-zero workspace
+
+
+def _ffn_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """Ticket / row-counter words of smoe_expert_ffn: allocated ZEROED once per device and stream; every launch leaves them zero
+    (the last workgroup to leave clears them), so no clearing launch runs in front of the GEMMs.  Keyed by the stream: launches on
+    two streams may overlap and must not share counters."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _ffn_ws.get(key)
+    if t is None or t.numel() < nbytes:
+        t = _ffn_ws[key] = torch.zeros(max(nbytes, 1 << 14), dtype=torch.uint8, device=dev)
+    return t
+
+
+def ffn_workspace_error(dev: torch.device) -> bool:
+    """True if any fused FFN launch on this device ever ran out of its wait on a row counter (reads the error words: a sync)."""
+    return any(bool(t.view(torch.int32)[17].item()) for (d, _), t in _ffn_ws.items() if d == dev.index)   # FUSED_WS_ERR
+
+
+def expert_ffn(X: torch.Tensor, W1: torch.Tensor, b1: Optional[torch.Tensor], W2: torch.Tensor, b2: Optional[torch.Tensor],
+               offsets: torch.Tensor, out: torch.Tensor, a_gather: Optional[torch.Tensor] = None, a_div: int = 1,
+               row_map: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
+               residual: Optional[torch.Tensor] = None, group_expert: Optional[torch.Tensor] = None,
+               H: Optional[torch.Tensor] = None, rows_hint: Optional[int] = None) -> Optional[torch.Tensor]:
+    """``out[row_map[r]] = residual[row_map[r]] + row_scale[row_map[r]] * (gelu(X[a_gather[r] / a_div] W1[e]^T + b1[e]) W2[e]^T + b2[e])``
+    -- both expert GEMMs of a MoE layer with the top-1 combine -- in ONE persistent launch (smoe_expert_ffn); bit-identical to
+    grouped_gemm(EPI_GELU) followed by grouped_gemm(row_map, row_scale, residual).  Returns ``out``, or None when the shape is
+    outside the fused launch's reach (the caller then issues the two launches)."""
+    _chk(X, "X", ndim=2)
+    _chk(W1, "W1", X.dtype, 3)
+    _chk(W2, "W2", X.dtype, 3)
+    _chk(offsets, "offsets", torch.int32, 1)
+    _chk(out, "out", torch.float32, 2)
+    E, h, d_in = W1.shape
+    E2, d_out, h2 = W2.shape
+    if X.shape[1] != d_in or h2 != h or E2 != E or out.shape[1] != d_out:
+        raise RuntimeError(f"expert_ffn: shapes disagree: X {tuple(X.shape)}, W1 {tuple(W1.shape)}, W2 {tuple(W2.shape)}, out {tuple(out.shape)}")
+    M = X.shape[0]
+    if a_gather is not None:
+        _chk(a_gather, "a_gather", torch.int64, 1, align=8)
+        M = a_gather.numel()
+    G = offsets.numel() - 1
+    if group_expert is None:
+        if G != E:
+            raise RuntimeError("offsets: expected E+1 entries")
+    else:
+        _chk(group_expert, "group_expert", torch.int32, 1)
+    for t, nm, n in ((b1, "b1", h), (b2, "b2", d_out)):
+        if t is not None:
+            _chk(t, nm, torch.float32, 2)
+            if tuple(t.shape) != (E, n):
+                raise RuntimeError(f"{nm}: expected [E,{n}]")
+    if row_map is not None:
+        _chk(row_map, "row_map", torch.int64, 1, align=8)
+    if row_scale is not None:
+        _chk(row_scale, "row_scale", torch.float32, align=4)
+    if residual is not None:
+        _chk(residual, "residual", torch.float32, 2)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise RuntimeError("residual: expected the shape of out")
+    if X.dtype not in (torch.float16, torch.bfloat16) or M == 0:
+        return None
+    if H is None:
+        H = torch.empty((M, h), dtype=X.dtype, device=X.device)
+    else:
+        _chk(H, "H", X.dtype, 2)
+    lib = _lib.load()
+    ws_bytes = lib.smoe_expert_ffn_workspace_bytes(M, G)
+    ws = _ffn_workspace(X.device, ws_bytes)
+    rows = M if rows_hint is None else rows_hint
+    with _timed("expert_ffn", {"flops": 2.0 * rows * h * (d_in + d_out)}, X):
+        rc = lib.smoe_expert_ffn(_ptr(X), _ptr(a_gather), a_div, _ptr(W1), _ptr(b1), _ptr(H), _ptr(W2), _ptr(b2), _ptr(offsets),
+                                 _ptr(group_expert), G, E, M, d_in, h, d_out, dtype_code(X.dtype), _ptr(row_map), _ptr(row_scale),
+                                 _ptr(residual), _ptr(out), out.shape[0], F32, _ptr(ws), ws.numel(), _stream(X))
+    if rc == -1:
+        return None
+    _lib.check(rc, "smoe_expert_ffn")
+    return out
+
+
 def grouped_gemm_gelu_keep(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], offsets: torch.Tensor,
                            group_expert: Optional[torch.Tensor] = None, variant: int = DEFAULT_GEMM_VARIANT):
     """(H, gelu(H)) with H = A W[e]^T + bias[e] per row group -- the first expert linear of the training forward, which keeps

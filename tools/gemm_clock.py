@@ -6,7 +6,8 @@ libslimmoe_hip_clock.so: two s_memtime / s_memrealtime stamps per workgroup of t
 >= SECONDS of back-to-back launches of each GEMM on random operands, then the stamps of the last launch:
 clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, median over workgroups.  Prints ONE JSON line:
 
-    {"gemm1_mhz": ..., "gemm2_mhz": ..., "gemm1_ms": ..., "gemm2_ms": ..., "seconds_each": ..., "workgroups": ...}
+    {"gemm1_mhz": ..., "gemm2_mhz": ..., "fused_mhz": ..., "gemm1_ms": ..., "gemm2_ms": ..., "fused_ms": ..., "seconds_each": ..., ...}
+(fused = smoe_expert_ffn, both GEMMs in one persistent launch)
 
 bench.py starts it as a child process (SLIMMOE_LIB selects the library at import) and reports `frac_of_clocked_peak` from it.
 usage: SLIMMOE_LIB=slim-switch-moe-vit_amd/libslimmoe_hip_clock.so python3 tools/gemm_clock.py [seconds_each=2.0] [batch=256]"""
@@ -55,10 +56,13 @@ def main():
     def gemm2():
         ops.grouped_gemm(hbuf, w2, b2, offsets, ops.EPI_NONE, row_map=pos, row_scale=score, out=out, variant=9, residual=res)
 
+    def fused():
+        ops.expert_ffn(x16, w1, b1, w2, b2, offsets, out, a_gather=pos, row_map=pos, row_scale=score, residual=res, H=hbuf)
+
     result = {"seconds_each": seconds, "batch": batch}
     gemm1()
     torch.cuda.synchronize()
-    for name, fn in (("gemm1", gemm1), ("gemm2", gemm2)):
+    for name, fn in (("gemm1", gemm1), ("gemm2", gemm2), ("fused", fused)):
         t0 = time.perf_counter()
         n = 0
         while time.perf_counter() - t0 < seconds:                  # back to back: the clock settles under THIS kernel's load
@@ -72,9 +76,14 @@ def main():
             fn()
         e1.record()
         torch.cuda.synchronize()
-        buf = np.zeros(1024 * 4, dtype=np.uint64)
+        if name == "fused":                                        # per-workgroup counts of ONE fused launch
+            clr = lib.__getattr__("smoe_clock_clear_stamps"); clr.restype = ctypes.c_int; clr.argtypes = []
+            clr()
+            fn()
+            torch.cuda.synchronize()
+        buf = np.zeros(1024 * 8, dtype=np.uint64)
         assert rd(buf.ctypes.data, buf.size) == 0
-        st = buf.reshape(1024, 4).astype(np.int64)
+        st = buf.reshape(1024, 8).astype(np.int64)
         ok = (st[:, 0] > 0) & (st[:, 2] > st[:, 0]) & (st[:, 3] > st[:, 1])
         st = st[ok]
         mhz = (st[:, 2] - st[:, 0]) / (st[:, 3] - st[:, 1]) * 100.0
@@ -83,6 +92,15 @@ def main():
         result[f"{name}_ms"] = round(e0.elapsed_time(e1) / 20, 4)
         result[f"{name}_kernel_cycles_median"] = int(np.median(st[:, 2] - st[:, 0]))
         result["workgroups"] = int(ok.sum())
+        if name == "fused":
+            result["fused_spins_per_wg_median_max"] = [int(np.median(st[:, 4])), int(st[:, 4].max())]
+            result["fused_gemm1_tiles_per_wg_min_max"] = [int(st[:, 5].min()), int(st[:, 5].max())]
+            result["fused_gemm2_tiles_per_wg_hist"] = np.bincount(st[:, 6]).tolist()
+            g2 = st[:, 7] / np.maximum(st[:, 6], 1)
+            g1 = (st[:, 2] - st[:, 0] - st[:, 7]) / np.maximum(st[:, 5], 1)
+            result["fused_cycles_per_gemm1_tile_p10_p50_p90"] = [int(np.percentile(g1, q)) for q in (10, 50, 90)]
+            result["fused_cycles_per_gemm2_tile_p10_p50_p90"] = [int(np.percentile(g2, q)) for q in (10, 50, 90)]
+            result["fused_wg_cycles_p10_p50_p90_max"] = [int(np.percentile(st[:, 2] - st[:, 0], q)) for q in (10, 50, 90, 100)]
     print(json.dumps(result), flush=True)
 
 

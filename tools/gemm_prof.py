@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Single-variant grouped-GEMM driver for rocprofv3 runs and calibration.
-usage: gemm_prof.py <variant> <shape: fc1|fc1n|qkv|fc2|fc2h|sq8k|sq4k> [iters] [images (default 256)]"""
+usage: gemm_prof.py <variant> <shape: fc1|fc1n|qkv|fc2|fc2h|sq8k|sq4k|ffn> [iters] [images (default 256)]
+(ffn = smoe_expert_ffn: both expert GEMMs of a layer, gathered rows / combine / residual as the model runs them, one launch)"""
 import os
 import sys
 
@@ -19,6 +20,30 @@ def main():
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
     dev = "cuda:0"
     torch.manual_seed(0)
+    if shape == "ffn":
+        T, d, h, E = (int(sys.argv[4]) if len(sys.argv) > 4 else 256) * 197, 768, 3072, 8
+        idx = torch.randint(0, E, (T, 1), device=dev)
+        counts, offsets, pos, inv_pos, _ = ops.dispatch_plan(idx, E)
+        x16 = torch.randn(T, d, device=dev).half()
+        w1, w2 = (torch.randn(E, h, d, device=dev) * 0.02).half(), (torch.randn(E, d, h, device=dev) * 0.02).half()
+        b1, b2 = torch.randn(E, h, device=dev) * 0.02, torch.randn(E, d, device=dev) * 0.02
+        score, res = torch.rand(T, device=dev), torch.randn(T, d, device=dev)
+        hbuf, out = torch.empty(T, h, device=dev, dtype=torch.float16), torch.empty(T, d, device=dev)
+
+        def run():
+            ops.expert_ffn(x16, w1, b1, w2, b2, offsets, out, a_gather=pos, row_map=pos, row_scale=score, residual=res, H=hbuf)
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            run()
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / iters
+        print(f"fused expert FFN T={T} d={d} h={h} E={E}: {ms:.4f} ms  {4.0*T*d*h/ms/1e9:.1f} TFLOP/s", flush=True)
+        return
     if shape.startswith("sq"):
         n = 8192 if shape == "sq8k" else 4096
         E, M, K, N = 1, n, n, n

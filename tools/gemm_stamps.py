@@ -40,6 +40,9 @@ def main():
     def run():
         if shape == "qkv":      # one group, N 2304, f16 out: the 256-row direct-store instantiation
             ops.grouped_gemm(x16, wq, bq, one, ops.EPI_NONE, torch.float16, variant=variant, out=qkv)
+        elif shape == "ffn":     # smoe_expert_ffn (fused launch): the stamps left are those of its GEMM-1 runs' tiles 2.. (the GEMM-2 runs
+            #                      overwrite tiles 0-1 of every workgroup)
+            ops.expert_ffn(x16, w1, b1, w2, b2, offsets, out, a_gather=pos, row_map=pos, row_scale=score, residual=res, H=hbuf)
         elif shape == "fc1":
             ops.grouped_gemm(x16, w1, b1, offsets, ops.EPI_NONE if os.environ.get("SMOE_EPI") == "none" else ops.EPI_GELU,
                              torch.float16, variant=variant, a_gather=pos, out=hbuf)
@@ -68,11 +71,11 @@ def main():
              (4, 5): "pass0: rows + GELU + LDS write", (5, 6): "pass0: wait + barrier", (6, 7): "pass0: LDS read + stores",
              (8, 9): "last pass: vmcnt(0)", (9, 10): "last pass: barrier", (10, 11): "last pass: stores", (11, 12): "last barrier",
              (0, 12): "whole tile", (1, 12): "tile boundary (everything but the main loop)"}
-    if shape in ("fc1", "qkv") and variant != 14:   # the direct-store epilogue (16-bit output, no row map): stamps 5 and 12 only
+    if shape in ("fc1", "qkv", "ffn") and variant != 14:   # the direct-store epilogue (16-bit output, no row map): stamps 5 and 12 only
         names = {(0, 1): "main loop", (1, 2): "advance", (2, 3): "setup (gather addresses)", (3, 4): "issue kt0 + kt1",
                  (4, 5): "direct epilogue: bias + GELU + pack + swaps + 20 stores issued", (5, 12): "wait for K-tile 0 + barrier",
                  (0, 12): "whole tile", (1, 12): "tile boundary (everything but the main loop)"}
-    sel = st[:, 1:6, :]          # tiles 1..5 of every workgroup (steady state, a next tile exists)
+    sel = st[:, (2 if shape == "ffn" else 1):6, :]          # tiles 1..5 of every workgroup (steady state, a next tile exists)
     ok = (sel[:, :, 12] > 0) & (sel[:, :, 0] > 0)
     print(f"variant {variant} {shape} grid={os.environ.get('SMOE_PS_GRID', 'all')} epi={os.environ.get('SMOE_EPI', 'default')}: {int(ok.sum())} tiles sampled; s_memtime = shader cycles (k = 1000 cycles)")
     for (a, b), nm in names.items():
