@@ -106,6 +106,17 @@ int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, const float* ln
 int smoe_zero_row_output(const float* bg, int E, int k, const float* w2, const float* b1, const float* b2, int d, int h,
                          float* out, void* stream);
 
+/* smoe_skip_gate_bwd: backward of one gated half of the residual-MoE block in TRAINING (models/resMoE.py:68-77: hard masks with
+ * the straight-through estimator; 131-143: tk = xn * m1, skip_tk = xn * m0, out = f(tk) + tk + skip_tk).  xn [T,d] f32 = the normed
+ * activations, g_f [T,d] (f32 / f16 / bf16) = d loss / d tk as the operator's input, g_out [T,d] f32 = d loss / d out (or NULL),
+ * mask [T,2] f32 = the forward's decisions (skip, keep: smoe_gate_ln_router), gate_w [d], gate_b [1] or NULL.  One pass, p recomputed:
+ *     dz[t]  = -<g_f[t], xn[t]> p (1 - p),  p = sigmoid(<xn[t], gate_w> + gate_b)          (d loss / d gate logit; f32 [T] or NULL)
+ *     dxn[t] = g_f[t] * keep[t] + g_out[t] + dz[t] * gate_w                                 (f32 [T,d]: into the LayerNorm backward)
+ * gate_on = 0 (Gate.disable: constant masks, no gradient): dxn = g_f + g_out, dz = 0.  d in {192, 384, 768, 1024}.
+ * The gate's parameter gradients follow from dz: dW = dz^T xn (smoe_gate_wgrad with E = 1), db = sum dz.                      */
+int smoe_skip_gate_bwd(const float* xn, const void* g_f, int g_f_dtype, const float* g_out, const float* gate_w,
+                       const float* gate_b, const float* mask, int gate_on, int64_t T, int d, float* dxn, float* dz, void* stream);
+
 /* LayerNorm alone (same arithmetic as the fused form; the `norm1` of models/vision_transformer.py:320 feeding the
  * attention GEMMs in 16 bit): d in {192, 384, 768, 1024}.                                              */
 int smoe_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, float eps, int64_t T, int d,

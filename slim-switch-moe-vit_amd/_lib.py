@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SLIMMOE_LIB: another build of the same sources (a diagnostic build, `make DIAG=-DSMOE_DIAG`, whose environment switches the
 # tools under tools/ use); the ABI and symbol checks below apply to it all the same
 LIB_PATH = os.environ.get("SLIMMOE_LIB") or os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -97,6 +97,8 @@ SIGNATURES = {
     "smoe_a2a_wait": (c_int, [c_void_p, c_void_p]),
     "smoe_a2a_last_ticket": (c_int64, [c_void_p]),
     "smoe_a2a_wait_ticket": (c_int, [c_void_p, c_int64, c_void_p]),
+    "smoe_skip_gate_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
+                                   c_void_p, c_void_p]),
     "smoe_zero_row_output": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }
 

@@ -115,7 +115,102 @@ __global__ __launch_bounds__(256) void zero_row_output_kernel(const float* __res
   if (lane == 0) out[c] = total;
 }
 
+// Backward of one gated half of the residual-MoE block in TRAINING (models/resMoE.py:68-77 hard masks with the straight-through
+// estimator, 131-143): with xn the normed activations, keep / skip the hard decisions and p = sigmoid(<xn, w> + b),
+//     tk = xn * m1,  skip_tk = xn * m0,  out = f(tk) + tk + skip_tk,   m1 = keep + p.detach() - p,  m0 = skip + (1 - p).detach() - (1 - p)
+// and the gradients g_f = dL/d(tk as the operator's input), g_out = dL/d(out):
+//     dL/dp = -<g_f, xn>            (the two <g_out, xn> terms of m1 and m0 cancel: d m1 / dp = -1, d m0 / dp = +1)
+//     dz    = dL/dp * p (1 - p)     (d loss / d gate logit; dw = dz^T xn and db = sum dz follow outside: smoe_gate_wgrad)
+//     dxn   = g_f * keep + g_out + dz * w
+// One pass: 16 lanes per token (the router's layout), p recomputed from xn (no saved activations beyond xn and the decisions).
+// gate_on = 0 (a disabled gate passes everything and has no gradient): dxn = g_f + g_out, dz = 0.
+template <typename GT, int NJ>
+__global__ __launch_bounds__(R16_THREADS, 4) void skip_gate_bwd_kernel(const float* __restrict__ xn, const GT* __restrict__ g_f,
+                                                                       const float* __restrict__ g_out, const float* __restrict__ w,
+                                                                       const float* __restrict__ b, const float* __restrict__ mask,
+                                                                       int gate_on, int64_t T, float* __restrict__ dxn,
+                                                                       float* __restrict__ dz_out) {
+  constexpr int d = 64 * NJ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, u = lane & 15;
+  const int64_t slot_stride = (int64_t)gridDim.x * (R16_THREADS / 64) * 4;
+  const float bias = (b && gate_on) ? *b : 0.f;
+  for (int64_t it0 = ((int64_t)blockIdx.x * (R16_THREADS / 64) + wave) * 4; it0 < T; it0 += slot_stride) {
+    const int64_t t = it0 + q;
+    const bool live = t < T;
+    const int64_t tc = live ? t : T - 1;
+    const int64_t rowoff = tc * (int64_t)d + u * 4;
+    f32x4 xv[NJ], gv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      xv[j] = *reinterpret_cast<const f32x4*>(xn + rowoff + 64 * j);
+      float tmp[4];
+      load4(g_f + rowoff + 64 * j, tmp);
+      gv[j] = f32x4{tmp[0], tmp[1], tmp[2], tmp[3]};
+    }
+    float az = 0.f, ad = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + u * 4 + 64 * j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        az = fmaf(xv[j][i], wv[i], az);
+        ad = fmaf(gv[j][i], xv[j][i], ad);
+      }
+    }
+    const float z = row16_sum(az) + bias, dot = row16_sum(ad);
+    const float p = 1.0f / (1.0f + expf(-z));
+    const float dz = gate_on ? -dot * p * (1.0f - p) : 0.f;
+    const float keep = gate_on ? mask[tc * 2 + 1] : 1.f;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + u * 4 + 64 * j);
+        f32x4 o = gv[j] * f32x4{keep, keep, keep, keep} + wv * f32x4{dz, dz, dz, dz};
+        if (g_out) o += *reinterpret_cast<const f32x4*>(g_out + rowoff + 64 * j);
+        *reinterpret_cast<f32x4*>(dxn + rowoff + 64 * j) = o;
+      }
+      if (u == 0 && dz_out) dz_out[t] = dz;
+    }
+  }
+}
+
+template <typename GT>
+int launch_skip_gate_bwd(const float* xn, const void* g_f, const float* g_out, const float* w, const float* b, const float* mask,
+                         int gate_on, int64_t T, int d, float* dxn, float* dz, hipStream_t s) {
+  int64_t need = (T + 15) / 16;
+  const int grid = (int)(need < 1 ? 1 : (need > 4096 ? 4096 : need));
+#define SGB(NJ) hipLaunchKernelGGL((skip_gate_bwd_kernel<GT, NJ>), dim3(grid), dim3(R16_THREADS), 0, s, xn, (const GT*)g_f, g_out, w, b, mask, gate_on, T, dxn, dz)
+  switch (d) {
+    case 192: SGB(3); break;
+    case 384: SGB(6); break;
+    case 768: SGB(12); break;
+    case 1024: SGB(16); break;
+    default: smoe_set_error("smoe_skip_gate_bwd: unsupported d=%d", d); return 1;
+  }
+#undef SGB
+  SMOE_CHECK_LAUNCH("smoe_skip_gate_bwd");
+  return 0;
+}
+
 }  // namespace
+
+extern "C" int smoe_skip_gate_bwd(const float* xn, const void* g_f, int g_f_dtype, const float* g_out, const float* gate_w,
+                                  const float* gate_b, const float* mask, int gate_on, int64_t T, int d, float* dxn, float* dz,
+                                  void* stream) {
+  if (T == 0) return 0;
+  SMOE_REQUIRE(xn && g_f && gate_w && dxn, "smoe_skip_gate_bwd: null pointer");
+  SMOE_REQUIRE(!gate_on || mask, "smoe_skip_gate_bwd: an enabled gate needs the forward's decisions (mask)");
+  SMOE_REQUIRE(T > 0 && T < (1ll << 31), "smoe_skip_gate_bwd: bad T");
+  hipStream_t s = (hipStream_t)stream;
+  switch (g_f_dtype) {
+    case SMOE_F32: return launch_skip_gate_bwd<float>(xn, g_f, g_out, gate_w, gate_b, mask, gate_on, T, d, dxn, dz, s);
+    case SMOE_F16: return launch_skip_gate_bwd<f16>(xn, g_f, g_out, gate_w, gate_b, mask, gate_on, T, d, dxn, dz, s);
+    case SMOE_BF16: return launch_skip_gate_bwd<bf16_bits>(xn, g_f, g_out, gate_w, gate_b, mask, gate_on, T, d, dxn, dz, s);
+  }
+  smoe_set_error("smoe_skip_gate_bwd: bad g_f dtype %d", g_f_dtype);
+  return 1;
+}
 
 extern "C" int smoe_gate_ln_router_supported(int d, int E, int k) {
   return ((d == 192 || d == 384 || d == 768 || d == 1024) && E >= 0 && E <= 8 && (E == 0 || (k >= 1 && k <= E && k <= R16_MAX_K))) ? 1 : 0;

@@ -324,6 +324,29 @@ def gate_ln_router(x: torch.Tensor, gate_w: torch.Tensor, gate_b: Optional[torch
     return {"xn16": xn16, "xn32": xn32, "idx": idx, "idx_plan": idx_plan, "score": score, "mask": mask}
 
 
+def skip_gate_bwd(xn: torch.Tensor, g_f: torch.Tensor, g_out: Optional[torch.Tensor], gate_w: torch.Tensor,
+                  gate_b: Optional[torch.Tensor], mask: Optional[torch.Tensor], gate_on: bool = True):
+    """Backward of one gated half of the residual-MoE block in training (smoe_skip_gate_bwd): (dxn f32 [T,d], dz f32 [T])."""
+    _chk(xn, "xn", torch.float32, 2)
+    _chk(g_f, "g_f", ndim=2)
+    T, d = xn.shape
+    if tuple(g_f.shape) != (T, d):
+        raise RuntimeError("skip_gate_bwd: g_f must have xn's shape")
+    if g_out is not None:
+        _chk(g_out, "g_out", torch.float32, 2)
+    gw = gate_w.detach().reshape(-1)
+    _chk(gw, "gate_w", torch.float32, 1, align=4)
+    gb = gate_b.detach().reshape(-1) if gate_b is not None else None
+    if mask is not None:
+        _chk(mask, "mask", torch.float32, 2, align=4)
+    dxn = torch.empty_like(xn)
+    dz = torch.empty(T, dtype=torch.float32, device=xn.device)
+    rc = _lib.load().smoe_skip_gate_bwd(_ptr(xn), _ptr(g_f), dtype_code(g_f.dtype), _ptr(g_out), _ptr(gw), _ptr(gb), _ptr(mask),
+                                        1 if gate_on else 0, T, d, _ptr(dxn), _ptr(dz), _stream(xn))
+    _lib.check(rc, "smoe_skip_gate_bwd")
+    return dxn, dz
+
+
 def zero_row_output(bg: Optional[torch.Tensor], k: int, w2: torch.Tensor, b1: Optional[torch.Tensor],
                     b2: Optional[torch.Tensor]) -> torch.Tensor:
     """out[d] = sum_j score_j (W2[e_j] gelu(b1[e_j]) + b2[e_j]) for the NaiveGate routing of an all-zero row."""

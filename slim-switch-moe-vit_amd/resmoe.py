@@ -157,6 +157,102 @@ def _residual_block_composed(blk, x):
     return blk.drop_path(blk.mlp(enter)) + enter + bypass
 
 
+class _GateLNFn(th.autograd.Function):
+    """One gated half's front end in TRAINING (models/resMoE.py:126-131 / 137-140 with Gate.forward's hard branch, 68-77):
+
+        xn = norm(x);  m = gate(xn);  tk = xn * m[..., 1:]          ->  (xn f32, tk, mask)
+
+    forward: ONE HIP pass (smoe_gate_ln_router: LayerNorm, gate logit, decision on the f64-accurate logit, the 16-bit masked
+    operand image for the attention half / + one scaled copy for the f32 image the MoE router reads); backward: smoe_skip_gate_bwd
+    (straight-through estimator: d m1 / d p = -1, d m0 / d p = +1; p recomputed) -> smoe_layernorm_bwd -> smoe_gate_wgrad.  The
+    caller computes out = f(tk) + xn (the reference's f(tk) + tk + skip_tk in value; the mask gradients are this Function's)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, gate_w, gate_b, eps, thr, skip_count, want16):
+        r = ops.gate_ln_router(x, gate_w, gate_b, thr, ln=(ln_w.detach().float(), ln_b.detach().float() if ln_b is not None else None, eps),
+                               xn16_dtype=th.float16 if want16 else None, want_xn32=True, want_mask=True, skip_count=skip_count)
+        xn, mask = r["xn32"], r["mask"]
+        if want16:
+            tk = r["xn16"]
+        else:   # the f32 image with the skipped rows zeroed: what the MoE's router and scatter read
+            ident = _ident_rows(x.shape[0], x.device)
+            tk = ops.scatter_rows(xn, ident, 1, th.float32, scale=mask[:, 1].contiguous())
+        ctx.eps, ctx.gate_on = eps, thr is not None
+        ctx.save_for_backward(x, ln_w, gate_w, gate_b if gate_b is not None else th.empty(0, device=x.device), xn, mask)
+        ctx.has_gb, ctx.has_lb = gate_b is not None, ln_b is not None
+        ctx.mark_non_differentiable(mask)
+        return xn, tk, mask
+
+    @staticmethod
+    def backward(ctx, d_xn, d_tk, _d_mask):
+        x, ln_w, gate_w, gate_b, xn, mask = ctx.saved_tensors
+        if d_tk is None:
+            d_tk = th.zeros_like(xn)
+        d_tk = d_tk.contiguous()
+        if d_xn is not None and not (d_xn.dtype == th.float32 and d_xn.is_contiguous()):
+            d_xn = d_xn.float().contiguous()
+        dxn, dz = ops.skip_gate_bwd(xn, d_tk, d_xn, gate_w, gate_b if ctx.has_gb else None, mask, ctx.gate_on)
+        dx, dg, dbeta = ops.layernorm_bwd(x, dxn, ln_w.detach().float(), ctx.eps)
+        dgw = dgb = None
+        if ctx.gate_on:
+            dgw = ops.gate_wgrad(dz.reshape(-1, 1), xn).reshape(gate_w.shape).to(gate_w.dtype)
+            dgb = dz.sum().reshape(gate_b.shape).to(gate_b.dtype) if ctx.has_gb else None
+        return dx, dg.to(ln_w.dtype), (dbeta if ctx.has_lb else None), dgw, dgb, None, None, None, None
+
+
+_ident_cache = {}
+
+
+def _ident_rows(n: int, device) -> th.Tensor:
+    key = (n, str(device))
+    t = _ident_cache.get(key)
+    if t is None:
+        t = _ident_cache[key] = th.arange(n, dtype=th.int64, device=device)
+    return t
+
+
+def _train_ok(blk, x) -> bool:
+    """fp16-autocast TRAINING of the residual-MoE block on the library's kernels: hard gates without dropout (the reference's
+    construction, resMoE.py:163-170), LayerNorms / attention / MoE operator the training kernels cover, own stochastic depth."""
+    from . import dense
+    from .vit import Attention, DropPath
+    d = x.shape[-1]
+    if not (x.is_cuda and x.dim() == 3 and x.dtype == th.float32 and x.is_contiguous() and dense.autocast_half_training(x)):
+        return False
+    gates_ok = all(isinstance(g, Gate) and (g.is_hard or not g.training) and not (g.training and g.head[0].p > 0)
+                   for g in (blk.dense_gate, blk.moe_gate))
+    return (gates_ok and isinstance(blk.attn, Attention) and (blk.stochastic_depth_inactive() or isinstance(blk.drop_path, DropPath))
+            and all(dense.layer_norm_supported(x, n) for n in (blk.norm1, blk.norm2))
+            and getattr(blk.mlp, "forward_add", None) is not None and ops.gate_ln_router_supported(d, 0, 1))
+
+
+def _gate_ln(x2, norm, gate):
+    lin = gate.head[1]
+    thr = gate.active_threshold()
+    if thr is not None:
+        gate._total_tokens += x2.shape[0]
+    return norm.weight, norm.bias, lin.weight, lin.bias, norm.eps, thr, (gate.skip_counter(x2.device) if thr is not None else None)
+
+
+def _residual_block_train(blk, x):
+    """models/resMoE.py:126-145 in fp16-autocast training, forward and backward on the library's kernels: per half ONE pass for
+    LayerNorm + gate (+ the masked operand image), the operator's own training path (qkv / attention / projection GEMMs with the
+    normed residual -- and stochastic depth's per-row factor -- in the projection's store; the MoE operator with the residual in
+    its combine), and in the backward the gate's straight-through gradients fused with the gradient of the residual in one pass in
+    front of the LayerNorm backward kernel.  Preconditions: _train_ok."""
+    B, N, d = x.shape
+    x2 = x.reshape(B * N, d)
+    _, rows1 = blk._depth_scale(x)
+    xn, tk16, _ = _GateLNFn.apply(x2, *_gate_ln(x2, blk.norm1, blk.dense_gate), True)
+    a, added = blk.attn(tk16.reshape(B, N, d), residual=xn.reshape(B, N, d), row_scale=rows1)
+    if not added:   # (the projection could not take the residual: add it here; the gate gradients are unaffected)
+        a = xn.reshape(B, N, d) + (a if rows1 is None else a * rows1.reshape(B, N, 1).to(a.dtype))
+    x1 = a.reshape(B * N, d)
+    _, rows2 = blk._depth_scale(x)
+    xn2, tk32, _ = _GateLNFn.apply(x1, *_gate_ln(x1, blk.norm2, blk.moe_gate), False)
+    return blk.mlp.forward_add(tk32.reshape(B, N, d), xn2.reshape(B, N, d), row_scale=rows2)
+
+
 def _fused_ok(blk, x) -> bool:
     from .vit import _autocast_half_inference, Attention
     d = x.shape[-1]
@@ -201,6 +297,8 @@ def forward_residule_moe(self, x):
     185-186)."""
     if _fused_ok(self, x):
         return _residual_block_fused(self, x)
+    if _train_ok(self, x):
+        return _residual_block_train(self, x)
     if x.is_cuda and th.is_autocast_enabled():
         from .vit import _warn_fallback
         _warn_fallback("residual-MoE block", "config: composed from torch modules (needs fp16-autocast inference, f32 contiguous "

@@ -347,3 +347,79 @@ def test_residual_block_against_the_reference_forward_residule_moe_fixture(mode)
     tol = 6e-3 if fused else 1e-4
     print(f"{mode}: max |y - reference| = {float(diff.abs().max()):.3e} (scale {scale:.2f}), rel L2 {float(diff.norm() / ref.norm()):.2e}")
     assert float(diff.abs().max()) <= tol * scale and float(diff.norm() / ref.norm()) <= tol
+
+
+# ---- training: the gate's backward kernel, the gated half's Function, the whole block against the reference's gradients ----------
+def _rel(got, ref):
+    return float((got.double().cpu() - ref.double().cpu()).norm() / ref.double().cpu().norm().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize("d,gdt", [(192, torch.float32), (768, torch.float16), (384, torch.float32), (1024, torch.float16)])
+def test_skip_gate_backward_kernel_matches_float64_autograd_of_the_reference_formula(d, gdt):
+    """smoe_skip_gate_bwd against float64 autograd through the reference's own expressions (resMoE.py:69-77, 131-136):
+    masks with the straight-through terms, tk = x * m1, skip_tk = x * m0, L = <g_f, tk> + <g_out, tk + skip_tk>."""
+    T = 777
+    g = _gen(d)
+    xn = torch.randn(T, d, generator=g)
+    w, b = torch.randn(d, generator=g) * 0.1, torch.randn(1, generator=g) * 0.1
+    g_f = (torch.randn(T, d, generator=g) * 0.3).to(gdt)
+    g_out = torch.randn(T, d, generator=g) * 0.2
+    thr = 0.55
+    xr, wr, br = xn.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    prob = torch.sigmoid(xr @ wr + br)[:, None]
+    _prob = 1 - prob
+    skip_tk = (prob > thr).double() + _prob.detach() - _prob
+    tk = (prob <= thr).double() + prob.detach() - prob
+    loss = (g_f.double() * (xr * tk)).sum() + (g_out.double() * (xr * tk + xr * skip_tk)).sum()
+    loss.backward()
+    mask = torch.cat([(prob > thr).float(), (prob <= thr).float()], dim=1).detach().float()
+    dxn, dz = ops.skip_gate_bwd(xn.to(DEV), g_f.to(DEV), g_out.to(DEV), w.to(DEV), b.to(DEV), mask.to(DEV))
+    assert _rel(dxn, xr.grad) <= 2e-5
+    dw = ops.gate_wgrad(dz.reshape(-1, 1), xn.to(DEV)).reshape(-1)
+    assert _rel(dw, wr.grad) <= 2e-5 and abs(float(dz.sum()) - float(br.grad)) <= 2e-5 * max(1.0, abs(float(br.grad)))
+    # a disabled gate: constant masks, no gate gradient
+    dxn0, dz0 = ops.skip_gate_bwd(xn.to(DEV), g_f.to(DEV), g_out.to(DEV), w.to(DEV), b.to(DEV), None, gate_on=False)
+    assert _rel(dxn0, g_f.double() + g_out.double()) <= 1e-6 and float(dz0.abs().max()) == 0.0
+
+
+def test_residual_block_training_against_the_reference_forward_residule_moe_gradients():
+    """fp16-autocast TRAINING of the block on the library's kernels (resmoe._residual_block_train) against output AND gradients of
+    the reference's own ``forward_residule_moe`` in train mode (hard gates on ``_threshold``, straight-through estimator;
+    tests/golden/make_golden_resmoe.py): y, dL/dx and every parameter gradient -- LayerNorms, qkv / proj, the E = 1 expert
+    (= the fixture's Mlp), both gates."""
+    from slim_switch_moe_vit_amd import resmoe
+    g = _fixture("ref_resblock_tiny.npz")
+    blk = _block_from_fixture(g).train()
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    dy = torch.from_numpy(g["dy"]).to(DEV)
+    calls = {"n": 0}
+    orig = resmoe._residual_block_train
+
+    def spy(b, t):
+        calls["n"] += 1
+        return orig(b, t)
+    resmoe._residual_block_train = spy
+    try:
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = blk(x)
+        y.backward(dy)
+    finally:
+        resmoe._residual_block_train = orig
+    assert calls["n"] == 1, "the training block must take the own-kernel path"
+    T = x.shape[0] * x.shape[1]
+    for gt, key in ((blk.dense_gate, "train_dense_mask"), (blk.moe_gate, "train_moe_mask")):
+        assert gt._total_tokens == T and gt._skipped_tokens == float(np.rint(g[key])[..., 0].sum()), key
+    ref_y = torch.from_numpy(g["train_y"])
+    assert float((y.float().cpu() - ref_y).abs().max()) <= 6e-3 * max(1.0, float(ref_y.abs().max()))
+    worst = [(_rel(x.grad, torch.from_numpy(g["train_dx"])), "x")]
+    names = {"mlp.experts.htoh4.weight": "mlp.fc1.weight", "mlp.experts.htoh4.bias": "mlp.fc1.bias",
+             "mlp.experts.h4toh.weight": "mlp.fc2.weight", "mlp.experts.h4toh.bias": "mlp.fc2.bias"}
+    for n, p in blk.named_parameters():
+        if n.startswith("mlp.gate."):      # the E = 1 router: score == 1, no gradient (the fixture's Mlp has no router)
+            continue
+        ref = torch.from_numpy(g["g." + names.get(n, n)]).reshape(p.shape)
+        assert p.grad is not None, n
+        worst.append((_rel(p.grad, ref), n))
+    print("residual block, training, relative L2 gradient differences vs the reference:",
+          {n: f"{e:.1e}" for e, n in sorted(worst, reverse=True)[:6]})
+    assert max(worst)[0] <= 3e-2, max(worst)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE cfg 5 timing: forward + backward (+ AdamW step through NativeScaler) with the SwitchGate, capacity_factor 1.0 and the
 aux loss, (a) for ONE MoE layer at ViT-B dims (T = images x 197 rows) and (b) for the whole ViT-B/16 E=8 model.
-usage: train_bench.py [layer|model] [images] [iters]      (run under rocprofv3 --kernel-trace --stats for the per-kernel table)"""
+usage: train_bench.py [layer|model] [images] [iters] [model name]     (run under rocprofv3 --kernel-trace --stats for the per-kernel table)
+model name: default moe_base_patch16_224_expert8_top1 with the SwitchGate (cfg 5); a resmoe_* name = the reference's live block
+(token-skip gates, residual on the normed activations, naive gate; thresholds set so that ~40 % of the tokens skip)."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -61,7 +63,16 @@ if what == "layer":
     print(f"MoE layer cfg 5 (T {T}, d {d}, h {h}, E {E}, switch gate, cf 1.0): forward {t_f:.3f} ms, forward+backward "
           f"{t_fb:.3f} ms  ({3 * fl / (t_fb * 1e-3) / 1e12:.0f} TFLOP/s over the 3 x 4Tdh expert-GEMM FLOPs)", flush=True)
 else:
-    model = sm.create_model("moe_base_patch16_224_expert8_top1", num_classes=1000, gate="switch", capacity_factor=1.0).to(dev)
+    name = sys.argv[4] if len(sys.argv) > 4 else "moe_base_patch16_224_expert8_top1"
+    if name.startswith("resmoe"):
+        model = sm.create_model(name, num_classes=1000, drop_path_rate=0.1, starting_threshold=0.55, target_threshold=0.5)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if "_gate.head.1.weight" in n:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        model = model.to(dev)
+    else:
+        model = sm.create_model(name, num_classes=1000, gate="switch", capacity_factor=1.0).to(dev)
     model.train()
     opt = smo.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
     scaler = smo.NativeScaler()
@@ -75,10 +86,15 @@ else:
             out = model(x)
             loss = crit(out, y)
             for m in moes:
-                loss = loss + 0.01 * m.gate.get_loss()
+                aux = m.gate.get_loss()
+                if aux is not None:
+                    loss = loss + 0.01 * aux
         opt.zero_grad()
         scaler(loss, opt, clip_grad=1.0, parameters=model.parameters())
 
     t = timed(train_step, iters)
-    print(f"ViT-B/16 E=8 switch cf 1.0 train step (fwd + bwd + clip + AdamW), batch {images}: {t:.2f} ms = {images / t * 1e3:.0f} images/s",
-          flush=True)
+    gates = [m for m in model.modules() if isinstance(m, sm.Gate)]
+    extra = ""
+    if gates:
+        extra = f"; skipped tokens {sum(gt._skipped_tokens for gt in gates) / max(1, sum(gt._total_tokens for gt in gates)):.2f}"
+    print(f"{name} train step (fwd + bwd + clip + AdamW), batch {images}: {t:.2f} ms = {images / t * 1e3:.0f} images/s{extra}", flush=True)
