@@ -71,12 +71,18 @@ int smoe_router_topk(const void* x, int x_dtype, const float* wg, const float* b
 /* LayerNorm + router fused (block glue, models/vision_transformer.py:321 `mlp(norm2(x))`): xn = LN(x)*gamma+beta
  * is written as a 16-bit image (xn16: f16/bf16, may be NULL) and / or f32 (xn32, may be NULL) and routed exactly
  * as smoe_router_topk routes xn.  Shapes covered: smoe_ln_router_supported(d, E, k) (k <= 4; E <= 8 with
- * d in {192, 384, 768, 1024}, E <= 32 with d in {768, 1024}); workspace as smoe_router_workspace_bytes(T). */
+ * d in {192, 384, 768, 1024}, E <= 32 with d in {768, 1024}); workspace as smoe_router_workspace_bytes(T).
+ * chunk_hist (may be NULL; i32 [ceil(T / tok)][E], tok = smoe_router_chunk_hist_tokens(d, E, k) > 0): the per-chunk expert
+ * histogram of the routing (count_by_gate folded into the router pass: the f32 pass walks contiguous chunks of `tok` tokens and
+ * counts what it decides, the redo pass adds the tokens it decides) -- smoe_dispatch_plan_hist then builds the plan without its
+ * own counting launch.  Shapes whose router writes none report tok = 0 and ignore the pointer.                             */
 int smoe_ln_router_supported(int d, int E, int k);
+int smoe_router_chunk_hist_tokens(int d, int E, int k);
 int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_gamma, const float* ln_beta, float ln_eps,
                         void* xn16, int xn16_dtype, float* xn32, const float* wg, const float* bg, const float* noise,
                         int64_t T, int d, int E, int k, int gate_kind, int64_t* idx, float* score,
-                        float* logits_out, float* probs, void* workspace, size_t workspace_bytes, void* stream);
+                        float* logits_out, float* probs, int32_t* chunk_hist, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* Token-skip gate of the residual-MoE block (models/resMoE.py:32-85 `Gate`; used at 126-145), fused with the LayerNorm
  * in front of it and -- for the MoE half -- with the router behind it: ONE pass over the activations replaces
@@ -99,6 +105,7 @@ int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, const float* ln
                         const float* gate_w, const float* gate_b, const float* threshold, void* xn16, int xn16_dtype,
                         float* xn32, const float* zero_out, const float* wg, const float* bg, int64_t T, int d, int E,
                         int k, int64_t* idx, int64_t* idx_plan, float* score, float* mask, int32_t* skip_count,
+                        int32_t* chunk_hist /* as smoe_ln_router_topk's; counts idx_plan's dispatched entries; may be NULL */,
                         void* workspace, size_t workspace_bytes, void* stream);
 /* What the MoE returns for an all-zero input row (every token the skip gate masks, resMoE.py:140-143):
  *   out[d] = sum_j score_j (W2[e_j] gelu(b1[e_j]) + b2[e_j]),  (e_j, score_j) = NaiveGate top-k of the gate bias bg.
@@ -116,6 +123,22 @@ int smoe_zero_row_output(const float* bg, int E, int k, const float* w2, const f
  * The gate's parameter gradients follow from dz: dW = dz^T xn (smoe_gate_wgrad with E = 1), db = sum dz.                      */
 int smoe_skip_gate_bwd(const float* xn, const void* g_f, int g_f_dtype, const float* g_out, const float* gate_w,
                        const float* gate_b, const float* mask, int gate_on, int64_t T, int d, float* dxn, float* dz, void* stream);
+
+/* ---- the embedding stage and the last LayerNorm of the ViT forward (models/vision_transformer.py:818-830) ----
+ * smoe_patchify_cast:  images f32 [B, C, H, W] -> patch rows [B * (H/ph) * (W/pw), C * ph * pw] (f16 / bf16), row (b, gy, gx) =
+ *                      images[b, :, gy*ph:(gy+1)*ph, gx*pw:(gx+1)*pw] flattened (c, py, px) -- the operand of the per-patch projection
+ *                      GEMM (timm PatchEmbed: Conv2d with kernel == stride); pw % 4 == 0
+ * smoe_embed_ln:       x32[b, 0] = cls_token + pos_embed[0],  x32[b, n] = tokens[b * P + n - 1] + pos_embed[n]  (n = 1 .. P)  -- the
+ *                      f32 residual stream [B, P + 1, d] -- and, when xn != NULL, xn = LayerNorm(x32) in f16 / bf16 (block 0's norm1)
+ *                      from the same pass.  tokens [B * P, d] f16 / bf16 (the projection GEMM's output), cls_token [d], pos_embed
+ *                      [P + 1, d], gamma / beta [d] f32; d in {192, 384, 768, 1024}
+ * smoe_layernorm_rows: LayerNorm of T f32 rows that start row_stride elements apart (the class-token rows x[:, 0] behind the last
+ *                      block: row_stride = (P + 1) * d); out f32 [T, d]                                                              */
+int smoe_patchify_cast(const float* images, int64_t B, int C, int H, int W, int ph, int pw, void* out, int out_dtype, void* stream);
+int smoe_embed_ln(const void* tokens, int tok_dtype, const float* cls_token, const float* pos_embed, const float* ln_gamma,
+                  const float* ln_beta, float ln_eps, int64_t B, int P, int d, float* x32, void* xn, int xn_dtype, void* stream);
+int smoe_layernorm_rows(const float* x, int64_t row_stride, const float* gamma, const float* beta, float eps, int64_t T, int d,
+                        float* out, void* stream);
 
 /* LayerNorm alone (same arithmetic as the fused form; the `norm1` of models/vision_transformer.py:320 feeding the
  * attention GEMMs in 16 bit): d in {192, 384, 768, 1024}.                                              */
@@ -151,6 +174,13 @@ size_t smoe_dispatch_plan_workspace_bytes(int64_t n, int E);
 int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t capacity,
                        int32_t* counts, int32_t* offsets, int64_t* pos, int64_t* inv_pos,
                        int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream);
+/* smoe_dispatch_plan_hist: the same plan from a chunk histogram the fused router wrote (smoe_ln_router_topk / smoe_gate_ln_router
+ * `chunk_hist`; hist_chunk = tokens per row x k flat entries): one launch, no counting pass over idx.  Falls back to
+ * smoe_dispatch_plan when the table does not fit the fused kernel.  idx here is what the plan is built over (for the gated MoE
+ * half: idx_plan, -1 = not dispatched -- exactly the entries the router left out of the histogram).                          */
+int smoe_dispatch_plan_hist(const int64_t* idx, int64_t n, int E, int64_t capacity, const int32_t* hist, int hist_chunk,
+                            int32_t* counts, int32_t* offsets, int64_t* pos, int64_t* inv_pos, int64_t* idx_pruned,
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* The same plan in the PADDED layout of a capacity gate's static expert-parallel exchange (SURVEY.md section 8e, Appendix B
  * `cap` note: "[W, E_local, cap, d] exchange buffers, no count exchange / host sync needed"): expert e owns the slots
  * [e * slot_rows, (e + 1) * slot_rows) whatever its count, slot = e * slot_rows + rank (slot_rows >= capacity: the slot

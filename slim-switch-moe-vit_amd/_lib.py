@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SLIMMOE_LIB: another build of the same sources (a diagnostic build, `make DIAG=-DSMOE_DIAG`, whose environment switches the
 # tools under tools/ use); the ABI and symbol checks below apply to it all the same
 LIB_PATH = os.environ.get("SLIMMOE_LIB") or os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -70,12 +70,15 @@ SIGNATURES = {
     "smoe_ln_router_supported": (c_int, [c_int, c_int, c_int]),
     "smoe_ln_router_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "smoe_router_chunk_hist_tokens": (c_int, [c_int, c_int, c_int]),
+    "smoe_dispatch_plan_hist": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "smoe_gate_ln_router_supported": (c_int, [c_int, c_int, c_int]),
     "smoe_gate_ln_router": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_grad_sumsq_blocks": (c_int64, [c_int64]),
     "smoe_grad_sumsq": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_adamw_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,
@@ -97,6 +100,10 @@ SIGNATURES = {
     "smoe_a2a_wait": (c_int, [c_void_p, c_void_p]),
     "smoe_a2a_last_ticket": (c_int64, [c_void_p]),
     "smoe_a2a_wait_ticket": (c_int, [c_void_p, c_int64, c_void_p]),
+    "smoe_patchify_cast": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "smoe_embed_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_int64, c_int, c_int, c_void_p,
+                              c_void_p, c_int, c_void_p]),
+    "smoe_layernorm_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, ctypes.c_float, c_int64, c_int, c_void_p, c_void_p]),
     "smoe_skip_gate_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                                    c_void_p, c_void_p]),
     "smoe_zero_row_output": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -106,7 +113,7 @@ _lib = None
 
 # what csrc/Makefile hashes into smoe_build_id(): the same names, sorted as strings, relative to csrc/
 _HASHED = ["api.hip", "router.hip", "router16.hip", "gate.hip", "dispatch.hip", "gemm.hip", "backward.hip", "attention.hip",
-           "optim.hip", "comm.hip", "dense_bwd.hip", "attention_bwd.hip", "smoe_common.h", "router16_kernel.h", "router_mt_kernel.h", "gemm_persistent.h",
+           "optim.hip", "comm.hip", "dense_bwd.hip", "attention_bwd.hip", "embed.hip", "smoe_common.h", "router16_kernel.h", "router_mt_kernel.h", "gemm_persistent.h",
            "../../include/slimmoe.h", "Makefile"]
 
 

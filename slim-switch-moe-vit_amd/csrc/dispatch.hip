@@ -82,7 +82,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
     const int64_t* __restrict__ idx, int64_t n, int E, int64_t capacity, const int32_t* __restrict__ rawbase_or_cnt,
     const int32_t* __restrict__ offsets_in, int64_t* __restrict__ pos, int64_t* __restrict__ inv_pos,
     int64_t* __restrict__ idx_pruned, int nblk, int32_t* __restrict__ counts_out, int32_t* __restrict__ offsets_out,
-    int64_t slot_stride, int32_t* __restrict__ group_end_out) {
+    int64_t slot_stride, int32_t* __restrict__ group_end_out, int tab_rows, int tab_ratio) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // run[w][e]: raw rank of the next entry of expert e seen by wave w (wave w owns a contiguous quarter of the chunk)
   int32_t* run = reinterpret_cast<int32_t*>(smem);  // [PLAN_WAVES][E]
@@ -97,13 +97,31 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
   if constexpr (FUSED) {
     for (int i = tid; i < 2 * E; i += PLAN_THREADS) sbase[i] = 0;
     __syncthreads();
+    // the count table: tab_rows rows of E, row b = the entries [b CH / tab_ratio, (b + 1) CH / tab_ratio) -- this kernel's own
+    // chunks (tab_ratio 1, smoe_dispatch_plan's counting launch) or the finer chunks the fused router counted on its way
+    // (smoe_dispatch_plan_hist): the rows in front of this workgroup's chunk are those below me * tab_ratio
     const int me = (int)blockIdx.x;
-    for (int j = tid; j < nblk * E; j += PLAN_THREADS) {
-      const int32_t c = rawbase_or_cnt[j];
-      if (c) {
-        const int b = j / E, e = j - b * E;
-        atomicAdd(&stot[e], c);
-        if (b < me) atomicAdd(&sbase[e], c);
+    if (PLAN_THREADS % E == 0) {
+      // every thread meets ONE expert on its stride (j = tid + i * 256, 256 % E == 0): private sums, two LDS atomics per thread
+      // (an atomic per table entry serialised thousands of adds on E words: the router's 64-token rows make the table 16 x longer)
+      const int e = tid % E;
+      int32_t tot = 0, base = 0;
+      const int first = me * tab_ratio * E;          // entries below `first` belong to rows in front of this chunk
+      for (int j = tid; j < tab_rows * E; j += PLAN_THREADS) {
+        const int32_t c = rawbase_or_cnt[j];
+        tot += c;
+        base += j < first ? c : 0;
+      }
+      if (tot) atomicAdd(&stot[e], tot);
+      if (base) atomicAdd(&sbase[e], base);
+    } else {
+      for (int j = tid; j < tab_rows * E; j += PLAN_THREADS) {
+        const int32_t c = rawbase_or_cnt[j];
+        if (c) {
+          const int b = j / E, e = j - b * E;
+          atomicAdd(&stot[e], c);
+          if (b < me * tab_ratio) atomicAdd(&sbase[e], c);
+        }
       }
     }
     __syncthreads();
@@ -486,7 +504,7 @@ static int plan_impl(const int64_t* idx, int64_t n, int E, int64_t capacity, int
   if (n > 0 && E <= PLAN_FUSED_E && nblk * E <= PLAN_FUSED_MAX) {
     hipLaunchKernelGGL(plan_assign_kernel<true>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)(PLAN_WAVES * E + 3 * E + 1) * 4, s,
                        idx, n, E, capacity, blockcnt, nullptr, pos, inv_pos, idx_pruned, (int)nblk, counts, offsets, slot_stride,
-                       group_end);
+                       group_end, (int)nblk, 1);
     SMOE_CHECK_LAUNCH("smoe_dispatch_plan/assign_fused");
     return 0;
   }
@@ -496,7 +514,7 @@ static int plan_impl(const int64_t* idx, int64_t n, int E, int64_t capacity, int
   hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(scan_threads), (size_t)E * 4, s, blockcnt, (int)nblk, E, capacity, rawbase, counts, offsets);
   SMOE_CHECK_LAUNCH("smoe_dispatch_plan/scan");
   if (n > 0) {
-    hipLaunchKernelGGL(plan_assign_kernel<false>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)PLAN_WAVES * E * 4, s, idx, n, E, capacity, rawbase, offsets, pos, inv_pos, idx_pruned, (int)nblk, nullptr, nullptr, (int64_t)0, nullptr);
+    hipLaunchKernelGGL(plan_assign_kernel<false>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)PLAN_WAVES * E * 4, s, idx, n, E, capacity, rawbase, offsets, pos, inv_pos, idx_pruned, (int)nblk, nullptr, nullptr, (int64_t)0, nullptr, 0, 1);
     SMOE_CHECK_LAUNCH("smoe_dispatch_plan/assign");
     int tb = (int)((n + 255) / 256);
     if (tb > 1024) tb = 1024;
@@ -510,6 +528,26 @@ extern "C" int smoe_dispatch_plan(const int64_t* idx, int64_t n, int E, int64_t 
                                   int32_t* offsets, int64_t* pos, int64_t* inv_pos, int64_t* idx_pruned,
                                   void* workspace, size_t workspace_bytes, void* stream) {
   return plan_impl(idx, n, E, capacity, counts, offsets, pos, inv_pos, idx_pruned, workspace, workspace_bytes, stream, 0, nullptr);
+}
+
+// The plan from a chunk histogram the router already made (smoe_ln_router_topk / smoe_gate_ln_router `chunk_hist`): hist[c][e] =
+// entries of expert e among the flat entries [c * hist_chunk, (c + 1) * hist_chunk) of idx (entries outside [0, E) uncounted).
+// ONE launch (the fused assign) instead of two, and no second pass over idx for counting.  Falls back to smoe_dispatch_plan
+// (counting launch included) when the table does not fit the fused kernel (E > 64, rows x E > 8192, hist_chunk not a divisor of 1024).
+extern "C" int smoe_dispatch_plan_hist(const int64_t* idx, int64_t n, int E, int64_t capacity, const int32_t* hist,
+                                       int hist_chunk, int32_t* counts, int32_t* offsets, int64_t* pos, int64_t* inv_pos,
+                                       int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream) {
+  const int64_t rows = hist_chunk > 0 ? (n + hist_chunk - 1) / hist_chunk : 0;
+  if (!hist || n <= 0 || hist_chunk <= 0 || PLAN_CH % hist_chunk != 0 || E > PLAN_FUSED_E || rows * E > PLAN_FUSED_MAX)
+    return plan_impl(idx, n, E, capacity, counts, offsets, pos, inv_pos, idx_pruned, workspace, workspace_bytes, stream, 0, nullptr);
+  SMOE_REQUIRE(counts && offsets && idx && pos && inv_pos, "smoe_dispatch_plan_hist: null pointer");
+  SMOE_REQUIRE(n < (1ll << 31) && E >= 1, "smoe_dispatch_plan_hist: bad sizes");
+  const int64_t nblk = plan_nblk(n);
+  hipLaunchKernelGGL(plan_assign_kernel<true>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)(PLAN_WAVES * E + 3 * E + 1) * 4,
+                     (hipStream_t)stream, idx, n, E, capacity, hist, nullptr, pos, inv_pos, idx_pruned, (int)nblk, counts, offsets,
+                     (int64_t)0, nullptr, (int)rows, PLAN_CH / hist_chunk);
+  SMOE_CHECK_LAUNCH("smoe_dispatch_plan_hist/assign_fused");
+  return 0;
 }
 
 extern "C" int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, int64_t capacity, int64_t slot_rows,

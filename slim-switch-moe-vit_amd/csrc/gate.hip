@@ -11,6 +11,7 @@ using namespace r16;
 
 struct GLnArgs {
   const float* g; const float* b; float eps; void* xn16; int xn16_dtype; float* xn32;
+  int32_t* hist = nullptr;   // chunk histogram for the dispatch plan (gate + router only), or NULL
 };
 
 template <int NJ, bool LN, typename NT, int GATE>
@@ -23,6 +24,8 @@ int launch_gate(const float* x, const GLnArgs& ln, const SkipGateArgs& ga, const
   constexpr int64_t max_wg = 768;
   const int64_t iters = (need + max_wg - 1) / max_wg;
   const int grid = (int)(need < 1 ? 1 : (need + iters - 1) / (iters < 1 ? 1 : iters));
+  HistArgs ha{GATE == 1 ? ln.hist : nullptr, R16_HIST_TOK};
+  const int grid0 = ha.hist ? (int)((T + R16_HIST_TOK - 1) / R16_HIST_TOK) : grid;
   if (!ws_zero) {   // (a kept workspace is zero already: the redo pass clears its counter words on the way out)
     hipError_t me = smoe_zero_words(rc, 4, s);
     if (me != hipSuccess) {
@@ -37,8 +40,8 @@ int launch_gate(const float* x, const GLnArgs& ln, const SkipGateArgs& ga, const
 #define G_LAUNCH(MODE, GRID)                                                                                          \
   hipLaunchKernelGGL((router16_kernel<float, NJ, MODE, LN, NT, EB, GATE>), dim3(GRID), dim3(R16_THREADS), smem, s, x,   \
                      ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, (const float*)nullptr, T, d, E, k,            \
-                     (int)SMOE_GATE_NAIVE, rc, rl, idx, score, (float*)nullptr, (float*)nullptr, ga)
-  G_LAUNCH(0, grid);
+                     (int)SMOE_GATE_NAIVE, rc, rl, idx, score, (float*)nullptr, (float*)nullptr, ga, ha)
+  G_LAUNCH(0, grid0);
   SMOE_CHECK_LAUNCH("smoe_gate_ln_router/f32");
   G_LAUNCH(1, (grid < 16 ? grid : 16));
   SMOE_CHECK_LAUNCH("smoe_gate_ln_router/redo");
@@ -220,7 +223,7 @@ extern "C" int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, cons
                                    float ln_eps, const float* gate_w, const float* gate_b, const float* threshold,
                                    void* xn16, int xn16_dtype, float* xn32, const float* zero_out, const float* wg,
                                    const float* bg, int64_t T, int d, int E, int k, int64_t* idx, int64_t* idx_plan,
-                                   float* score, float* mask, int32_t* skip_count, void* workspace,
+                                   float* score, float* mask, int32_t* skip_count, int32_t* chunk_hist, void* workspace,
                                    size_t workspace_bytes, void* stream) {
   if (T == 0) return 0;
   SMOE_REQUIRE(x && gate_w, "smoe_gate_ln_router: null pointer");
@@ -233,6 +236,7 @@ extern "C" int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, cons
   int32_t* rc = reinterpret_cast<int32_t*>(workspace);
   int32_t* rl = reinterpret_cast<int32_t*>((char*)workspace + 16);
   GLnArgs ln{ln_gamma, ln_beta, ln_eps, xn16, xn16_dtype, xn32};
+  ln.hist = (chunk_hist && E > 0 && 1024 % (R16_HIST_TOK * k) == 0) ? chunk_hist : nullptr;
   SkipGateArgs ga{gate_w, gate_b, threshold, skip_count, mask, zero_out, E > 0 ? idx_plan : nullptr};
   hipStream_t s = (hipStream_t)stream;
   const bool ws_zero = (with_ln & 2) != 0;   // bit 1: the caller keeps the workspace's counter words zero between calls

@@ -90,6 +90,7 @@ int ln_dispatch_nj(const void* x, const float* g, const float* b, float eps, int
 
 struct LnArgs {
   const float* g; const float* b; float eps; void* xn16; int xn16_dtype; float* xn32; bool on;
+  int32_t* hist = nullptr;   // chunk histogram for the dispatch plan (E <= 8 images only), or NULL
 };
 
 template <typename XT, int NJ, bool LN, typename NT, int EB>
@@ -106,7 +107,10 @@ int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, 
   // per workgroup), every workgroup the same number of 16-token groups
   constexpr int64_t max_wg = EB <= 8 ? 768 : (EB <= 16 ? 512 : 256);
   const int64_t iters = (need + max_wg - 1) / max_wg;
-  const int grid = (int)(need < 1 ? 1 : (need + iters - 1) / (iters < 1 ? 1 : iters));
+  int grid = (int)(need < 1 ? 1 : (need + iters - 1) / (iters < 1 ? 1 : iters));
+  // with a chunk histogram every workgroup of the f32 pass walks ONE contiguous chunk of R16_HIST_TOK tokens
+  HistArgs ha{(EB == 8 && !(force_f64 & 1)) ? ln.hist : nullptr, R16_HIST_TOK};
+  const int grid0 = ha.hist ? (int)((T + R16_HIST_TOK - 1) / R16_HIST_TOK) : grid;
   if (smem > 64 * 1024) {  // 16 experts x d 1024 (+ LayerNorm vectors): above the default dynamic-LDS limit
     SMOE_ENSURE_SMEM(router16_kernel<XT, NJ, 0, LN, NT, EB, 0, NTH>);
     SMOE_ENSURE_SMEM(router16_kernel<XT, NJ, 1, LN, NT, EB, 0, R16_THREADS>);
@@ -115,7 +119,7 @@ int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, 
   hipLaunchKernelGGL((router16_kernel<XT, NJ, MODE, LN, NT, EB, 0, (MODE == 0 ? NTH : R16_THREADS)>), dim3(GRID),       \
                      dim3(MODE == 0 ? NTH : R16_THREADS), smem, s, (const XT*)x,                                      \
                      ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, noise, T, d, E, k, gate_kind, RC, RL, idx,   \
-                     score, logits_out, probs, SkipGateArgs{})
+                     score, logits_out, probs, SkipGateArgs{}, ha)
   const bool ws_zero = (force_f64 & 2) != 0;
   force_f64 &= 1;
   if (force_f64 && !LN) {
@@ -137,7 +141,7 @@ int launch16(const void* x, const LnArgs& ln, const float* wg, const float* bg, 
     SMOE_CHECK_LAUNCH("smoe_router_topk/f64");
     return 0;
   }
-  R16_LAUNCH(0, grid, rc, rl);
+  R16_LAUNCH(0, grid0, rc, rl);
   SMOE_CHECK_LAUNCH("smoe_router_topk/f32");
   R16_LAUNCH(1, (grid < 16 ? grid : 16), rc, rl);
   SMOE_CHECK_LAUNCH("smoe_router_topk/redo");
@@ -272,13 +276,19 @@ int smoe_router16_try(const void* x, int x_dtype, const float* wg, const float* 
 
 extern "C" int smoe_ln_router_supported(int d, int E, int k) { return shape_ok16(d, E, k) ? 1 : 0; }
 
+// Tokens per row of the chunk histogram that smoe_ln_router_topk / smoe_gate_ln_router write for this shape when the caller hands
+// them a table (smoe_dispatch_plan_hist then needs no counting pass); 0 = this shape's router writes none.
+extern "C" int smoe_router_chunk_hist_tokens(int d, int E, int k) {
+  return (shape_ok16(d, E, k) && E <= 8 && k >= 1 && 1024 % (R16_HIST_TOK * k) == 0) ? R16_HIST_TOK : 0;
+}
+
 // LayerNorm + router in one pass over x (block glue fusion): xn = LN(x) * gamma + beta is
 // written as the 16-bit operand image (xn16, f16 or bf16; may be NULL) and / or as f32 (xn32; may be NULL) and
 // routed exactly like smoe_router_topk routes xn.  Shapes: smoe_ln_router_supported(d, E, k).
 extern "C" int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_gamma, const float* ln_beta, float ln_eps,
                                    void* xn16, int xn16_dtype, float* xn32, const float* wg, const float* bg,
                                    const float* noise, int64_t T, int d, int E, int k, int gate_kind, int64_t* idx,
-                                   float* score, float* logits_out, float* probs, void* workspace,
+                                   float* score, float* logits_out, float* probs, int32_t* chunk_hist, void* workspace,
                                    size_t workspace_bytes, void* stream) {
   const int force_f64 = ((gate_kind & 0x100) ? 1 : 0) | ((gate_kind & 0x200) ? 2 : 0);   // bit 1: the workspace's counter words are kept zero by the caller
   gate_kind &= 0xff;
@@ -294,6 +304,7 @@ extern "C" int smoe_ln_router_topk(const void* x, int x_dtype, const float* ln_g
   int32_t* rc = reinterpret_cast<int32_t*>(workspace);
   int32_t* rl = reinterpret_cast<int32_t*>((char*)workspace + 16);
   LnArgs ln{ln_gamma, ln_beta, ln_eps, xn16, xn16_dtype, xn32, true};
+  ln.hist = (chunk_hist && smoe_router_chunk_hist_tokens(d, E, k)) ? chunk_hist : nullptr;
   hipStream_t s = (hipStream_t)stream;
   switch (x_dtype) {
     case SMOE_F32: return dispatch16_ln<float>(x, ln, wg, bg, noise, T, d, E, k, gate_kind, force_f64, rc, rl, idx, score, logits_out, probs, s);

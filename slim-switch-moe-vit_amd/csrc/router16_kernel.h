@@ -38,6 +38,16 @@ struct SkipGateArgs {
   int64_t* idx_plan;       // [T,k] idx, -1 for skipped tokens; NULL when there is no router
 };
 
+// Chunk histogram for the dispatch plan (smoe_dispatch_plan_hist): hist[c][e] = dispatched entries of expert e among the tokens
+// [c * tok, (c + 1) * tok).  The f32 pass then walks CONTIGUOUS chunks (workgroup b = chunk b) and counts in LDS what it decides
+// itself; the redo pass adds the tokens it decides (a handful, global atomics).  The plan's own counting launch and its pass
+// over idx go away.
+constexpr int R16_HIST_TOK = 64;
+struct HistArgs {
+  int32_t* hist;           // [ceil(T / tok)][E] i32, or NULL
+  int tok;                 // tokens per chunk (R16_HIST_TOK)
+};
+
 template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
   const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true);
   return v + __builtin_bit_cast(float, moved);
@@ -84,7 +94,8 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
     NT* __restrict__ xn16, float* __restrict__ xn32, const float* __restrict__ wg, const float* __restrict__ bg,
     const float* __restrict__ noise, int64_t T, int d, int E, int k, int gate_kind,
     int32_t* __restrict__ redo_count, int32_t* __restrict__ redo_list, int64_t* __restrict__ idx_out,
-    float* __restrict__ score_out, float* __restrict__ logits_out, float* __restrict__ probs_out, SkipGateArgs ga) {
+    float* __restrict__ score_out, float* __restrict__ logits_out, float* __restrict__ probs_out, SkipGateArgs ga,
+    HistArgs ha) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool ROUTE = GATE != 2;
   constexpr int EW = ROUTE ? EB : 0;                        // expert rows held in LDS
@@ -96,6 +107,7 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
   float* lds_be = lds_g + (LN ? d : 0);
   float* lds_gw = lds_be + (LN ? d : 0);                    // [d] skip-gate weight (GATE only)
   double* lds_gz = reinterpret_cast<double*>(lds_gw + (GATE ? d : 0));  // [0] logit(threshold)  [1] |gate_w|^2  [2] gate bias
+  int* lds_hist = reinterpret_cast<int*>(lds_gz + (GATE ? 4 : 0));       // [EB] this chunk's histogram (ha.hist only)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, u = lane & 15;
   if (MODE == 1 && redo_list && *redo_count == 0) return;  // nothing to redo (the common case): exit before any setup
@@ -105,8 +117,15 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
     n_items = *redo_count;
     n_items = n_items < 0 ? 0 : (n_items > T ? T : n_items);
   }
-  const int64_t slot_gid = ((int64_t)blockIdx.x * (NTH / 64) + wave) * 4 + q;
-  const int64_t slot_stride = (int64_t)gridDim.x * (NTH / 64) * 4;
+  // tokens of this workgroup: 16-token groups strided over the grid -- or, with a chunk histogram (f32 pass), ONE contiguous
+  // chunk of ha.tok tokens
+  const bool chunked = MODE == 0 && ROUTE && ha.hist != nullptr;
+  const int64_t slot_gid = chunked ? (int64_t)blockIdx.x * ha.tok + wave * 4 + q : ((int64_t)blockIdx.x * (NTH / 64) + wave) * 4 + q;
+  const int64_t slot_stride = chunked ? (int64_t)(NTH / 64) * 4 : (int64_t)gridDim.x * (NTH / 64) * 4;
+  if (chunked) {
+    const int64_t chunk_end = ((int64_t)blockIdx.x + 1) * ha.tok;
+    if (chunk_end < n_items) n_items = chunk_end;
+  }
   // The row of the NEXT item is fetched as soon as the current one's registers are free -- the first one before
   // the weight staging below, so the HBM latency of the first rows runs under the prologue.  Dead slots of the
   // last group re-read the last item (no predication on the loads; only stores are guarded).
@@ -158,6 +177,9 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
   }
   if constexpr (GATE != 0) {
     for (int i = tid; i < d; i += NTH) lds_gw[i] = ga.w[i];
+  }
+  if constexpr (ROUTE) {
+    if (tid < EB) lds_hist[tid] = 0;
   }
   __syncthreads();
   if constexpr (ROUTE) {
@@ -441,6 +463,14 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
       redo = (ambiguous && xs > 0.f) || gate_ambiguous;
       if (redo && live && u == 0) list_push(redo_count, redo_list, T, t);
     }
+    if (ha.hist && live && u == 0 && !redo && !(GATE != 0 && skip)) {   // (a redo token is counted by the pass that decides it)
+#pragma unroll
+      for (int r = 0; r < R16_MAX_K; ++r)
+        if (r < k) {
+          if constexpr (MODE == 0) atomicAdd(&lds_hist[chosen[r]], 1);
+          else atomicAdd(&ha.hist[(t / ha.tok) * (int64_t)E + chosen[r]], 1);
+        }
+    }
     if constexpr (GATE != 0) {
       if (live && u == 0 && ga.mask) {
         ga.mask[t * 2] = skip ? 1.f : 0.f;
@@ -486,6 +516,12 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
     }
     }  // ROUTE
   }
+  if constexpr (ROUTE && MODE == 0) {
+    if (ha.hist) {         // kernel-uniform: this chunk's row of the table
+      __syncthreads();
+      if (tid < E) ha.hist[(int64_t)blockIdx.x * E + tid] = lds_hist[tid];
+    }
+  }
   if constexpr (GATE != 0) {
     if (ga.skip_count) {   // kernel-uniform
       __syncthreads();     // the weight image in LDS is dead from here on: reuse its first word
@@ -515,7 +551,8 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
 // dynamic LDS of one workgroup of router16_kernel
 template <int NJ, bool LN, int EB, int GATE> constexpr size_t router16_smem() {
   constexpr int d = 64 * NJ;
-  return ((size_t)(GATE != 2 ? EB : 0) * d + 2 * EB + (LN ? 2 * (size_t)d : 0) + (GATE != 0 ? (size_t)d : 0)) * 4 + (GATE != 0 ? 32 : 0);
+  return ((size_t)(GATE != 2 ? EB : 0) * d + 2 * EB + (LN ? 2 * (size_t)d : 0) + (GATE != 0 ? (size_t)d : 0)) * 4 + (GATE != 0 ? 32 : 0)
+         + (GATE != 2 ? (size_t)EB * 4 : 0);
 }
 
 }  // namespace r16

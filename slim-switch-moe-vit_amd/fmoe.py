@@ -314,11 +314,12 @@ class FMoETransformerMLP(nn.Module):
         noise = g.make_noise(T, x2.device) if is_switch else None
         gw = g.gate.weight.detach().float().contiguous()
         gb = g.gate.bias.detach().float() if g.gate.bias is not None else None
+        hist = ops.chunk_hist(T, d, g.tot_expert, k, x2.device)   # the router pass also counts for the plan (count_by_gate folded in)
         xn16, _, idx, score, _, probs = ops.ln_router_topk(
             x2, norm.weight.detach().float(), norm.bias.detach().float() if norm.bias is not None else None, norm.eps,
-            gw, gb, k, g.kind, noise, xn16_dtype=cd, want_probs=is_switch)
+            gw, gb, k, g.kind, noise, xn16_dtype=cd, want_probs=is_switch, hist=hist)
         cap = g.capacity(T)
-        counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, g.tot_expert, cap)
+        counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, g.tot_expert, cap, hist=hist)
         self.last_plan = (idx, score, counts, offsets, pos, inv_pos)
         if is_switch:
             from .autograd import switch_aux_loss
@@ -395,9 +396,10 @@ class FMoETransformerMLP(nn.Module):
             ln=(norm.weight.detach(), norm.bias.detach() if norm.bias is not None else None, norm.eps),
             wg=g.gate.weight.detach().float().contiguous(), bg=g.gate.bias.detach().float() if g.gate.bias is not None else None,
             k=k, xn16_dtype=cd, want_xn32=True, zero_out=self.zero_row_output() if thr is not None else None,
-            skip_count=skip_gate.skip_counter(x.device) if thr is not None else None)
+            skip_count=skip_gate.skip_counter(x.device) if thr is not None else None,
+            hist=(hist := ops.chunk_hist(T, d, g.tot_expert, k, x2.device)))
         idx, score, out = r["idx"], r["score"], r["xn32"]
-        counts, offsets, pos, inv_pos, _ = ops.dispatch_plan(r["idx_plan"], g.tot_expert, -1)
+        counts, offsets, pos, inv_pos, _ = ops.dispatch_plan(r["idx_plan"], g.tot_expert, -1, hist=hist)
         self.last_plan = (idx, score, counts, offsets, pos, inv_pos)
         ex = self.experts
         w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)

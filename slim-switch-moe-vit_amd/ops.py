@@ -185,6 +185,49 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, weight: Optional[torch.Tens
     return dx, gb[:d], gb[d:]
 
 
+def patchify_cast(images: torch.Tensor, ph: int, pw: int, out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """images f32 [B, C, H, W] -> patch rows [B * gh * gw, C * ph * pw] in 16 bit (smoe_patchify_cast)."""
+    _chk(images, "images", torch.float32, 4)
+    B, C, H, W = images.shape
+    out = torch.empty((B * (H // ph) * (W // pw), C * ph * pw), dtype=out_dtype, device=images.device)
+    rc = _lib.load().smoe_patchify_cast(_ptr(images), B, C, H, W, ph, pw, _ptr(out), dtype_code(out_dtype), _stream(images))
+    _lib.check(rc, "smoe_patchify_cast")
+    return out
+
+
+def embed_ln(tokens: torch.Tensor, cls_token: torch.Tensor, pos_embed: torch.Tensor, B: int, P: int,
+             ln: Optional[tuple] = None, xn_dtype: torch.dtype = torch.float16):
+    """(x32 [B, P + 1, d], xn | None): the f32 stream cat(cls, tokens) + pos_embed and, with ``ln`` = (weight, bias, eps), its
+    LayerNorm in 16 bit from the same pass (smoe_embed_ln)."""
+    _chk(tokens, "tokens", ndim=2)
+    d = tokens.shape[1]
+    cls = cls_token.detach().reshape(-1)
+    pos = pos_embed.detach().reshape(-1, d)
+    _chk(cls, "cls_token", torch.float32, 1)
+    _chk(pos, "pos_embed", torch.float32, 2)
+    if cls.numel() != d or pos.shape[0] != P + 1 or tokens.shape[0] != B * P:
+        raise RuntimeError("embed_ln: shapes disagree")
+    x32 = torch.empty((B, P + 1, d), dtype=torch.float32, device=tokens.device)
+    xn = torch.empty((B, P + 1, d), dtype=xn_dtype, device=tokens.device) if ln is not None else None
+    lg, lb, eps = ln if ln is not None else (None, None, 0.0)
+    with _timed("embed_ln", {"bytes": B * (P + 1) * d * (2 + 4 + (2 if ln is not None else 0))}, tokens):
+        rc = _lib.load().smoe_embed_ln(_ptr(tokens), dtype_code(tokens.dtype), _ptr(cls), _ptr(pos), _ptr(lg), _ptr(lb), float(eps), B, P, d,
+                                       _ptr(x32), _ptr(xn), dtype_code(xn_dtype), _stream(tokens))
+    _lib.check(rc, "smoe_embed_ln")
+    return x32, xn
+
+
+def layernorm_rows(x: torch.Tensor, row_stride: int, T: int, d: int, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+                   eps: float) -> torch.Tensor:
+    """LayerNorm of the T rows x.data_ptr() + t * row_stride (f32, d elements each) -> f32 [T, d] (smoe_layernorm_rows)."""
+    if not (x.is_cuda and x.dtype == torch.float32):
+        raise RuntimeError("layernorm_rows: f32 GPU tensor expected")
+    out = torch.empty((T, d), dtype=torch.float32, device=x.device)
+    rc = _lib.load().smoe_layernorm_rows(_ptr(x), int(row_stride), _ptr(weight), _ptr(bias), float(eps), T, d, _ptr(out), _stream(x))
+    _lib.check(rc, "smoe_layernorm_rows")
+    return out
+
+
 def attention_supported(N: int, head_dim: int) -> bool:
     return bool(_lib.load().smoe_attention_supported(N, head_dim))
 
@@ -229,11 +272,34 @@ def ln_router_supported(d: int, E: int, k: int) -> bool:
     return bool(_lib.load().smoe_ln_router_supported(d, E, k))
 
 
+# SLIMMOE_ROUTER_HIST=1: the fused router pass also counts for the dispatch plan (count_by_gate folded in: chunk_hist +
+# smoe_dispatch_plan_hist, one plan launch instead of two).  Bit-identical plans, and OFF by default: measured inside the model
+# (two alternating bench runs on one box) the LayerNorm + router pass costs 72.3-73.1 us with it against 68.9-69.2 us without (it must
+# walk contiguous 64-token chunks: 788 workgroups of 4 groups instead of 631 of 5) while the plan only drops from 15.1-15.4 to
+# 14.8 us -- the counting launch was nearly free next to the assign launch, which now reads a 16 x longer table.
+ROUTER_HIST = _os.environ.get("SLIMMOE_ROUTER_HIST", "0") == "1"
+
+
+def chunk_hist(T: int, d: int, E: int, k: int, device) -> Optional[torch.Tensor]:
+    """An (uninitialised) chunk-histogram table for the fused router passes to fill -- i32 [ceil(T / tok), E] with ``.tok`` tokens
+    per row -- or None when this shape's router writes none (dispatch_plan then counts by itself)."""
+    if not ROUTER_HIST or T <= 0:
+        return None
+    tok = _lib.load().smoe_router_chunk_hist_tokens(d, E, k)
+    if tok <= 0:
+        return None
+    t = torch.empty((-(-T // tok), E), dtype=torch.int32, device=device)
+    t.tok = tok
+    return t
+
+
 def ln_router_topk(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], eps: float,
                    wg: torch.Tensor, bg: Optional[torch.Tensor], k: int, gate_kind: int = GATE_NAIVE,
                    noise: Optional[torch.Tensor] = None, xn16_dtype: Optional[torch.dtype] = torch.float16,
-                   want_xn32: bool = False, want_probs: bool = False, want_logits: bool = False, force_f64: bool = False):
-    """LayerNorm + router in one pass: (xn16 | None, xn32 | None, idx, score, logits | None, probs | None)."""
+                   want_xn32: bool = False, want_probs: bool = False, want_logits: bool = False, force_f64: bool = False,
+                   hist: Optional[torch.Tensor] = None):
+    """LayerNorm + router in one pass: (xn16 | None, xn32 | None, idx, score, logits | None, probs | None).  ``hist``
+    (chunk_hist(T, d, E, k, device)): filled with the routing's per-chunk expert counts for dispatch_plan(hist=...)."""
     _chk(x, "x", ndim=2)
     _chk(wg, "wg", torch.float32, 2)
     T, d = x.shape
@@ -256,7 +322,8 @@ def ln_router_topk(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: 
         rc = lib.smoe_ln_router_topk(_ptr(x), dtype_code(x.dtype), _ptr(ln_weight), _ptr(ln_bias), float(eps), _ptr(xn16),
                                      dtype_code(xn16_dtype) if xn16_dtype is not None else F16, _ptr(xn32), _ptr(wg),
                                      _ptr(bg), _ptr(noise), T, d, E, k, gate_kind | (0x100 if force_f64 else WS_KEPT_ZERO),
-                                     _ptr(idx), _ptr(score), _ptr(logits), _ptr(probs), _ptr(ws), ws_bytes, _stream(x))
+                                     _ptr(idx), _ptr(score), _ptr(logits), _ptr(probs), _ptr(None if force_f64 else hist), _ptr(ws),
+                                     ws_bytes, _stream(x))
     _lib.check(rc, "smoe_ln_router_topk")
     return xn16, xn32, idx, score, logits, probs
 
@@ -269,7 +336,8 @@ def gate_ln_router(x: torch.Tensor, gate_w: torch.Tensor, gate_b: Optional[torch
                    ln: Optional[tuple] = None, wg: Optional[torch.Tensor] = None, bg: Optional[torch.Tensor] = None,
                    k: int = 1, xn16_dtype: Optional[torch.dtype] = None, want_xn32: bool = False,
                    zero_out: Optional[torch.Tensor] = None, want_mask: bool = False,
-                   skip_count: Optional[torch.Tensor] = None, xn32_out: Optional[torch.Tensor] = None):
+                   skip_count: Optional[torch.Tensor] = None, xn32_out: Optional[torch.Tensor] = None,
+                   hist: Optional[torch.Tensor] = None):
     """[LayerNorm +] token-skip gate (+ NaiveGate router) in one pass (smoe_gate_ln_router).  ``ln`` = (weight, bias,
     eps) or None; ``threshold`` = the gate's 0-dim DEVICE buffer (None = gate disabled); ``wg`` None = no router.
     Returns a dict: xn16, xn32, idx, idx_plan, score, mask (entries that were not asked for are None)."""
@@ -319,7 +387,8 @@ def gate_ln_router(x: torch.Tensor, gate_w: torch.Tensor, gate_b: Optional[torch
                                      _ptr(gb), _ptr(thr), _ptr(xn16),
                                      dtype_code(xn16_dtype) if xn16_dtype is not None else F16, _ptr(xn32),
                                      _ptr(zero_out), _ptr(wg), _ptr(bg), T, d, E, k, _ptr(idx), _ptr(idx_plan),
-                                     _ptr(score), _ptr(mask), _ptr(skip_count), _ptr(ws), ws_bytes, _stream(x))
+                                     _ptr(score), _ptr(mask), _ptr(skip_count), _ptr(hist if E else None), _ptr(ws), ws_bytes,
+                                     _stream(x))
     _lib.check(rc, "smoe_gate_ln_router")
     return {"xn16": xn16, "xn32": xn32, "idx": idx, "idx_plan": idx_plan, "score": score, "mask": mask}
 
@@ -361,8 +430,11 @@ def zero_row_output(bg: Optional[torch.Tensor], k: int, w2: torch.Tensor, b1: Op
     return out
 
 
-def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Optional[bool] = None):
-    """(counts i32 [E], offsets i32 [E+1], pos i64 [n], inv_pos i64 [n], idx_pruned i64 [n] | None)."""
+def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Optional[bool] = None,
+                  hist: Optional[torch.Tensor] = None):
+    """(counts i32 [E], offsets i32 [E+1], pos i64 [n], inv_pos i64 [n], idx_pruned i64 [n] | None).  ``hist``: the chunk histogram the
+    fused router filled for exactly this ``idx`` (chunk_hist / ln_router_topk / gate_ln_router): the plan then skips its counting
+    launch (smoe_dispatch_plan_hist)."""
     _chk(idx, "idx", torch.int64, align=8)  # read element-wise: slices of a [T,k] tensor are fine
     flat = idx.reshape(-1)
     n = flat.numel()
@@ -378,8 +450,14 @@ def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Op
     inv_pos = torch.empty(n, dtype=torch.int64, device=dev)
     pruned = torch.empty(n, dtype=torch.int64, device=dev) if want_pruned else None
     with _timed("plan", {"bytes": n * 24}, idx):
-        rc = lib.smoe_dispatch_plan(_ptr(flat), n, E, int(capacity), _ptr(counts), _ptr(offsets), _ptr(pos),
-                                    _ptr(inv_pos), _ptr(pruned), _ptr(ws), ws_bytes, _stream(idx))
+        if hist is not None:
+            _chk(hist, "hist", torch.int32, 2)
+            k = idx.shape[1] if idx.dim() == 2 else 1      # flat entries per token
+            rc = lib.smoe_dispatch_plan_hist(_ptr(flat), n, E, int(capacity), _ptr(hist), int(hist.tok) * k, _ptr(counts), _ptr(offsets),
+                                             _ptr(pos), _ptr(inv_pos), _ptr(pruned), _ptr(ws), ws_bytes, _stream(idx))
+        else:
+            rc = lib.smoe_dispatch_plan(_ptr(flat), n, E, int(capacity), _ptr(counts), _ptr(offsets), _ptr(pos),
+                                        _ptr(inv_pos), _ptr(pruned), _ptr(ws), ws_bytes, _stream(idx))
     _lib.check(rc, "smoe_dispatch_plan")
     return counts, offsets, pos, inv_pos, pruned
 

@@ -514,7 +514,18 @@ class VisionTransformer(nn.Module):
     def no_weight_decay(self):
         return {"pos_embed", "cls_token", "dist_token"}
 
-    def _embed(self, x):
+    def _first_norm1(self):
+        """Block 0's norm1 if the embedding pass may produce it (a stock ``Block`` whose forward was not replaced: it takes
+        ``xn1``; a LayerNorm with affine parameters over the embedding width), else None."""
+        blk = self.blocks[0] if len(self.blocks) else None
+        if blk is None or not hasattr(blk, "forward_steps") or "forward" in blk.__dict__:
+            return None
+        n = blk.norm1
+        ok = (isinstance(n, nn.LayerNorm) and n.elementwise_affine and tuple(n.normalized_shape) == (self.embed_dim,)
+              and n.weight.dtype == torch.float32)
+        return n if ok else None
+
+    def _embed(self, x, want_xn1: bool = False):
         """``pos_drop(cat(cls_token, patch_embed(x)) + pos_embed)`` (models/vision_transformer.py:818-824).  Under
         fp16-autocast inference the same arithmetic in three launches fewer: patch gather and the fp16 cast autocast
         puts in front of the projection in one copy, cached fp16 weights, and the class-token concat folded into the
@@ -522,21 +533,34 @@ class VisionTransformer(nn.Module):
         pe = self.patch_embed
         if (type(pe) is PatchEmbed and _autocast_half_inference(x) and x.dtype == torch.float32 and not self.training
                 and tuple(x.shape[-2:]) == pe.img_size):
+            from . import ops
             hc = _half_cache(self)
             B, C = x.shape[0], x.shape[1]
             (ph, pw), (gh, gw) = pe.patch_size, pe.grid_size
-            p16 = torch.empty((B, gh, gw, C, ph, pw), dtype=torch.float16, device=x.device)
-            p16.copy_(x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5))
+            dm = pe.proj.weight.shape[0]
+            own = pw % 4 == 0 and dm in _LN_DIMS and x.is_contiguous() and self.pos_embed.dtype == torch.float32
+            if own:   # patch gather + the cast autocast puts in front of the projection: one HIP pass (reads the image once)
+                p2 = ops.patchify_cast(x, ph, pw, torch.float16)
+            else:
+                _warn_fallback("patch embedding", "patch width % 4 != 0 or an embedding width outside {192, 384, 768, 1024}", x.shape)
+                p16 = torch.empty((B, gh, gw, C, ph, pw), dtype=torch.float16, device=x.device)
+                p16.copy_(x.reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5))
+                p2 = p16.reshape(B * gh * gw, C * ph * pw)
             w = hc.get(pe.proj.weight).reshape(pe.proj.weight.shape[0], -1)
-            tok = _linear16(hc, p16.reshape(B * gh * gw, C * ph * pw), pe.proj.weight, pe.proj.bias, name="patch_embed_gemm")
+            tok = _linear16(hc, p2, pe.proj.weight, pe.proj.bias, name="patch_embed_gemm")
             if tok is None:
-                tok = F.linear(p16.reshape(B, gh * gw, C * ph * pw), w,
-                               hc.get(pe.proj.bias) if pe.proj.bias is not None else None)
+                tok = F.linear(p2, w, hc.get(pe.proj.bias) if pe.proj.bias is not None else None)
+            if own and tok.is_contiguous():
+                # class-token row, position embedding and -- when the first block takes it -- that block's norm1, in one pass
+                n1 = self._first_norm1()
+                ln = (n1.weight.detach(), n1.bias.detach() if n1.bias is not None else None, n1.eps) if (want_xn1 and n1 is not None) else None
+                out, xn1 = ops.embed_ln(tok, self.cls_token, self.pos_embed, B, gh * gw, ln=ln)
+                return (out, xn1) if want_xn1 else out
             tok = tok.reshape(B, gh * gw, -1)
             out = torch.empty((B, gh * gw + 1, tok.shape[-1]), dtype=torch.float32, device=x.device)
             torch.add(tok, self.pos_embed[:, 1:], out=out[:, 1:])
             out[:, 0] = self.cls_token[0, 0] + self.pos_embed[0, 0]
-            return out
+            return (out, None) if want_xn1 else out
         from . import dense
         if (type(pe) is PatchEmbed and dense.autocast_half_training(x) and x.dtype == torch.float32
                 and tuple(x.shape[-2:]) == pe.img_size and DENSE_GEMM == "own"):
@@ -550,10 +574,12 @@ class VisionTransformer(nn.Module):
                 tok = dense.LinearFn.apply(p2, pe.proj.weight, pe.proj.bias, None, _half_cache(self), torch.float16,
                                            "patch_embed_gemm").reshape(B, gh * gw, -1)
                 x = torch.cat((self.cls_token.expand(B, -1, -1), tok.float()), dim=1)
-                return self.pos_drop(x + self.pos_embed)
+                x = self.pos_drop(x + self.pos_embed)
+                return (x, None) if want_xn1 else x
         x = pe(x)
         x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x), dim=1)
-        return self.pos_drop(x + self.pos_embed)
+        x = self.pos_drop(x + self.pos_embed)
+        return (x, None) if want_xn1 else x
 
     def forward_features(self, x):
         n = self._ep_pipeline_depth(x)
@@ -562,10 +588,10 @@ class VisionTransformer(nn.Module):
         if (int(self.compute_streams) == 2 and x.is_cuda and not torch.is_grad_enabled() and not self.training
                 and x.shape[0] >= 2):
             return self._forward_features_two_streams(x)
-        x = self._embed(x)
-        if x.is_cuda and not torch.is_grad_enabled() and self._ep_blocks():
+        x, xn1 = self._embed(x, want_xn1=True)
+        if x.is_cuda and not torch.is_grad_enabled() and (self._ep_blocks() or xn1 is not None):
             from .ep import drain
-            x = drain(self._blocks_steps(x))
+            x = drain(self._blocks_steps(x, xn1))
         else:
             x = self.blocks(x)
         return self.pre_logits(self._final_norm_cls(x))
@@ -583,6 +609,9 @@ class VisionTransformer(nn.Module):
                     and x.shape[-1] in _LN_DIMS):
                 from . import ops
                 n = self.norm
+                if x.is_contiguous() and n.weight.dtype == torch.float32:   # the class-token rows read in place, (P + 1) * d apart
+                    return ops.layernorm_rows(x, x.shape[1] * x.shape[2], x.shape[0], x.shape[2], n.weight.detach(),
+                                              n.bias.detach() if n.bias is not None else None, n.eps)
                 return ops.layernorm(x[:, 0].contiguous(), n.weight.detach(), n.bias.detach() if n.bias is not None else None,
                                      n.eps, torch.float32)
             return self.norm(x[:, 0])
@@ -646,11 +675,11 @@ class VisionTransformer(nn.Module):
                 ep = True
         return n if ep else 1
 
-    def _blocks_steps(self, x):
+    def _blocks_steps(self, x, xn0=None):
         """``self.blocks(x)`` as a generator, handing every block the next block's ``norm1`` so that an expert-parallel
         combine can produce it on the way out (one pass over the residual stream less per layer)."""
         blocks = list(self.blocks)
-        xn = None
+        xn = xn0                 # norm1(x) of block 0 when the embedding pass produced it (_embed)
         for i, blk in enumerate(blocks):
             if not hasattr(blk, "forward_steps") or "forward" in blk.__dict__:   # e.g. resmoe.forward_residule_moe
                 x, xn = blk(x), None
@@ -665,8 +694,8 @@ class VisionTransformer(nn.Module):
         return any(hasattr(getattr(b, "mlp", None), "ep_active") and b.mlp.ep_active() for b in self.blocks)
 
     def _features_steps(self, x):
-        x = self._embed(x)
-        x = yield from self._blocks_steps(x)
+        x, xn1 = self._embed(x, want_xn1=True)
+        x = yield from self._blocks_steps(x, xn1)
         return self.pre_logits(self._final_norm_cls(x))
 
     def _forward_features_pipelined(self, x, n: int):

@@ -187,3 +187,27 @@ def test_gather_combine_with_next_layernorm_equals_the_two_kernels(d, k):
     assert torch.equal(out, ref_out)
     ref_xn = torch.nn.functional.layer_norm(ref_out.double(), (d,), w.double(), b.double(), 1e-6)
     assert (xn.double() - ref_xn).abs().max().item() <= 2e-3 * max(1.0, float(ref_xn.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,size,patch,d", [(3, 3, 224, 16, 768), (2, 3, 224, 16, 192), (2, 3, 384, 16, 1024), (1, 1, 32, 8, 192)])
+def test_embedding_stage_kernels_equal_the_torch_composition(B, C, size, patch, d):
+    """smoe_patchify_cast = the patch gather + fp16 cast (exact copy); smoe_embed_ln = cat(cls, tokens) + pos_embed bit for bit
+    (f16 + f32 -> f32) with LayerNorm(row) = smoe_layernorm of that row bit for bit; smoe_layernorm_rows = smoe_layernorm of the
+    gathered class-token rows bit for bit (models/vision_transformer.py:818-830)."""
+    g = _gen(B + d)
+    img = torch.randn(B, C, size, size, generator=g).to(DEV)
+    gh = gw = size // patch
+    ref = img.reshape(B, C, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gw, C * patch * patch).half()
+    assert torch.equal(ops.patchify_cast(img, patch, patch, torch.float16), ref)
+    P = gh * gw
+    tok = torch.randn(B * P, d, generator=g).half().to(DEV)
+    cls, pos = torch.randn(1, 1, d, generator=g).to(DEV), torch.randn(1, P + 1, d, generator=g).to(DEV)
+    w, b = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
+    x32, xn = ops.embed_ln(tok, cls, pos, B, P, ln=(w, b, 1e-6))
+    want = torch.cat((cls.expand(B, -1, -1), tok.reshape(B, P, d).float()), dim=1) + pos
+    assert torch.equal(x32, want)
+    assert torch.equal(xn, ops.layernorm(want.contiguous(), w, b, 1e-6, torch.float16))
+    x_only, none = ops.embed_ln(tok, cls, pos, B, P)
+    assert none is None and torch.equal(x_only, want)
+    rows = ops.layernorm_rows(want, (P + 1) * d, B, d, w, b, 1e-6)
+    assert torch.equal(rows, ops.layernorm(want[:, 0].contiguous(), w, b, 1e-6, torch.float32))

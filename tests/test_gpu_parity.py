@@ -955,3 +955,68 @@ def test_grouped_gemm_separate_row_ranges_touch_only_their_rows(variant, out_dt)
         r = slice(l * cap, l * cap + fill[l])
         ref[r] = torch.nn.functional.gelu(A[r].double() @ W[gexp[l]].double().t() + bias[gexp[l]].double())
     assert (got.double()[valid] - ref[valid]).abs().max() <= 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("T,d,E,k,cap", [(50432, 768, 8, 1, -1), (1576, 192, 4, 1, -1), (3001, 768, 8, 2, -1), (9000, 384, 8, 1, 700),
+                                         (777, 1024, 5, 4, -1), (64, 192, 8, 1, -1), (65, 192, 8, 2, 10)])
+def test_router_chunk_histogram_gives_the_same_plan_without_the_counting_launch(T, d, E, k, cap):
+    """count_by_gate folded into the fused LayerNorm + router pass (chunk_hist): the table equals a bincount of idx per 64-token
+    chunk -- INCLUDING the tokens the f64 redo pass decides (exact ties planted below) -- and smoe_dispatch_plan_hist builds from it,
+    bit for bit, the plan smoe_dispatch_plan builds by counting idx itself (oracle-pinned in test_dispatch_plan_bit_exact)."""
+    from slim_switch_moe_vit_amd import ops
+    ops.ROUTER_HIST = True                           # (opt-in: measured no faster, ops.py)
+    g = torch.Generator().manual_seed(T + E)
+    x = torch.randn(T, d, generator=g)
+    wg = torch.randn(E, d, generator=g) * 0.1
+    bg = torch.randn(E, generator=g) * 0.05
+    if E >= 2:
+        wg[1] = wg[0]; bg[1] = bg[0]                 # experts 0 and 1 tie on EVERY token: wherever they are in the top k + 1
+    lw, lb = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    hist = ops.chunk_hist(T, d, E, k, DEV)
+    if k == 3 or hist is None:
+        pytest.skip("this shape's router writes no histogram")
+    hist.fill_(-7)                                   # every row must be written
+    xn16, _, idx, score, _, _ = ops.ln_router_topk(x.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6, wg.to(DEV), bg.to(DEV), k, hist=hist)
+    ref_idx = ops.ln_router_topk(x.to(DEV), lw.to(DEV), lb.to(DEV), 1e-6, wg.to(DEV), bg.to(DEV), k)[2]
+    assert torch.equal(idx, ref_idx), "the chunked token order must not change a decision"
+    tok = hist.tok
+    want = torch.zeros_like(hist)
+    chunk = (torch.arange(T, device=DEV) // tok)[:, None].expand(T, k).reshape(-1)
+    want.view(-1).index_add_(0, chunk * E + idx.reshape(-1), torch.ones(T * k, dtype=torch.int32, device=DEV))
+    assert torch.equal(hist, want)
+    a = ops.dispatch_plan(idx, E, cap, hist=hist)
+    b = ops.dispatch_plan(idx, E, cap)
+    ops.ROUTER_HIST = False
+    for u, v, nm in zip(a, b, ("counts", "offsets", "pos", "inv_pos", "pruned")):
+        assert (u is None and v is None) or torch.equal(u, v), nm
+
+
+def test_gated_router_chunk_histogram_counts_only_dispatched_tokens():
+    """The token-skip gate's fused pass (smoe_gate_ln_router): skipped tokens (idx_plan = -1) are not in the histogram, tokens on the
+    gate's threshold are counted by the pass that decides them, and the plan over idx_plan equals the counting plan."""
+    from slim_switch_moe_vit_amd import ops
+    ops.ROUTER_HIST = True
+    T, d, E, k = 5000, 192, 8, 2
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(T, d, generator=g)
+    gw, gb = torch.randn(1, d, generator=g) * 0.1, torch.zeros(1)
+    wg, bgr = torch.randn(E, d, generator=g) * 0.1, torch.randn(E, generator=g) * 0.05
+    lw, lb = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    thr = torch.tensor(0.5, device=DEV)
+    hist = ops.chunk_hist(T, d, E, k, DEV)
+    hist.fill_(-7)
+    r = ops.gate_ln_router(x.to(DEV), gw.to(DEV), gb.to(DEV), thr, ln=(lw.to(DEV), lb.to(DEV), 1e-6), wg=wg.to(DEV), bg=bgr.to(DEV),
+                           k=k, xn16_dtype=torch.float16, want_xn32=True, want_mask=True, hist=hist)
+    ip = r["idx_plan"]
+    n_skip = int((ip[:, 0] < 0).sum())
+    assert 0 < n_skip < T
+    keep = (ip >= 0).reshape(-1)
+    chunk = (torch.arange(T, device=DEV) // hist.tok)[:, None].expand(T, k).reshape(-1)
+    want = torch.zeros_like(hist)
+    want.view(-1).index_add_(0, (chunk * E + ip.reshape(-1).clamp(min=0))[keep], torch.ones(int(keep.sum()), dtype=torch.int32, device=DEV))
+    assert torch.equal(hist, want)
+    a = ops.dispatch_plan(ip, E, -1, hist=hist)
+    b = ops.dispatch_plan(ip, E, -1)
+    ops.ROUTER_HIST = False
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u, v)

@@ -71,7 +71,14 @@ print(d['ms_per_step'], {k: v['avg_ms'] for k, v in d['kernels'].items() if 'gem
     TAG=$1; O=gpurun_out/prof_$TAG; mkdir -p $O
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 bench.py --no-cpu-baseline --clock-seconds 0 --steps 20 --warmup 5 > $O/bench.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o train -- python3 tools/train_bench.py model 128 6 > $O/train.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_resmoe -o train -- python3 tools/train_bench.py model 128 6 resmoe_base_patch16_224_expert8_top1 > $O/train_resmoe.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/dispatch -o dispatch -- python3 tools/dispatch_prof.py 20 > $O/dispatch.log 2>&1
+    for set in A B; do   # attention forward + backward (counters before any change)
+      if [ $set = A ]; then C="$PMC_A"; else C="$PMC_B"; fi
+      rocprofv3 --pmc $C --output-format csv -d $O/pmc${set}_attn -o a -- python3 tools/attn_prof.py > $O/pmc${set}_attn.log 2>&1
+    done
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_attn -o f -- python3 tools/attn_prof.py > $O/fetch_attn.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_attn -o w -- python3 tools/attn_prof.py > $O/write_attn.log 2>&1
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_dispatch -o f -- python3 tools/dispatch_prof.py 3 > $O/fetch_dispatch.log 2>&1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_dispatch -o w -- python3 tools/dispatch_prof.py 3 > $O/write_dispatch.log 2>&1
     for shape in fc1 fc2 ffn; do
