@@ -102,7 +102,7 @@ class _GroupFFN(torch.autograd.Function):
     """rows [n, d] in G groups (group g uses expert group_expert[g], or g) -> Y [n, d]."""
 
     @staticmethod
-    def forward(ctx, rows, w1, b1, w2, b2, mod, offsets, group_expert, drop_mask):
+    def forward(ctx, rows, w1, b1, w2, b2, mod, offsets, group_expert, drop_mask, zero_groups=0):
         cd = rows.dtype
         ex = mod.experts
         w1c, w2c = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
@@ -113,6 +113,7 @@ class _GroupFFN(torch.autograd.Function):
         Y = ops.grouped_gemm(A, w2c, b2.detach().float() if b2 is not None else None, offsets, ops.EPI_NONE, cd,
                              variant=mod.gemm_variant, group_expert=group_expert)
         ctx.mod = mod
+        ctx.zero_groups = zero_groups
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
         ctx.has_map, ctx.has_drop = group_expert is not None, drop_mask is not None
         ctx.save_for_backward(rows, Hp, A, offsets,
@@ -140,10 +141,31 @@ class _GroupFFN(torch.autograd.Function):
             dH = dH * drop_mask
         # dW2[e] = dY_e^T A_e, dW1[e] = dH_e^T R_e straight from the token-major tensors (transposing LDS reads;
         # smoe_transpose_pad + smoe_grouped_wgrad is the older two-step form, kept in ops for A/B tests)
-        dW2 = ops.grouped_wgrad_rows(dY, A, offsets)
-        dW1 = ops.grouped_wgrad_rows(dH, rows, offsets)
-        db2 = ops.group_colsum(dY, offsets) if ctx.has_b2 else None
-        db1 = ops.group_colsum(dH, offsets) if ctx.has_b1 else None
+        Z = ctx.zero_groups
+        if Z:
+            # The last Z row groups hold ALL-ZERO input rows (tokens the skip gate masked: models/resMoE.py:141 `x * mask`), every one
+            # routed by the gate bias alone to the same expert gmap[E + j] -- up to half of the batch in ONE group, and a weight-gradient
+            # tile walks its whole group (443 us against 129 us per launch at ViT-B with 41 % skipped).  Their weight gradients need no
+            # GEMM: dW1 gets nothing (zero input rows), and the rows of A = gelu(b1[e]) are identical, so dW2 gets the rank-1 term
+            # colsum(dY_g) (x) A_row; the bias gradients are column sums as for every group.  The GEMMs run over the first E groups only.
+            E = G - Z
+            offs_e = offsets[: E + 1]
+            dW2 = ops.grouped_wgrad_rows(dY, A, offs_e)
+            dW1 = ops.grouped_wgrad_rows(dH, rows, offs_e)
+            cs2 = ops.group_colsum(dY, offsets)                       # [G, d]
+            cs1 = ops.group_colsum(dH, offsets)                       # [G, h]
+            tgt = gmap[E:].long()                                     # experts of the zero-row groups (device; no host read)
+            first = offsets[E:G].long().clamp(max=max(n - 1, 0))      # a row of each zero group (an empty group's sum is 0 anyway)
+            a_rows = A.index_select(0, first).float()                 # [Z, h]
+            dW2.index_add_(0, tgt, cs2[E:, :, None] * a_rows[:, None, :])
+            db2 = cs2[:E].index_add(0, tgt, cs2[E:]) if ctx.has_b2 else None
+            db1 = cs1[:E].index_add(0, tgt, cs1[E:]) if ctx.has_b1 else None
+            G = E
+        else:
+            dW2 = ops.grouped_wgrad_rows(dY, A, offsets)
+            dW1 = ops.grouped_wgrad_rows(dH, rows, offsets)
+            db2 = ops.group_colsum(dY, offsets) if ctx.has_b2 else None
+            db1 = ops.group_colsum(dH, offsets) if ctx.has_b1 else None
         if G != E_local:  # rank-major groups (source rank, local expert): fold the source ranks
             dW2, dW1 = dW2.view(-1, E_local, *dW2.shape[1:]).sum(0), dW1.view(-1, E_local, *dW1.shape[1:]).sum(0)
             db2 = db2.view(-1, E_local, db2.shape[1]).sum(0) if db2 is not None else None
@@ -153,7 +175,7 @@ class _GroupFFN(torch.autograd.Function):
             w1t = ex.htoh4.weight_t_as(cd)                                               # [E, d, h]  (N = d, K = h)
             drows = ops.grouped_gemm(dH, w1t, None, offsets, ops.EPI_NONE, cd, variant=mod.gemm_variant,
                                      group_expert=gexp)
-        return drows, dW1, db1, dW2, db2, None, None, None, None
+        return drows, dW1, db1, dW2, db2, None, None, None, None, None
 
 
 class _GateLogits(torch.autograd.Function):
@@ -209,8 +231,31 @@ class _SwitchScoreAux(torch.autograd.Function):
         return ops.switch_gate_bwd(probs, idx.reshape(-1), ds, coef), None, None, None, None, None
 
 
-def _route_train(mod, x):
-    """HIP routing + the differentiable gate score; returns (idx, score, plan tensors)."""
+def _zero_row_routing(mod) -> torch.Tensor:
+    """int64 [k] (device): the experts an all-zero row is routed to (top-k of the gate bias; ties -> lowest id), from the HIP
+    router itself, cached per version of the gate parameters."""
+    from ._cache import StreamCache, param_version
+    g = mod.gate.gate
+    cache = mod.__dict__.get("_zero_route")
+    if cache is None:
+        cache = mod.__dict__["_zero_route"] = StreamCache()
+        mod.register_load_state_dict_post_hook(lambda m, _k: m.__dict__["_zero_route"].invalidate())
+    ver = (param_version(g.weight), param_version(g.bias) if g.bias is not None else None)
+
+    def make():
+        z = torch.zeros((1, mod.d_model), dtype=torch.float32, device=g.weight.device)
+        idx0, _, _, _ = ops.router_topk(z, g.weight.detach().float().contiguous(), g.bias.detach().float() if g.bias is not None else None,
+                                        mod.top_k, ops.GATE_NAIVE)
+        return idx0.reshape(-1).clone()
+    return cache.get(str(g.weight.device), ver, make)
+
+
+def _route_train(mod, x, zero_rows=None):
+    """HIP routing + the differentiable gate score; returns (score, counts, offsets, pos, inv_pos, group map | None, zero groups).
+    ``zero_rows`` (bool [T], NaiveGate only): tokens whose row is all zero (masked by the token-skip gate).  They get row groups of
+    their own -- group E + j for their j-th choice -- that use the expert the gate bias sends every zero row to (the group ->
+    expert map): same numbers as dispatching them with everybody else, but the experts' own groups stay balanced and the zero
+    groups' weight gradients are rank-1 (_GroupFFN.backward)."""
     from .fmoe import SwitchGate
 
     g = mod.gate
@@ -221,11 +266,20 @@ def _route_train(mod, x):
     gw = g.gate.weight.detach().float().contiguous()
     gb = g.gate.bias.detach().float() if g.gate.bias is not None else None
     need_grad = is_switch or k > 1
+    g_map, zero_groups = None, 0
     with torch.no_grad():
         idx, score_c, logits_r, probs_r = ops.router_topk(x.detach(), gw, gb, k, g.kind, noise, want_logits=need_grad,
                                                           want_probs=is_switch)
         cap = g.capacity(T)
-        counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, g.tot_expert, cap)
+        E = g.tot_expert
+        if zero_rows is not None and not is_switch and cap < 0 and E + k <= 63:
+            idx0 = _zero_row_routing(mod)                                                  # [k]: where the bias sends a zero row
+            idx_plan = torch.where(zero_rows.reshape(T, 1), torch.arange(E, E + k, device=x.device).reshape(1, k), idx)
+            counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx_plan, E + k, cap)
+            g_map = torch.cat((torch.arange(E, device=x.device), idx0)).to(torch.int32)
+            zero_groups = k
+        else:
+            counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, E, cap)
     mod.last_plan = (idx, score_c, counts, offsets, pos, inv_pos)
     if need_grad:  # tiny [T,E] work -- the routing itself stays the HIP router's
         logits = _GateLogits.apply(x, g.gate.weight, g.gate.bias, logits_r)
@@ -236,10 +290,11 @@ def _route_train(mod, x):
             score = torch.softmax(logits.gather(1, idx), dim=-1)
     else:
         score = score_c  # top-1 naive gate: softmax over one logit == 1, no gradient (SURVEY.md 'DDP + top-1')
-    return score, counts, offsets, pos, inv_pos
+    return score, counts, offsets, pos, inv_pos, g_map, zero_groups
 
 
-def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row_scale: torch.Tensor = None) -> torch.Tensor:
+def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row_scale: torch.Tensor = None,
+                      zero_rows: torch.Tensor = None) -> torch.Tensor:
     """FMoETransformerMLP.forward with autograd: single rank, or expert parallel (one exchange each way); ``residual``
     (inp's shape and dtype) is added in the combine's store; ``row_scale`` (f32 [T], no gradient) multiplies every token's
     combined expert output (stochastic depth) -- folded into the combine weights, so the backward sees it as part of them."""
@@ -254,9 +309,9 @@ def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row
     if not x.is_contiguous():
         x = x.contiguous()
     T = x.shape[0]
-    score, counts, offsets, pos, inv_pos = _route_train(mod, x)
-    ex = mod.experts
     ep = mod.world_size > 1 or getattr(mod, "force_ep", False)
+    score, counts, offsets, pos, inv_pos, zmap, zero_groups = _route_train(mod, x, None if ep else zero_rows)
+    ex = mod.experts
     S = _Scatter.apply(x, pos, inv_pos, k, cd)
     if ep:
         from .ep import exchange_counts, segment_table
@@ -267,13 +322,13 @@ def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row
         g_offsets = torch.tensor(offs, dtype=torch.int32, device=x.device)
         g_map = torch.tensor(gexp, dtype=torch.int32, device=x.device)
     else:
-        rows, g_offsets, g_map = S, offsets, None
+        rows, g_offsets, g_map = S, offsets, zmap
     drop_mask = None
     if mod._drop_p > 0 and mod.training:
         keep = 1.0 - mod._drop_p
         drop_mask = (torch.rand(rows.shape[0], mod.d_hidden, device=x.device) < keep).to(cd) / keep
     Y = _GroupFFN.apply(rows, ex.htoh4.weight, ex.htoh4.bias, ex.h4toh.weight, ex.h4toh.bias, mod, g_offsets, g_map,
-                        drop_mask)
+                        drop_mask, zero_groups)
     if ep:
         back = _AllToAll.apply(Y, recv_rows, send_rows, mod.moe_group)
         if back.shape[0] < pos.numel():  # slots past the kept count carry no row

@@ -68,12 +68,6 @@ def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, 
     group cannot take CUDA tensors through all-to-all, so there the buffers are staged through the host -- slow, but
     it lets the complete multi-rank data path (routing, exchange layouts, group->expert GEMMs, the micro-batch
     pipeline) run as several processes on ONE GPU in tests/test_gpu_model.py."""
-    if inp.is_cuda and dist.get_backend(group) == "gloo":
-        h_in = inp.cpu()
-        h_out = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(h_out, h_in, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
-        out.copy_(h_out)
-        return _DoneWork() if async_op else None
     if inp.is_cuda and os.environ.get("SLIMMOE_EP_TRANSPORT", "torch") == "cabi":
         # the C-ABI transport (include/slimmoe.h smoe_a2a_*): own communicator, own stream, event fences
         ctx = _cabi_context(group, inp.device)
@@ -86,6 +80,12 @@ def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, 
         rr = out_splits if out_splits is not None else [rows_out.shape[0] // W] * W
         ctx.all_to_all_rows(rows_in, sr, rr, wait=not async_op, out=rows_out)
         return _CtxWork(ctx, out) if async_op else None
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        h_in = inp.cpu()
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, h_in, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(h_out)
+        return _DoneWork() if async_op else None
     return dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
                                   async_op=async_op)
 

@@ -247,17 +247,20 @@ class FMoETransformerMLP(nn.Module):
             p.dp_comm = "dp" if self.world_size > 1 else "none"
 
     # -- hot path ------------------------------------------------------------------------------------
-    def forward_add(self, inp: torch.Tensor, residual: torch.Tensor, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward_add(self, inp: torch.Tensor, residual: torch.Tensor, row_scale: Optional[torch.Tensor] = None,
+                    zero_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``residual + self(inp)`` with the add fused into the combine store (the ``x + mlp(norm2(x))`` of
         models/vision_transformer.py:321); same arithmetic as the unfused form, one HBM pass fewer.  ``row_scale`` (f32, one
         entry per token, no gradient): ``residual + row_scale[t] * self(inp)[t]`` -- stochastic depth's per-sample ``mask / keep``
-        (models/vision_transformer.py:308) folded into the combine weights."""
+        (models/vision_transformer.py:308) folded into the combine weights.  ``zero_rows`` (bool, one entry per token; training only):
+        the rows of ``inp`` that are all zero because the token-skip gate masked them -- a hint that changes no result, only how the
+        row groups are cut (autograd._route_train)."""
         if torch.is_grad_enabled() and (inp.requires_grad or residual.requires_grad or
                                         any(p.requires_grad for p in self.parameters())):
             if inp.is_cuda and residual.shape == inp.shape and residual.dtype == inp.dtype and residual.is_contiguous():
                 from .autograd import moe_forward_train
                 # the add rides in the combine, forward and backward
-                return moe_forward_train(self, inp, residual=residual, row_scale=row_scale)
+                return moe_forward_train(self, inp, residual=residual, row_scale=row_scale, zero_rows=zero_rows)
         if row_scale is not None:
             return residual + self.forward(inp) * row_scale.reshape(inp.shape[:-1] + (1,)).to(inp.dtype)
         if torch.is_grad_enabled() and (inp.requires_grad or residual.requires_grad or

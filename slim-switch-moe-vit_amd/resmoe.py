@@ -249,8 +249,10 @@ def _residual_block_train(blk, x):
         a = xn.reshape(B, N, d) + (a if rows1 is None else a * rows1.reshape(B, N, 1).to(a.dtype))
     x1 = a.reshape(B * N, d)
     _, rows2 = blk._depth_scale(x)
-    xn2, tk32, _ = _GateLNFn.apply(x1, *_gate_ln(x1, blk.norm2, blk.moe_gate), False)
-    return blk.mlp.forward_add(tk32.reshape(B, N, d), xn2.reshape(B, N, d), row_scale=rows2)
+    xn2, tk32, mask2 = _GateLNFn.apply(x1, *_gate_ln(x1, blk.norm2, blk.moe_gate), False)
+    # (the skipped tokens' all-zero rows get row groups of their own in the operator's training path: autograd._route_train)
+    skipped = mask2[:, 0] > 0.5 if blk.moe_gate.active_threshold() is not None else None
+    return blk.mlp.forward_add(tk32.reshape(B, N, d), xn2.reshape(B, N, d), row_scale=rows2, zero_rows=skipped)
 
 
 def _fused_ok(blk, x) -> bool:

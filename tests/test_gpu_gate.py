@@ -423,3 +423,31 @@ def test_residual_block_training_against_the_reference_forward_residule_moe_grad
     print("residual block, training, relative L2 gradient differences vs the reference:",
           {n: f"{e:.1e}" for e, n in sorted(worst, reverse=True)[:6]})
     assert max(worst)[0] <= 3e-2, max(worst)
+
+
+@pytest.mark.parametrize("E,k", [(8, 1), (8, 2), (4, 1)])
+def test_zero_row_groups_change_no_result_of_the_training_operator(E, k):
+    """The training path's hint ``zero_rows`` (tokens the skip gate masked) cuts the all-zero rows into row groups of their own
+    (group -> expert map, rank-1 weight gradients): the output is bit for bit the output without the hint, every gradient agrees to
+    summation order -- with ~45 % of the rows zero, i.e. one expert's group 4-5 x the size of the others without it."""
+    d, h, T = 192, 768, 3000
+    mod = _mk_moe(d, h, E, k, seed=5).train()
+    g = _gen(9)
+    x = torch.randn(T, d, generator=g)
+    zero = torch.rand(T, generator=g) < 0.45
+    x[zero] = 0.0
+    res = torch.randn(T, d, generator=g).to(DEV)
+    dy = (torch.randn(T, d, generator=g) * 0.1).to(DEV)
+
+    def run(hint):
+        mod.zero_grad(set_to_none=True)
+        xg = x.to(DEV).requires_grad_(True)
+        out = mod.forward_add(xg, res, zero_rows=zero.to(DEV) if hint else None)
+        out.backward(dy)
+        return out.detach(), xg.grad, {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+    o1, dx1, g1 = run(True)
+    o2, dx2, g2 = run(False)
+    assert torch.equal(o1, o2) and torch.equal(dx1, dx2)
+    assert set(g1) == set(g2)
+    for n in g1:
+        assert _rel(g1[n], g2[n]) <= 2e-3, (n, _rel(g1[n], g2[n]))
