@@ -720,7 +720,11 @@ class VisionTransformer(nn.Module):
         f = self.forward_features(x)
         if isinstance(self.head, nn.Linear) and _autocast_half_inference(f):
             hc = _half_cache(self)  # what autocast computes, minus the per-call weight casts
-            f16 = f.to(torch.float16)
+            if f.dtype == torch.float32 and f.is_contiguous():
+                from . import ops
+                f16 = ops.cast(f, torch.float16)
+            else:
+                f16 = f.to(torch.float16)
             out = _linear16(hc, f16.reshape(-1, f16.shape[-1]), self.head.weight, self.head.bias, name="head_gemm") if f16.dim() == 2 else None
             if out is not None:
                 return out
