@@ -197,6 +197,10 @@ int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, int64_t capa
  * (backward of the combine: dY[s] = score * dout[token]).                                           */
 int smoe_scatter_rows(const void* x, int x_dtype, const int64_t* pos, const float* scale, int64_t n_slots, int k, int d,
                       void* buf, int buf_dtype, void* stream);
+/* the same, and every slot with pos[s] < 0 (no token: past the kept count under a capacity) is written as a zero row in the same
+ * pass (the training path's buffers: instead of clearing the whole buffer first).                                             */
+int smoe_scatter_rows_fill(const void* x, int x_dtype, const int64_t* pos, const float* scale, int64_t n_slots, int k, int d,
+                           void* buf, int buf_dtype, void* stream);
 
 /* ---- gather + combine (MOEGather.forward + bmm(gate_score, y)) -------------------
  * out[t,:] = sum_j score[t,j] * y[inv_pos[t*k+j], :]   (a dropped entry contributes 0)
@@ -296,10 +300,18 @@ int smoe_transpose_pad(const void* src, int dtype, const int32_t* offsets, const
                        int64_t n_rows, int C, int Lp, void* dst, void* stream);
 /* smoe_switch_gate_bwd: gradient of the SwitchGate's score and load-balance loss w.r.t. the router logits (fmoe.gates.SwitchGate:
  * score = softmax(logits)[idx], aux = E sum_e frac_e prob_e), one pass over [T, E]:  g[t,e] = coef[e] + (e == idx[t] ? dscore[t] : 0),
- * dlogits[t,e] = probs[t,e] (g[t,e] - sum_j probs[t,j] g[t,j]).  coef [E] f32 (device; = daux * E * frac_e / kept) or NULL,
- * dscore [T] f32 or NULL, idx [T] int64 (entries outside [0, E) select nothing).                                               */
-int smoe_switch_gate_bwd(const float* probs, const int64_t* idx, const float* dscore, const float* coef, int64_t T, int E,
-                         float* dlogits, void* stream);
+ * dlogits[t,e] = probs[t,e] (g[t,e] - sum_j probs[t,j] g[t,j]).  coef [E] f32 (device; = E * frac_e / kept, smoe_switch_aux's) or
+ * NULL, times *coef_scale (device scalar: d loss / d aux; NULL = 1); dscore [T] f32 or NULL, idx [T] int64 (entries outside
+ * [0, E) select nothing).                                                                                                       */
+int smoe_switch_gate_bwd(const float* probs, const int64_t* idx, const float* dscore, const float* coef, const float* coef_scale,
+                         int64_t T, int E, float* dlogits, void* stream);
+/* smoe_switch_aux: the SwitchGate's load-balance loss (fmoe.gates.SwitchGate), forward: aux [1] = E sum_e frac_e prob_e,
+ * frac_e = counts[e] / kept, prob_e = sum_t probs[t,e] / kept, kept = max(sum_e counts[e], 1); coef [E] = E frac_e / kept
+ * (= d aux / d probs[t,e] for every t: what smoe_switch_gate_bwd takes).  probs f32 [T, E], counts i32 [E] (the plan's kept counts);
+ * E <= 256; two deterministic launches (chunk column sums, then one workgroup).                                                 */
+size_t smoe_switch_aux_workspace_bytes(int64_t T, int E);
+int smoe_switch_aux(const float* probs, const int32_t* counts, int64_t T, int E, float* aux, float* coef, void* workspace,
+                    size_t workspace_bytes, void* stream);
 /* smoe_transpose_cast: dst[b][c][r] = (dst_dtype) src[b][r][c] for b < B; R % 64 == 0, C % 64 == 0.  The backward pass reads every
  * expert weight [E, out, in] a second time as [E, in, out] (FastMoE: `MOELinear.backward` -> fmoe_cuda.linear_backward contracts
  * grad_out with the weight over `out`); this makes that 16-bit image straight from the f32 master in one pass.               */
@@ -314,10 +326,11 @@ int smoe_grouped_wgrad_rows(const void* P, const void* Q, int ab_dtype, const in
                             const void* zero16, float* out, void* stream);
 /* smoe_gate_wgrad: router weight gradient dWg [E, C] f32 = dl^T x, dl [n_rows, E] f32 (d loss / d logits), x [n_rows, C]
  * f32 / f16 / bf16; E <= 16, C % 4 == 0; HBM-bound two-pass weighted column sum (what torch's matmul backward of the gate
- * nn.Linear computes, models/resmoe_flop_hook.py:7-8 names that layer). */
+ * nn.Linear computes, models/resmoe_flop_hook.py:7-8 names that layer).  db (f32 [E], may be NULL) = column sums of dl, the gate
+ * bias' gradient, from the same pass (x's "ones column"). */
 size_t smoe_gate_wgrad_workspace_bytes(int64_t n_rows, int E, int C);
-int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int64_t n_rows, int E, int C, float* out, void* workspace,
-                    size_t workspace_bytes, void* stream);
+int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int64_t n_rows, int E, int C, float* out, float* db,
+                    void* workspace, size_t workspace_bytes, void* stream);
 size_t smoe_group_colsum_workspace_bytes(int64_t n_rows_max, int E, int C);
 int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int64_t n_rows_max, int C, float* out,
                       void* workspace, size_t workspace_bytes, void* stream);

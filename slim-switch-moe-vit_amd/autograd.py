@@ -51,9 +51,49 @@ class _Scatter(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dS):
         (inv_pos,) = ctx.saved_tensors
-        ones = torch.ones(ctx.T * ctx.k, dtype=torch.float32, device=dS.device)
-        dx = ops.gather_combine(dS.contiguous(), inv_pos, ones, ctx.T, ctx.k, ctx.dtype)
+        dx = ops.gather_combine(dS.contiguous(), inv_pos, ops.ones_f32(ctx.T * ctx.k, dS.device), ctx.T, ctx.k, ctx.dtype)
         return dx, None, None, None, None
+
+
+class _GateScatter(torch.autograd.Function):
+    """The two readers of the routed rows x as ONE autograd node: ``(logits, S)`` = (the gate's logits the HIP router already computed,
+    the scattered rows).  x feeds the gate linear and the scatter; as two nodes autograd adds their input gradients with a kernel
+    of its own (a [T, d] read-modify-write per layer).  Here the scatter's adjoint (smoe_gather_combine) takes the gate's
+    dx = dl Wg (smoe_gate_dgrad) as its residual operand -- the add rides in the gather's store."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, logits, pos, inv_pos, k, cd):
+        ctx.k, ctx.has_b = k, b is not None
+        ctx.save_for_backward(x, w, inv_pos)
+        return logits.view_as(logits), ops.scatter_rows(x, pos, k, cd, zero_fill=True)
+
+    @staticmethod
+    def backward(ctx, dl, dS):
+        x, w, inv_pos = ctx.saved_tensors
+        T, k = x.shape[0], ctx.k
+        dgate = dw = db = None
+        if dl is not None:
+            dl = dl.float().contiguous()
+            if ctx.needs_input_grad[0]:
+                dgate = ops.gate_dgrad(dl, w.detach().float().contiguous(), x.dtype)
+            if ctx.needs_input_grad[1]:
+                want_b = ctx.has_b and ctx.needs_input_grad[2]
+                if dl.shape[1] <= 16:
+                    got = ops.gate_wgrad(dl, x.contiguous(), want_bias=want_b)
+                    dw, db = got if want_b else (got, None)
+                else:
+                    dw = dl.t() @ x.float()
+                    db = dl.sum(0) if want_b else None
+                dw = dw.to(w.dtype)
+            elif ctx.has_b and ctx.needs_input_grad[2]:
+                db = dl.sum(0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if dS is not None:
+                dx = ops.gather_combine(dS.contiguous(), inv_pos, ops.ones_f32(T * k, x.device), T, k, x.dtype, residual=dgate)
+            else:
+                dx = dgate
+        return dx, dw, db, None, None, None, None, None
 
 
 class _Combine(torch.autograd.Function):
@@ -199,13 +239,17 @@ class _GateLogits(torch.autograd.Function):
                 dx = ops.gate_dgrad(dl, w.detach(), x.dtype)       # [T, E] x [E, d]: a streaming kernel, not a GEMM
             else:
                 dx = (dl @ w.float()).to(x.dtype)
-        dw = None
+        dw = db = None
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if x.is_cuda and dl.shape[1] <= 16 and x.shape[1] % 4 == 0 and x.dtype in (torch.float32, torch.float16, torch.bfloat16):
-                dw = ops.gate_wgrad(dl, x.contiguous()).to(w.dtype)
+                got = ops.gate_wgrad(dl, x.contiguous(), want_bias=want_b)     # the bias gradient = the same pass' "ones column"
+                dw, db = got if want_b else (got, None)
+                dw = dw.to(w.dtype)
             else:
                 dw = (dl.t() @ x.float()).to(w.dtype)
-        db = dl.sum(0) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        if want_b and db is None:
+            db = dl.sum(0)
         return dx, dw, db, None
 
 
@@ -217,18 +261,18 @@ class _SwitchScoreAux(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, logits, probs, score, idx, counts, E):
-        kept = counts.sum().clamp(min=1).to(torch.float32)
-        frac = counts.to(torch.float32) / kept                      # share of kept tokens per expert (dropped ones count nowhere)
-        aux = E * (frac * (probs.sum(0) / kept)).sum()
-        ctx.save_for_backward(probs, idx, (E * frac / kept).contiguous())   # d aux / d p[t, e], the same for every t
-        return score.clone(), aux
+        # aux and cbase[e] = E frac_e / kept = d aux / d p[t, e] (the same for every t; dropped tokens count nowhere): smoe_switch_aux
+        aux, cbase = ops.switch_aux(probs, counts)
+        ctx.save_for_backward(probs, idx, cbase)
+        return score.view_as(score), aux
 
     @staticmethod
     def backward(ctx, dscore, daux):
         probs, idx, cbase = ctx.saved_tensors
-        coef = (cbase * daux.to(cbase.dtype)).contiguous() if daux is not None else None
         ds = dscore.reshape(-1).to(torch.float32).contiguous() if dscore is not None else None
-        return ops.switch_gate_bwd(probs, idx.reshape(-1), ds, coef), None, None, None, None, None
+        scale = daux.reshape(1).to(torch.float32) if daux is not None else None      # multiplied onto cbase inside the kernel
+        return (ops.switch_gate_bwd(probs, idx.reshape(-1), ds, cbase if daux is not None else None, scale),
+                None, None, None, None, None)
 
 
 def _zero_row_routing(mod) -> torch.Tensor:
@@ -250,8 +294,10 @@ def _zero_row_routing(mod) -> torch.Tensor:
     return cache.get(str(g.weight.device), ver, make)
 
 
-def _route_train(mod, x, zero_rows=None):
-    """HIP routing + the differentiable gate score; returns (score, counts, offsets, pos, inv_pos, group map | None, zero groups).
+def _route_train(mod, x, zero_rows=None, scatter_cd=None):
+    """HIP routing + the differentiable gate score; returns (score, counts, offsets, pos, inv_pos, group map | None, zero groups, S).
+    ``scatter_cd``: also scatter the rows (compute dtype) -- S, else None; when the gate's logits carry a gradient the scatter and
+    the gate linear are one autograd node (_GateScatter: one gradient for x, no add kernel).
     ``zero_rows`` (bool [T], NaiveGate only): tokens whose row is all zero (masked by the token-skip gate).  They get row groups of
     their own -- group E + j for their j-th choice -- that use the expert the gate bias sends every zero row to (the group ->
     expert map): same numbers as dispatching them with everybody else, but the experts' own groups stay balanced and the zero
@@ -281,8 +327,14 @@ def _route_train(mod, x, zero_rows=None):
         else:
             counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, E, cap)
     mod.last_plan = (idx, score_c, counts, offsets, pos, inv_pos)
+    S = None
     if need_grad:  # tiny [T,E] work -- the routing itself stays the HIP router's
-        logits = _GateLogits.apply(x, g.gate.weight, g.gate.bias, logits_r)
+        fused = (scatter_cd is not None and x.is_cuda and x.shape[1] % 4 == 0 and x.dtype in ops._DT
+                 and g.gate.weight.dtype == torch.float32)
+        if fused:
+            logits, S = _GateScatter.apply(x, g.gate.weight, g.gate.bias, logits_r, pos, inv_pos, k, scatter_cd)
+        else:
+            logits = _GateLogits.apply(x, g.gate.weight, g.gate.bias, logits_r)
         if is_switch:   # probs_r = softmax(logits + noise) and score_c = probs_r[idx] are the router's own
             score, aux = _SwitchScoreAux.apply(logits, probs_r, score_c, idx, counts, g.tot_expert)
             g.set_loss(aux)
@@ -290,7 +342,9 @@ def _route_train(mod, x, zero_rows=None):
             score = torch.softmax(logits.gather(1, idx), dim=-1)
     else:
         score = score_c  # top-1 naive gate: softmax over one logit == 1, no gradient (SURVEY.md 'DDP + top-1')
-    return score, counts, offsets, pos, inv_pos, g_map, zero_groups
+    if S is None and scatter_cd is not None:
+        S = _Scatter.apply(x, pos, inv_pos, k, scatter_cd)
+    return score, counts, offsets, pos, inv_pos, g_map, zero_groups, S
 
 
 def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row_scale: torch.Tensor = None,
@@ -310,9 +364,8 @@ def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row
         x = x.contiguous()
     T = x.shape[0]
     ep = mod.world_size > 1 or getattr(mod, "force_ep", False)
-    score, counts, offsets, pos, inv_pos, zmap, zero_groups = _route_train(mod, x, None if ep else zero_rows)
+    score, counts, offsets, pos, inv_pos, zmap, zero_groups, S = _route_train(mod, x, None if ep else zero_rows, scatter_cd=cd)
     ex = mod.experts
-    S = _Scatter.apply(x, pos, inv_pos, k, cd)
     if ep:
         from .ep import exchange_counts, segment_table
         lec, gec = exchange_counts([counts], mod.world_size, mod.moe_group)

@@ -148,28 +148,101 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const ST* __restric
 //   g[t, e] = coef[e] + (e == idx[t] ? dscore[t] : 0)          coef[e] = d aux / d p[t, e] = daux * E * frac_e / kept (any t)
 //   dlogits[t, e] = p[t, e] * (g[t, e] - sum_j p[t, j] g[t, j])                                     (softmax backward)
 // One thread per token; the row (E <= 64 floats) is read twice from L1.
+// coef_scale (device scalar, optional): the loss's gradient w.r.t. aux, multiplied onto coef here (not by a host-launched [E] multiply)
 __global__ __launch_bounds__(256) void switch_gate_bwd_kernel(const float* __restrict__ probs, const int64_t* __restrict__ idx,
                                                               const float* __restrict__ dscore, const float* __restrict__ coef,
+                                                              const float* __restrict__ coef_scale,
                                                               int64_t T, int E, float* __restrict__ dlogits) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
   const float* p = probs + t * E;
   const int64_t sel = idx[t];
   const float ds = dscore ? dscore[t] : 0.f;
+  const float cs = coef_scale ? *coef_scale : 1.0f;
   float dot = 0.f;
-  for (int e = 0; e < E; ++e) dot = fmaf(p[e], (coef ? coef[e] : 0.f) + (e == sel ? ds : 0.f), dot);
+  for (int e = 0; e < E; ++e) dot = fmaf(p[e], (coef ? coef[e] * cs : 0.f) + (e == sel ? ds : 0.f), dot);
   float* o = dlogits + t * E;
-  for (int e = 0; e < E; ++e) o[e] = p[e] * ((coef ? coef[e] : 0.f) + (e == sel ? ds : 0.f) - dot);
+  for (int e = 0; e < E; ++e) o[e] = p[e] * ((coef ? coef[e] * cs : 0.f) + (e == sel ? ds : 0.f) - dot);
 }
 
-// Bias gradients, two deterministic passes.  Pass 1: one workgroup per (512-row chunk of one expert, 256-column slab);
-// wave w sums the chunk's rows w, w+4, ... (a row of the slab is 256 contiguous elements = one 8-byte load per lane),
-// the four waves meet in LDS and the workgroup stores one f32 partial row.  The grid is an upper bound (the row
-// counts live on the device); chunks are numbered expert by expert, so pass 2 adds each expert's partial rows in
-// chunk order.  (The previous one-thread-per-column walk over all of an expert's rows ran 96 workgroups at
-// 735 us for 310 MB; this streams it at HBM speed.)
-constexpr int CS_ROWS = 512;
-constexpr int CS_COLS = 256;
+// SwitchGate load-balance loss, forward (fmoe.gates.SwitchGate): aux = E sum_e frac_e prob_e with
+// frac_e = counts[e] / kept, prob_e = sum_t p[t, e] / kept, kept = max(sum_e counts[e], 1); and coef[e] = E frac_e / kept =
+// d aux / d p[t, e] (any t) for the backward.  Two deterministic launches instead of ~14 tiny host-launched ones: column sums of
+// p [T, E] per SA_ROWS-row chunk (thread = (row of the pass, column), coalesced), then ONE workgroup adds the chunks in order.
+constexpr int SA_ROWS = 1024;
+constexpr int SA_MAX_E = 256;
+
+__global__ __launch_bounds__(256) void switch_aux_partial_kernel(const float* __restrict__ probs, int64_t T, int E,
+                                                                 float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int rpp = 256 / E;                       // rows per pass (E <= 256)
+  const int rr = threadIdx.x / E, e = threadIdx.x - rr * E;
+  const int64_t r0 = (int64_t)blockIdx.x * SA_ROWS;
+  const int64_t r1 = r0 + SA_ROWS < T ? r0 + SA_ROWS : T;
+  float a0 = 0.f, a1 = 0.f;
+  if (rr < rpp) {
+    int64_t r = r0 + rr;
+    for (; r + rpp < r1; r += 2 * rpp) {
+      a0 += probs[r * E + e];
+      a1 += probs[(r + rpp) * E + e];
+    }
+    if (r < r1) a0 += probs[r * E + e];
+  }
+  red[threadIdx.x] = a0 + a1;
+  __syncthreads();
+  if (threadIdx.x < E) {
+    float acc = 0.f;
+    for (int q = 0; q < rpp; ++q) acc += red[q * E + threadIdx.x];
+    partial[(int64_t)blockIdx.x * E + threadIdx.x] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void switch_aux_final_kernel(const float* __restrict__ partial, int n_chunks,
+                                                               const int32_t* __restrict__ counts, int E,
+                                                               float* __restrict__ aux, float* __restrict__ coef) {
+  __shared__ float term[SA_MAX_E];
+  __shared__ float kept_s;
+  const int e = threadIdx.x;
+  if (e == 0) {
+    int64_t k = 0;
+    for (int q = 0; q < E; ++q) k += counts[q];
+    kept_s = (float)(k < 1 ? 1 : k);
+  }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (e < E) {
+    int c = 0;
+    for (; c + 3 < n_chunks; c += 4) {
+      a0 += partial[(int64_t)c * E + e];
+      a1 += partial[(int64_t)(c + 1) * E + e];
+      a2 += partial[(int64_t)(c + 2) * E + e];
+      a3 += partial[(int64_t)(c + 3) * E + e];
+    }
+    for (; c < n_chunks; ++c) a0 += partial[(int64_t)c * E + e];
+  }
+  __syncthreads();
+  const float kept = kept_s;
+  if (e < E) {
+    const float frac = (float)counts[e] / kept;
+    term[e] = frac * (((a0 + a1) + (a2 + a3)) / kept);
+    coef[e] = (float)E * frac / kept;
+  }
+  __syncthreads();
+  if (e == 0) {
+    float acc = 0.f;
+    for (int q = 0; q < E; ++q) acc += term[q];
+    *aux = (float)E * acc;
+  }
+}
+
+// Bias gradients, two deterministic passes.  Pass 1: one workgroup of 16 waves per (CS_ROWS-row chunk of one group, slab of 64 x VEC
+// columns: VEC = 8 elements = one 16-byte load per lane for 16-bit rows, 4 for f32); wave w sums the chunk's rows w, w+16, ...
+// with four rows in flight per lane, the sixteen waves meet in LDS (fixed order) and the workgroup stores one f32 partial row.
+// The grid is an upper bound (the row counts live on the device); chunks are numbered group by group, so pass 2 adds each
+// group's partial rows in chunk order (four waves x two chains per 64-column slab).  [25216, 768] f16 = 99 chunks x 2 slabs of
+// 1024 threads: every CU busy, which the 256-thread / 512-row form (150 workgroups) was not.
+constexpr int CS_ROWS = 256;
+constexpr int CS_COLS = 256;    // slab of the router weight gradient below
+constexpr int CS_WAVES = 16;
 
 __device__ __forceinline__ bool colsum_find_chunk(const int32_t* __restrict__ offsets, int E, int chunk, int& e_out,
                                                   int& r0, int& r1) {
@@ -188,63 +261,83 @@ __device__ __forceinline__ bool colsum_find_chunk(const int32_t* __restrict__ of
   return false;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void group_colsum_partial_kernel(const T* __restrict__ src,
-                                                                   const int32_t* __restrict__ offsets, int E, int C,
-                                                                   float* __restrict__ partial) {
-  __shared__ float red[4][CS_COLS];
+template <typename T, int VEC>
+__global__ __launch_bounds__(64 * CS_WAVES) void group_colsum_partial_kernel(const T* __restrict__ src,
+                                                                             const int32_t* __restrict__ offsets, int E, int C,
+                                                                             float* __restrict__ partial) {
+  static_assert(VEC == 4 || (VEC == 8 && !std::is_same<T, float>::value), "16-byte loads at most");
+  constexpr int SLAB = 64 * VEC;
+  __shared__ float red[CS_WAVES][SLAB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * CS_COLS + lane * 4;
+  const int c = blockIdx.x * SLAB + lane * VEC;
   int e, r0, r1;
   const bool have = colsum_find_chunk(offsets, E, (int)blockIdx.y, e, r0, r1);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (have && c < C) {  // C % 4 == 0 (checked on the host)
-    auto ld = [&](int row, float (&v)[4]) {
+  float a[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) a[q] = 0.f;
+  if (have && c < C) {  // C % VEC == 0 (checked on the host)
+    auto ld = [&](int row, float (&v)[VEC]) {
       const T* p = src + (int64_t)row * C + c;
       if constexpr (std::is_same<T, float>::value) {
         const f32x4 t = *reinterpret_cast<const f32x4*>(p);
         v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+      } else if constexpr (VEC == 8) {
+        load8(p, v);
       } else {
         load4(p, v);
       }
     };
     int r = r0 + wave;
-    for (; r + 12 < r1; r += 16) {  // four rows in flight per lane
-      float v0[4], v1[4], v2[4], v3[4];
-      ld(r, v0); ld(r + 4, v1); ld(r + 8, v2); ld(r + 12, v3);
-      a0 += (v0[0] + v1[0]) + (v2[0] + v3[0]);
-      a1 += (v0[1] + v1[1]) + (v2[1] + v3[1]);
-      a2 += (v0[2] + v1[2]) + (v2[2] + v3[2]);
-      a3 += (v0[3] + v1[3]) + (v2[3] + v3[3]);
+    for (; r + 3 * CS_WAVES < r1; r += 4 * CS_WAVES) {  // four rows in flight per lane
+      float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+      ld(r, v0); ld(r + CS_WAVES, v1); ld(r + 2 * CS_WAVES, v2); ld(r + 3 * CS_WAVES, v3);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) a[q] += (v0[q] + v1[q]) + (v2[q] + v3[q]);
     }
-    for (; r < r1; r += 4) {
-      float v0[4];
+    for (; r < r1; r += CS_WAVES) {
+      float v0[VEC];
       ld(r, v0);
-      a0 += v0[0]; a1 += v0[1]; a2 += v0[2]; a3 += v0[3];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) a[q] += v0[q];
     }
   }
-  red[wave][lane * 4 + 0] = a0;
-  red[wave][lane * 4 + 1] = a1;
-  red[wave][lane * 4 + 2] = a2;
-  red[wave][lane * 4 + 3] = a3;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) red[wave][lane * VEC + q] = a[q];
   __syncthreads();
-  const int cc = blockIdx.x * CS_COLS + threadIdx.x;
-  if (cc < C)
-    partial[(int64_t)blockIdx.y * C + cc] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if ((int)threadIdx.x < SLAB) {
+    const int cc = blockIdx.x * SLAB + threadIdx.x;
+    if (cc < C) {
+      float s4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        s4[g] = (red[4 * g][threadIdx.x] + red[4 * g + 1][threadIdx.x]) + (red[4 * g + 2][threadIdx.x] + red[4 * g + 3][threadIdx.x]);
+      partial[(int64_t)blockIdx.y * C + cc] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+  }
 }
 
+// one workgroup per (64-column slab, group): wave w adds the group's chunks w, w+4, ... (lane = column; two chains), the four meet in LDS
 __global__ __launch_bounds__(256) void group_colsum_final_kernel(const float* __restrict__ partial,
                                                                  const int32_t* __restrict__ offsets, int C,
                                                                  float* __restrict__ out) {
-  const int e = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[4][64];
+  const int e = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   int base = 0;
   for (int q = 0; q < e; ++q) base += (offsets[q + 1] - offsets[q] + CS_ROWS - 1) / CS_ROWS;
   const int nc = (offsets[e + 1] - offsets[e] + CS_ROWS - 1) / CS_ROWS;
-  float acc = 0.f;
-  for (int k = 0; k < nc; ++k) acc += partial[(int64_t)(base + k) * C + c];
-  out[(int64_t)e * C + c] = acc;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < C) {
+    int k = wave;
+    for (; k + 4 < nc; k += 8) {
+      a0 += partial[(int64_t)(base + k) * C + c];
+      a1 += partial[(int64_t)(base + k + 4) * C + c];
+    }
+    if (k < nc) a0 += partial[(int64_t)(base + k) * C + c];
+  }
+  red[wave][lane] = a0 + a1;
+  __syncthreads();
+  if (wave == 0 && c < C) out[(int64_t)e * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // Router weight gradient dWg[e, c] = sum_t dl[t, e] * x[t, c]: a [E x T] x [T x d] product whose output is tiny (E <= 16
@@ -256,7 +349,8 @@ constexpr int GW_ROWS = 256;  // rows per chunk: ~600 workgroups at T = 50k, all
 
 template <typename T, int EB>
 __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const float* __restrict__ dl, const T* __restrict__ x,
-                                                                 int64_t n_rows, int E, int C, float* __restrict__ partial) {
+                                                                 int64_t n_rows, int E, int C, float* __restrict__ partial,
+                                                                 float* __restrict__ bias_partial) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);  // [4 waves][EB][CS_COLS]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -264,14 +358,17 @@ __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const float* __
   const int64_t r0 = (int64_t)blockIdx.y * GW_ROWS;
   const int64_t r1 = r0 + GW_ROWS < n_rows ? r0 + GW_ROWS : n_rows;
   float acc[EB][4];
+  float bacc[EB];   // the bias gradient dbg[e] = sum_t dl[t, e] (x's "ones column"): the first slab's workgroups carry it
+  const bool with_bias = bias_partial != nullptr && blockIdx.x == 0;
 #pragma unroll
-  for (int e = 0; e < EB; ++e) acc[e][0] = acc[e][1] = acc[e][2] = acc[e][3] = 0.f;
+  for (int e = 0; e < EB; ++e) acc[e][0] = acc[e][1] = acc[e][2] = acc[e][3] = bacc[e] = 0.f;
   if (c < C) {
     auto row = [&](int64_t r, const float (&v)[4]) {
       const float* g = dl + r * E;
 #pragma unroll
       for (int e = 0; e < EB; ++e) {
         const float w = e < E ? g[e] : 0.f;
+        if (with_bias) bacc[e] += w;
         acc[e][0] = fmaf(w, v[0], acc[e][0]);
         acc[e][1] = fmaf(w, v[1], acc[e][1]);
         acc[e][2] = fmaf(w, v[2], acc[e][2]);
@@ -306,14 +403,33 @@ __global__ __launch_bounds__(256) void gate_wgrad_partial_kernel(const float* __
       partial[((int64_t)blockIdx.y * E + e) * C + cc] = s01 + s23;
     }
   }
+  if (with_bias) {   // block-uniform; lane 0 of a wave saw every row its wave handled (the slab's first columns: c < C holds)
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int e = 0; e < EB; ++e) red[wave * EB + e] = bacc[e];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < E)
+      bias_partial[(int64_t)blockIdx.y * E + threadIdx.x] =
+          (red[0 * EB + threadIdx.x] + red[1 * EB + threadIdx.x]) + (red[2 * EB + threadIdx.x] + red[3 * EB + threadIdx.x]);
+  }
 }
 
 // one workgroup per (64-column slab, expert): wave w adds chunks w, w+4, ... (lane = column), the four meet in LDS
 __global__ __launch_bounds__(256) void gate_wgrad_final_kernel(const float* __restrict__ partial, int n_chunks, int E, int C,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, const float* __restrict__ bias_partial,
+                                                               float* __restrict__ bias_out) {
   __shared__ float red[4][64];
   const int e = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  if (bias_out && blockIdx.x == gridDim.x - 1 && wave == 3) {   // the bias column: lane l adds chunks l, l + 64, ..., then a fixed tree
+    float b = 0.f;
+    for (int k = lane; k < n_chunks; k += 64) b += bias_partial[(int64_t)k * E + e];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) b += __shfl_xor(b, m, 64);
+    if (lane == 0) bias_out[e] = b;
+  }
   float a0 = 0.f, a1 = 0.f;
   if (c < C) {
     int k = wave;
@@ -417,10 +533,17 @@ extern "C" int smoe_group_colsum(const void* src, int dtype, const int32_t* offs
   const int64_t chunks = colsum_chunks(n_rows_max, E);
   SMOE_REQUIRE(chunks <= 65535, "smoe_group_colsum: too many rows (%lld)", (long long)n_rows_max);
   float* partial = reinterpret_cast<float*>(workspace);
-  dim3 grid1((C + CS_COLS - 1) / CS_COLS, (unsigned)chunks), grid2((C + 255) / 256, E);
+  const bool wide = dtype != SMOE_F32 && C % 8 == 0;     // 16-byte loads: 8 elements of a 16-bit row
+  const int slab = 64 * (wide ? 8 : 4);
+  dim3 grid1((C + slab - 1) / slab, (unsigned)chunks), grid2((C + 63) / 64, E);
   return by_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
-    hipLaunchKernelGGL((group_colsum_partial_kernel<T>), grid1, dim3(256), 0, s, (const T*)src, offsets, E, C, partial);
+    if constexpr (std::is_same<T, float>::value) {
+      hipLaunchKernelGGL((group_colsum_partial_kernel<T, 4>), grid1, dim3(64 * CS_WAVES), 0, s, (const T*)src, offsets, E, C, partial);
+    } else {
+      if (wide) hipLaunchKernelGGL((group_colsum_partial_kernel<T, 8>), grid1, dim3(64 * CS_WAVES), 0, s, (const T*)src, offsets, E, C, partial);
+      else hipLaunchKernelGGL((group_colsum_partial_kernel<T, 4>), grid1, dim3(64 * CS_WAVES), 0, s, (const T*)src, offsets, E, C, partial);
+    }
     SMOE_CHECK_LAUNCH("smoe_group_colsum/partial");
     hipLaunchKernelGGL(group_colsum_final_kernel, grid2, dim3(256), 0, s, partial, offsets, C, out);
     SMOE_CHECK_LAUNCH("smoe_group_colsum/final");
@@ -430,17 +553,19 @@ extern "C" int smoe_group_colsum(const void* src, int dtype, const int32_t* offs
 
 extern "C" size_t smoe_gate_wgrad_workspace_bytes(int64_t n_rows, int E, int C) {
   if (n_rows < 0 || E < 1 || C < 1) return 0;
-  return (size_t)((n_rows + GW_ROWS - 1) / GW_ROWS) * (size_t)E * (size_t)C * 4;
+  return (size_t)((n_rows + GW_ROWS - 1) / GW_ROWS) * (size_t)E * ((size_t)C + 1) * 4;   // + the bias column's partials
 }
 
 // dWg [E, C] (f32) = dl^T x for dl [n_rows, E] f32 and x [n_rows, C] (f32 / f16 / bf16); E <= 16, C % 4 == 0.
-extern "C" int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int64_t n_rows, int E, int C, float* out,
+// db (optional, f32 [E]) = column sums of dl (the gate bias' gradient) from the same pass.
+extern "C" int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int64_t n_rows, int E, int C, float* out, float* db,
                                void* workspace, size_t workspace_bytes, void* stream) {
   SMOE_REQUIRE(out && E >= 1 && E <= GW_MAX_E && C > 0 && C % 4 == 0 && n_rows >= 0, "smoe_gate_wgrad: bad arguments (E <= %d, C %% 4 == 0)", GW_MAX_E);
   hipStream_t s = (hipStream_t)stream;
   if (n_rows == 0) {
     hipError_t me = smoe_zero_words(out, (int64_t)E * C, s);
-    SMOE_REQUIRE(me == hipSuccess, "smoe_gate_wgrad: counter clear failed");
+    if (me == hipSuccess && db) me = smoe_zero_words(db, E, s);
+    SMOE_REQUIRE(me == hipSuccess, "smoe_gate_wgrad: clear failed");
     return 0;
   }
   SMOE_REQUIRE(dl && x, "smoe_gate_wgrad: null pointer");
@@ -448,21 +573,47 @@ extern "C" int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int6
   const int64_t chunks = (n_rows + GW_ROWS - 1) / GW_ROWS;
   SMOE_REQUIRE(chunks <= 65535, "smoe_gate_wgrad: too many rows (%lld)", (long long)n_rows);
   float* partial = reinterpret_cast<float*>(workspace);
+  float* bpart = db ? partial + (size_t)chunks * E * C : nullptr;
   dim3 grid1((C + CS_COLS - 1) / CS_COLS, (unsigned)chunks), grid2((C + 63) / 64, E);
   return by_dtype(x_dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
     if (E <= 8) {
-      hipLaunchKernelGGL((gate_wgrad_partial_kernel<T, 8>), grid1, dim3(256), (size_t)4 * 8 * CS_COLS * 4, s, dl, (const T*)x, n_rows, E, C, partial);
+      hipLaunchKernelGGL((gate_wgrad_partial_kernel<T, 8>), grid1, dim3(256), (size_t)4 * 8 * CS_COLS * 4, s, dl, (const T*)x, n_rows, E, C, partial, bpart);
     } else {
       auto kern = gate_wgrad_partial_kernel<T, 16>;
       SMOE_ENSURE_SMEM(gate_wgrad_partial_kernel<T, 16>);
-      hipLaunchKernelGGL(kern, grid1, dim3(256), (size_t)4 * 16 * CS_COLS * 4, s, dl, (const T*)x, n_rows, E, C, partial);
+      hipLaunchKernelGGL(kern, grid1, dim3(256), (size_t)4 * 16 * CS_COLS * 4, s, dl, (const T*)x, n_rows, E, C, partial, bpart);
     }
     SMOE_CHECK_LAUNCH("smoe_gate_wgrad/partial");
-    hipLaunchKernelGGL(gate_wgrad_final_kernel, grid2, dim3(256), 0, s, partial, (int)chunks, E, C, out);
+    hipLaunchKernelGGL(gate_wgrad_final_kernel, grid2, dim3(256), 0, s, partial, (int)chunks, E, C, out, bpart, db);
     SMOE_CHECK_LAUNCH("smoe_gate_wgrad/final");
     return 0;
   });
+}
+
+extern "C" size_t smoe_switch_aux_workspace_bytes(int64_t T, int E) {
+  if (T < 0 || E < 1) return 0;
+  return (size_t)((T + SA_ROWS - 1) / SA_ROWS + 1) * (size_t)E * 4;
+}
+
+// SwitchGate load-balance loss: aux [1] = E sum_e (counts[e] / kept) (sum_t probs[t, e] / kept), coef [E] = E counts[e] / kept^2
+// (kept = max(sum counts, 1)); probs f32 [T, E], counts i32 [E] (the dispatch plan's kept counts); E <= 256.
+extern "C" int smoe_switch_aux(const float* probs, const int32_t* counts, int64_t T, int E, float* aux, float* coef,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  SMOE_REQUIRE(T >= 0 && E >= 1 && E <= SA_MAX_E, "smoe_switch_aux: bad sizes T=%lld E=%d (E <= %d)", (long long)T, E, SA_MAX_E);
+  SMOE_REQUIRE(counts && aux && coef && (T == 0 || probs), "smoe_switch_aux: null pointer");
+  SMOE_REQUIRE(workspace && workspace_bytes >= smoe_switch_aux_workspace_bytes(T, E), "smoe_switch_aux: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t chunks = (T + SA_ROWS - 1) / SA_ROWS;
+  SMOE_REQUIRE(chunks <= (1 << 24), "smoe_switch_aux: too many rows");
+  float* partial = reinterpret_cast<float*>(workspace);
+  if (chunks > 0) {
+    hipLaunchKernelGGL(switch_aux_partial_kernel, dim3((unsigned)chunks), dim3(256), 0, s, probs, T, E, partial);
+    SMOE_CHECK_LAUNCH("smoe_switch_aux/partial");
+  }
+  hipLaunchKernelGGL(switch_aux_final_kernel, dim3(1), dim3(256), 0, s, partial, (int)chunks, counts, E, aux, coef);
+  SMOE_CHECK_LAUNCH("smoe_switch_aux/final");
+  return 0;
 }
 
 template <typename ST>
@@ -490,13 +641,13 @@ extern "C" int smoe_transpose_cast(const void* src, int src_dtype, void* dst, in
   }
 }
 
-extern "C" int smoe_switch_gate_bwd(const float* probs, const int64_t* idx, const float* dscore, const float* coef, int64_t T, int E,
-                                    float* dlogits, void* stream) {
+extern "C" int smoe_switch_gate_bwd(const float* probs, const int64_t* idx, const float* dscore, const float* coef,
+                                    const float* coef_scale, int64_t T, int E, float* dlogits, void* stream) {
   SMOE_REQUIRE(T >= 0 && E >= 1 && E <= 4096, "smoe_switch_gate_bwd: bad sizes T=%lld E=%d", (long long)T, E);
   if (T == 0) return 0;
   SMOE_REQUIRE(probs && idx && dlogits, "smoe_switch_gate_bwd: null pointer");
   hipLaunchKernelGGL(switch_gate_bwd_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, (hipStream_t)stream, probs, idx, dscore,
-                     coef, T, E, dlogits);
+                     coef, coef_scale, T, E, dlogits);
   SMOE_CHECK_LAUNCH("smoe_switch_gate_bwd");
   return 0;
 }

@@ -236,15 +236,21 @@ __global__ void plan_tail_kernel(const int32_t* __restrict__ offsets, int E, int
 template <typename XT, typename BT>
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const XT* __restrict__ x, const int64_t* __restrict__ pos,
                                                            const float* __restrict__ scale, int64_t n_slots, int k, int d,
-                                                           BT* __restrict__ buf) {
+                                                           BT* __restrict__ buf, int zero_unmapped) {
   const int lane = threadIdx.x & 63;
   const int64_t wave_gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t s = wave_gid; s < n_slots; s += nwaves) {
     const int64_t p = pos[s];
-    if (p < 0) continue;  // wave-uniform
-    const XT* src = x + (p / k) * (int64_t)d;
     BT* dst = buf + s * (int64_t)d;
+    if (p < 0) {  // wave-uniform: a slot no token maps to (past the kept count) -- left alone, or cleared in the same pass
+      if (zero_unmapped) {
+        float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = lane * 8; c < d; c += 512) store8(dst + c, z);
+      }
+      continue;
+    }
+    const XT* src = x + (p / k) * (int64_t)d;
     const float sc = scale ? scale[p] : 1.0f;
     for (int c = lane * 8; c < d; c += 512) {
       float v[8];
@@ -410,17 +416,17 @@ inline int rows_grid(int64_t rows) {
 
 template <typename XT>
 int scatter_dispatch_b(const void* x, const int64_t* pos, const float* scale, int64_t n_slots, int k, int d, void* buf,
-                       int buf_dtype, hipStream_t s) {
+                       int buf_dtype, int zero_unmapped, hipStream_t s) {
   const int grid = rows_grid(n_slots);
   switch (buf_dtype) {
     case SMOE_F32:
-      hipLaunchKernelGGL((scatter_rows_kernel<XT, float>), dim3(grid), dim3(256), 0, s, (const XT*)x, pos, scale, n_slots, k, d, (float*)buf);
+      hipLaunchKernelGGL((scatter_rows_kernel<XT, float>), dim3(grid), dim3(256), 0, s, (const XT*)x, pos, scale, n_slots, k, d, (float*)buf, zero_unmapped);
       break;
     case SMOE_F16:
-      hipLaunchKernelGGL((scatter_rows_kernel<XT, f16>), dim3(grid), dim3(256), 0, s, (const XT*)x, pos, scale, n_slots, k, d, (f16*)buf);
+      hipLaunchKernelGGL((scatter_rows_kernel<XT, f16>), dim3(grid), dim3(256), 0, s, (const XT*)x, pos, scale, n_slots, k, d, (f16*)buf, zero_unmapped);
       break;
     case SMOE_BF16:
-      hipLaunchKernelGGL((scatter_rows_kernel<XT, bf16_bits>), dim3(grid), dim3(256), 0, s, (const XT*)x, pos, scale, n_slots, k, d, (bf16_bits*)buf);
+      hipLaunchKernelGGL((scatter_rows_kernel<XT, bf16_bits>), dim3(grid), dim3(256), 0, s, (const XT*)x, pos, scale, n_slots, k, d, (bf16_bits*)buf, zero_unmapped);
       break;
     default:
       smoe_set_error("smoe_scatter_rows: bad buf_dtype %d", buf_dtype);
@@ -563,20 +569,31 @@ extern "C" int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, i
                    slot_rows, group_end);
 }
 
-extern "C" int smoe_scatter_rows(const void* x, int x_dtype, const int64_t* pos, const float* scale, int64_t n_slots,
-                                 int k, int d, void* buf, int buf_dtype, void* stream) {
+static int scatter_rows_impl(const void* x, int x_dtype, const int64_t* pos, const float* scale, int64_t n_slots,
+                             int k, int d, void* buf, int buf_dtype, int zero_unmapped, void* stream) {
   SMOE_REQUIRE(n_slots >= 0 && k >= 1 && d > 0 && d % 8 == 0, "smoe_scatter_rows: bad sizes n_slots=%lld k=%d d=%d",
                (long long)n_slots, k, d);
   if (n_slots == 0) return 0;
   SMOE_REQUIRE(x && pos && buf, "smoe_scatter_rows: null pointer");
   hipStream_t s = (hipStream_t)stream;
   switch (x_dtype) {
-    case SMOE_F32: return scatter_dispatch_b<float>(x, pos, scale, n_slots, k, d, buf, buf_dtype, s);
-    case SMOE_F16: return scatter_dispatch_b<f16>(x, pos, scale, n_slots, k, d, buf, buf_dtype, s);
-    case SMOE_BF16: return scatter_dispatch_b<bf16_bits>(x, pos, scale, n_slots, k, d, buf, buf_dtype, s);
+    case SMOE_F32: return scatter_dispatch_b<float>(x, pos, scale, n_slots, k, d, buf, buf_dtype, zero_unmapped, s);
+    case SMOE_F16: return scatter_dispatch_b<f16>(x, pos, scale, n_slots, k, d, buf, buf_dtype, zero_unmapped, s);
+    case SMOE_BF16: return scatter_dispatch_b<bf16_bits>(x, pos, scale, n_slots, k, d, buf, buf_dtype, zero_unmapped, s);
   }
   smoe_set_error("smoe_scatter_rows: bad x_dtype %d", x_dtype);
   return 1;
+}
+
+extern "C" int smoe_scatter_rows(const void* x, int x_dtype, const int64_t* pos, const float* scale, int64_t n_slots,
+                                 int k, int d, void* buf, int buf_dtype, void* stream) {
+  return scatter_rows_impl(x, x_dtype, pos, scale, n_slots, k, d, buf, buf_dtype, 0, stream);
+}
+
+// the same, and slots with pos[s] < 0 (no token: past the kept count under a capacity) are written as zero rows in the same pass
+extern "C" int smoe_scatter_rows_fill(const void* x, int x_dtype, const int64_t* pos, const float* scale, int64_t n_slots,
+                                      int k, int d, void* buf, int buf_dtype, void* stream) {
+  return scatter_rows_impl(x, x_dtype, pos, scale, n_slots, k, d, buf, buf_dtype, 1, stream);
 }
 
 extern "C" int smoe_gather_combine(const void* y, int y_dtype, const int64_t* inv_pos, const float* score, int64_t T,

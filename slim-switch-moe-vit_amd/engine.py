@@ -122,10 +122,9 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
             outputs = model(samples)
             loss = criterion(samples, outputs, targets) if with_inputs else criterion(outputs, targets)
             if aux_loss_weight:
-                for m in moes:
-                    aux = m.gate.get_loss()
-                    if aux is not None:
-                        loss = loss + aux_loss_weight * aux
+                auxes = [a for a in (m.gate.get_loss() for m in moes) if a is not None]
+                if auxes:     # one stack + sum instead of two tiny kernels (and two backward nodes) per layer
+                    loss = loss + aux_loss_weight * torch.stack([a.reshape(()) for a in auxes]).sum()
         lv = loss.detach().float()
         finite = torch.isfinite(lv)
         if every_step and not bool(finite):           # the reference's order: abort before the step and the EMA update

@@ -125,8 +125,8 @@ class SwitchGate(NaiveGate):
     def make_noise(self, T: int, device) -> Optional[torch.Tensor]:
         if not self.training or self.switch_eps <= 0:
             return None
-        # upstream adds U[0,1) * 2*eps + (1 - eps) to the logits
-        return torch.rand(T, self.tot_expert, device=device) * (2 * self.switch_eps) + (1.0 - self.switch_eps)
+        # upstream adds U[0,1) * 2*eps + (1 - eps) to the logits: one generator kernel (uniform_ applies the affine map itself)
+        return torch.empty(T, self.tot_expert, device=device).uniform_(1.0 - self.switch_eps, 1.0 + self.switch_eps)
 
 
 class _Expert(nn.Module):

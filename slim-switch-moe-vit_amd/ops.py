@@ -492,13 +492,13 @@ def scatter_rows(x: torch.Tensor, pos: torch.Tensor, k: int, out_dtype: torch.dt
                  out: Optional[torch.Tensor] = None, zero_fill: bool = False,
                  scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """buf[s] = cast(x[pos[s] // k]) (* scale[pos[s]]) for every slot with pos[s] >= 0 (MOEScatter local part;
-    with ``scale`` = the adjoint of the combine)."""
+    with ``scale`` = the adjoint of the combine); ``zero_fill``: the other slots become zero rows (also of a given ``out``)."""
     _chk(x, "x", ndim=2)
     _chk(pos, "pos", torch.int64, 1, align=8)
     n_slots = pos.numel()
     d = x.shape[1]
     if out is None:
-        out = (torch.zeros if zero_fill else torch.empty)((n_slots, d), dtype=out_dtype, device=x.device)
+        out = torch.empty((n_slots, d), dtype=out_dtype, device=x.device)
     else:
         _chk(out, "out", out_dtype, 2)
     if scale is not None:
@@ -506,9 +506,10 @@ def scatter_rows(x: torch.Tensor, pos: torch.Tensor, k: int, out_dtype: torch.dt
         if scale.numel() != x.shape[0] * k:
             raise RuntimeError("scale: expected T*k entries")
     lib = _lib.load()
+    # zero_fill: slots no token maps to (pos < 0) are written as zero rows by the same pass, not by a memset of the whole buffer
+    fn = lib.smoe_scatter_rows_fill if zero_fill else lib.smoe_scatter_rows
     with _timed("scatter", {"bytes": n_slots * d * (x.element_size() + out.element_size())}, x):
-        rc = lib.smoe_scatter_rows(_ptr(x), dtype_code(x.dtype), _ptr(pos), _ptr(scale), n_slots, k, d, _ptr(out),
-                                   dtype_code(out.dtype), _stream(x))
+        rc = fn(_ptr(x), dtype_code(x.dtype), _ptr(pos), _ptr(scale), n_slots, k, d, _ptr(out), dtype_code(out.dtype), _stream(x))
     _lib.check(rc, "smoe_scatter_rows")
     return out
 
@@ -785,9 +786,27 @@ def rowdot(dout: torch.Tensor, y: torch.Tensor, inv_pos: torch.Tensor, k: int) -
     return out
 
 
-def switch_gate_bwd(probs: torch.Tensor, idx: torch.Tensor, dscore: Optional[torch.Tensor], coef: Optional[torch.Tensor]) -> torch.Tensor:
+def switch_aux(probs: torch.Tensor, counts: torch.Tensor):
+    """(aux f32 [] , coef f32 [E]): the SwitchGate's load-balance loss E sum_e frac_e prob_e from the router's probabilities [T, E] and
+    the plan's kept counts (i32 [E]), and d aux / d probs[t, e] = E frac_e / kept -- two launches, no host-launched [E]-sized ops."""
+    _chk(probs, "probs", torch.float32, 2, align=4)
+    _chk(counts, "counts", torch.int32, 1)
+    T, E = probs.shape
+    if counts.numel() != E:
+        raise RuntimeError("switch_aux: one count per expert")
+    lib = _lib.load()
+    out = torch.empty(E + 1, dtype=torch.float32, device=probs.device)
+    ws_bytes = lib.smoe_switch_aux_workspace_bytes(T, E)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=probs.device)
+    rc = lib.smoe_switch_aux(_ptr(probs), _ptr(counts), T, E, _ptr(out), out.data_ptr() + 4, _ptr(ws), ws_bytes, _stream(probs))
+    _lib.check(rc, "smoe_switch_aux")
+    return out[0], out[1:]
+
+
+def switch_gate_bwd(probs: torch.Tensor, idx: torch.Tensor, dscore: Optional[torch.Tensor], coef: Optional[torch.Tensor],
+                    coef_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dlogits [T, E] of the SwitchGate's score (= probs[t, idx[t]]) and load-balance loss in one pass (softmax backward of
-    g[t, e] = coef[e] + (e == idx[t]) dscore[t])."""
+    g[t, e] = coef[e] * coef_scale + (e == idx[t]) dscore[t]); ``coef_scale``: a one-element f32 device tensor (d loss / d aux)."""
     _chk(probs, "probs", torch.float32, 2, align=4)
     T, E = probs.shape
     _chk(idx, "idx", torch.int64, align=8)
@@ -797,8 +816,11 @@ def switch_gate_bwd(probs: torch.Tensor, idx: torch.Tensor, dscore: Optional[tor
         _chk(dscore, "dscore", torch.float32, align=4)
     if coef is not None:
         _chk(coef, "coef", torch.float32, 1, align=4)
+    if coef_scale is not None:
+        _chk(coef_scale, "coef_scale", torch.float32, align=4)
     out = torch.empty_like(probs)
-    rc = _lib.load().smoe_switch_gate_bwd(_ptr(probs), _ptr(idx), _ptr(dscore), _ptr(coef), T, E, _ptr(out), _stream(probs))
+    rc = _lib.load().smoe_switch_gate_bwd(_ptr(probs), _ptr(idx), _ptr(dscore), _ptr(coef), _ptr(coef_scale), T, E, _ptr(out),
+                                          _stream(probs))
     _lib.check(rc, "smoe_switch_gate_bwd")
     return out
 
@@ -847,6 +869,20 @@ def grouped_wgrad(PT: torch.Tensor, QT: torch.Tensor, offsets_pad: torch.Tensor)
 _zero_pages = StreamCache()
 
 
+_ones_cache = {}
+
+
+def ones_f32(n: int, device) -> torch.Tensor:
+    """A cached f32 vector of ones (read-only: unit combine weights of the scatter's adjoint) -- not a fill kernel per backward."""
+    key = (torch.device(device).index, int(n))
+    t = _ones_cache.get(key)
+    if t is None:
+        if len(_ones_cache) > 64:
+            _ones_cache.clear()
+        t = _ones_cache[key] = torch.ones(int(n), dtype=torch.float32, device=device)
+    return t
+
+
 def _zero16(device) -> torch.Tensor:
     return _zero_pages.get(str(device), 0, lambda: torch.zeros(64, dtype=torch.uint8, device=device))
 
@@ -887,8 +923,9 @@ def grouped_wgrad_rows(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor, 
     return out
 
 
-def gate_wgrad(dl: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dWg [E, d] f32 = dl^T x for dl [T, E] f32, x [T, d]: the router weight gradient as a streaming reduction."""
+def gate_wgrad(dl: torch.Tensor, x: torch.Tensor, want_bias: bool = False):
+    """dWg [E, d] f32 = dl^T x for dl [T, E] f32, x [T, d]: the router weight gradient as a streaming reduction.
+    ``want_bias``: returns (dWg, dbg [E] = column sums of dl) from the same pass."""
     _chk(dl, "dl", torch.float32, 2, align=4)
     _chk(x, "x", ndim=2)
     T, E = dl.shape
@@ -897,11 +934,12 @@ def gate_wgrad(dl: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
         raise RuntimeError("gate_wgrad: row counts differ")
     lib = _lib.load()
     out = torch.empty((E, C), dtype=torch.float32, device=x.device)
+    db = torch.empty(E, dtype=torch.float32, device=x.device) if want_bias else None
     ws_bytes = lib.smoe_gate_wgrad_workspace_bytes(T, E, C)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-    rc = lib.smoe_gate_wgrad(_ptr(dl), _ptr(x), dtype_code(x.dtype), T, E, C, _ptr(out), _ptr(ws), ws_bytes, _stream(x))
+    rc = lib.smoe_gate_wgrad(_ptr(dl), _ptr(x), dtype_code(x.dtype), T, E, C, _ptr(out), _ptr(db), _ptr(ws), ws_bytes, _stream(x))
     _lib.check(rc, "smoe_gate_wgrad")
-    return out
+    return (out, db) if want_bias else out
 
 
 def gate_dgrad(dl: torch.Tensor, w: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:

@@ -124,7 +124,13 @@ class _HalfCache(StreamCache):
         return super().get(("ident", rows, str(device)), 0, lambda: torch.arange(rows, dtype=torch.int64, device=device))
 
     def get(self, p: torch.Tensor) -> torch.Tensor:  # noqa: D102
-        return super().get(id(p), param_version(p), lambda: p.detach().half())
+        def make():
+            q = p.detach()
+            if q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.numel() % 8 == 0:
+                from . import ops
+                return ops.cast(q, torch.float16)
+            return q.half()
+        return super().get(id(p), param_version(p), make)
 
     def get_padded(self, p: torch.Tensor, rows: int, dtype) -> torch.Tensor:
         """``p`` (a weight [N, K] or a bias [N]) in ``dtype`` with zero rows appended up to ``rows`` (a classifier head whose

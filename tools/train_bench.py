@@ -85,10 +85,9 @@ else:
         with torch.autocast("cuda", dtype=torch.float16):
             out = model(x)
             loss = crit(out, y)
-            for m in moes:
-                aux = m.gate.get_loss()
-                if aux is not None:
-                    loss = loss + 0.01 * aux
+            auxes = [a for a in (m.gate.get_loss() for m in moes) if a is not None]
+            if auxes:
+                loss = loss + 0.01 * torch.stack([a.reshape(()) for a in auxes]).sum()
         opt.zero_grad()
         scaler(loss, opt, clip_grad=1.0, parameters=model.parameters())
 
@@ -98,3 +97,23 @@ else:
     if gates:
         extra = f"; skipped tokens {sum(gt._skipped_tokens for gt in gates) / max(1, sum(gt._total_tokens for gt in gates)):.2f}"
     print(f"{name} train step (fwd + bwd + clip + AdamW), batch {images}: {t:.2f} ms = {images / t * 1e3:.0f} images/s{extra}", flush=True)
+
+    if os.environ.get("TRAIN_BENCH_TRACE"):
+        # which host call starts each torch (non-library) kernel of the step: aten op, input shapes, innermost package frames
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+            train_step()
+            torch.cuda.synchronize()
+        rows = {}
+        for ev in prof.events():
+            if not ev.name.startswith("aten::") or not ev.kernels:
+                continue
+            dt = sum(k.duration for k in ev.kernels)
+            frames = [f for f in (ev.stack or []) if "slim" in f or "tools/" in f][:3]
+            key = (ev.name, str(ev.input_shapes)[:90], " <- ".join(f.split("/")[-1][:60] for f in frames))
+            r = rows.setdefault(key, [0, 0.0, ev.kernels[0].name[:70]])
+            r[0] += 1
+            r[1] += dt
+        print("torch ops that launch kernels in ONE step (calls, us total, op, shapes, frames, first kernel):")
+        for key, r in sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]:
+            print(f"{r[0]:4d} {r[1]:9.1f}  {key[0]:28s} {key[1]:90s} {key[2]} [{r[2]}]", flush=True)
