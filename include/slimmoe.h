@@ -331,6 +331,14 @@ int smoe_grouped_wgrad_rows(const void* P, const void* Q, int ab_dtype, const in
 size_t smoe_gate_wgrad_workspace_bytes(int64_t n_rows, int E, int C);
 int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int64_t n_rows, int E, int C, float* out, float* db,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* smoe_zero_group_fold: the training path's zero-row groups (tokens the token-skip gate masked, models/resMoE.py:141 `x * mask`: all-zero
+ * rows, every one routed by the gate bias alone to expert gmap[E + j]) need no weight-gradient GEMM: group E + j adds the rank-1 term
+ * colsum(dY_g) (x) A_row to dW2[gmap[E + j]] (the rows of A = gelu(b1[e]) are identical), and an expert's bias gradients are the column sums
+ * of its own group plus those of the zero groups that use it.  cs2 f32 [E + Z, d], cs1 f32 [E + Z, h] = smoe_group_colsum of dY / dH over
+ * all E + Z groups; A [n_rows, h] f16 / bf16 / f32; offsets i32 [E + Z + 1]; gmap i32 [E + Z]; dW2 f32 [E, d, h] updated IN PLACE;
+ * db2 f32 [E, d], db1 f32 [E, h] written (either may be NULL).  h % 4 == 0.  Groups are folded in index order.                        */
+int smoe_zero_group_fold(const float* cs2, const float* cs1, const void* A, int a_dtype, const int32_t* offsets, const int32_t* gmap,
+                         int E, int Z, int d, int h, int64_t n_rows, float* dW2, float* db2, float* db1, void* stream);
 size_t smoe_group_colsum_workspace_bytes(int64_t n_rows_max, int E, int C);
 int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int64_t n_rows_max, int C, float* out,
                       void* workspace, size_t workspace_bytes, void* stream);

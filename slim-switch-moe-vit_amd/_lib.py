@@ -40,6 +40,8 @@ SIGNATURES = {
     "smoe_grouped_gemm_gelu_keep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int,
                                             c_void_p, c_void_p, c_void_p]),
     "smoe_switch_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "smoe_zero_group_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_switch_aux_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "smoe_switch_aux": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -65,6 +65,7 @@ class _GateScatter(torch.autograd.Function):
     def forward(ctx, x, w, b, logits, pos, inv_pos, k, cd):
         ctx.k, ctx.has_b = k, b is not None
         ctx.save_for_backward(x, w, inv_pos)
+        ctx.set_materialize_grads(False)
         return logits.view_as(logits), ops.scatter_rows(x, pos, k, cd, zero_fill=True)
 
     @staticmethod
@@ -193,13 +194,9 @@ class _GroupFFN(torch.autograd.Function):
             dW2 = ops.grouped_wgrad_rows(dY, A, offs_e)
             dW1 = ops.grouped_wgrad_rows(dH, rows, offs_e)
             cs2 = ops.group_colsum(dY, offsets)                       # [G, d]
-            cs1 = ops.group_colsum(dH, offsets)                       # [G, h]
-            tgt = gmap[E:].long()                                     # experts of the zero-row groups (device; no host read)
-            first = offsets[E:G].long().clamp(max=max(n - 1, 0))      # a row of each zero group (an empty group's sum is 0 anyway)
-            a_rows = A.index_select(0, first).float()                 # [Z, h]
-            dW2.index_add_(0, tgt, cs2[E:, :, None] * a_rows[:, None, :])
-            db2 = cs2[:E].index_add(0, tgt, cs2[E:]) if ctx.has_b2 else None
-            db1 = cs1[:E].index_add(0, tgt, cs1[E:]) if ctx.has_b1 else None
+            cs1 = ops.group_colsum(dH, offsets) if ctx.has_b1 else None   # [G, h]
+            # rank-1 terms into dW2 (in place) and the experts' bias gradients, one launch (smoe_zero_group_fold)
+            db2, db1 = ops.zero_group_fold(cs2, cs1, A, offsets, gmap, E, dW2, want_b2=ctx.has_b2, want_b1=ctx.has_b1)
             G = E
         else:
             dW2 = ops.grouped_wgrad_rows(dY, A, offsets)
@@ -264,20 +261,23 @@ class _SwitchScoreAux(torch.autograd.Function):
         # aux and cbase[e] = E frac_e / kept = d aux / d p[t, e] (the same for every t; dropped tokens count nowhere): smoe_switch_aux
         aux, cbase = ops.switch_aux(probs, counts)
         ctx.save_for_backward(probs, idx, cbase)
+        ctx.set_materialize_grads(False)     # no aux loss in the objective: daux is None, not a zero tensor
         return score.view_as(score), aux
 
     @staticmethod
     def backward(ctx, dscore, daux):
         probs, idx, cbase = ctx.saved_tensors
+        if dscore is None and daux is None:
+            return (None,) * 6
         ds = dscore.reshape(-1).to(torch.float32).contiguous() if dscore is not None else None
         scale = daux.reshape(1).to(torch.float32) if daux is not None else None      # multiplied onto cbase inside the kernel
         return (ops.switch_gate_bwd(probs, idx.reshape(-1), ds, cbase if daux is not None else None, scale),
                 None, None, None, None, None)
 
 
-def _zero_row_routing(mod) -> torch.Tensor:
-    """int64 [k] (device): the experts an all-zero row is routed to (top-k of the gate bias; ties -> lowest id), from the HIP
-    router itself, cached per version of the gate parameters."""
+def _zero_row_routing(mod):
+    """(int64 [k] (device): the experts an all-zero row is routed to (top-k of the gate bias; ties -> lowest id), from the HIP
+    router itself; the group -> expert map i32 [E + k]; the zero groups' ids int64 [1, k]), cached per version of the gate parameters."""
     from ._cache import StreamCache, param_version
     g = mod.gate.gate
     cache = mod.__dict__.get("_zero_route")
@@ -291,7 +291,12 @@ def _zero_row_routing(mod) -> torch.Tensor:
         idx0, _, _, _ = ops.router_topk(z, g.weight.detach().float().contiguous(), g.bias.detach().float() if g.bias is not None else None,
                                         mod.top_k, ops.GATE_NAIVE)
         return idx0.reshape(-1).clone()
-    return cache.get(str(g.weight.device), ver, make)
+    dev = g.weight.device
+    E, k = mod.gate.tot_expert, mod.top_k
+    idx0 = cache.get(("idx0", str(dev)), ver, make)
+    g_map = cache.get(("gmap", str(dev)), ver, lambda: torch.cat((torch.arange(E, device=dev), idx0)).to(torch.int32))
+    zero_ids = cache.get(("zid", str(dev), E, k), 0, lambda: torch.arange(E, E + k, device=dev).reshape(1, k))
+    return idx0, g_map, zero_ids
 
 
 def _route_train(mod, x, zero_rows=None, scatter_cd=None):
@@ -319,10 +324,9 @@ def _route_train(mod, x, zero_rows=None, scatter_cd=None):
         cap = g.capacity(T)
         E = g.tot_expert
         if zero_rows is not None and not is_switch and cap < 0 and E + k <= 63:
-            idx0 = _zero_row_routing(mod)                                                  # [k]: where the bias sends a zero row
-            idx_plan = torch.where(zero_rows.reshape(T, 1), torch.arange(E, E + k, device=x.device).reshape(1, k), idx)
+            _idx0, g_map, zero_ids = _zero_row_routing(mod)                                # (cached per gate-parameter version)
+            idx_plan = torch.where(zero_rows.reshape(T, 1), zero_ids, idx)
             counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx_plan, E + k, cap)
-            g_map = torch.cat((torch.arange(E, device=x.device), idx0)).to(torch.int32)
             zero_groups = k
         else:
             counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx, E, cap)
@@ -364,6 +368,8 @@ def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row
         x = x.contiguous()
     T = x.shape[0]
     ep = mod.world_size > 1 or getattr(mod, "force_ep", False)
+    if mod._drop_p > 0 and mod.training:
+        zero_rows = None      # (the rank-1 form of the zero groups' gradients needs identical activation rows: no dropout behind GELU)
     score, counts, offsets, pos, inv_pos, zmap, zero_groups, S = _route_train(mod, x, None if ep else zero_rows, scatter_cd=cd)
     ex = mod.experts
     if ep:

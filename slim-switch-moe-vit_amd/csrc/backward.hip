@@ -444,6 +444,50 @@ __global__ __launch_bounds__(256) void gate_wgrad_final_kernel(const float* __re
   if (wave == 0 && c < C) out[(int64_t)e * C + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// Zero-row groups of the MoE operator's training path (tokens the skip gate masked: all-zero input rows, every one routed by the
+// gate bias to expert gmap[E + j]; autograd._GroupFFN.backward): their weight gradients need no GEMM.  The rows of A = gelu(b1[e])
+// are identical, so group E + j adds the rank-1 term colsum(dY_g) (x) A_row to dW2[gmap[E + j]]; the bias gradients of an expert
+// are the column sums of its own group plus those of the zero groups that use it.  ONE launch instead of ~12 host-launched
+// [E]-sized ones per layer; groups are folded in index order (deterministic).
+template <typename AT>
+__global__ __launch_bounds__(256) void zero_group_fold_kernel(const float* __restrict__ cs2, const float* __restrict__ cs1,
+                                                              const AT* __restrict__ A, const int32_t* __restrict__ offsets,
+                                                              const int32_t* __restrict__ gmap, int E, int Z, int d, int h,
+                                                              int64_t n_rows, float* __restrict__ dW2, float* __restrict__ db2,
+                                                              float* __restrict__ db1) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_w = (int64_t)d * (h / 4);       // f32x4 pieces of one [d, h] matrix
+  if (gid < per_w) {
+    const int c = (int)(gid / (h / 4)), r = (int)(gid % (h / 4)) * 4;
+    for (int j = 0; j < Z; ++j) {
+      const int e = gmap[E + j];
+      if (e < 0 || e >= E) continue;                 // (caller data)
+      int64_t first = offsets[E + j];
+      if (first >= offsets[E + j + 1]) continue;     // an empty group contributes nothing
+      if (first > n_rows - 1) first = n_rows - 1;
+      float a[4];
+      load4(A + first * h + r, a);
+      const float w = cs2[(int64_t)(E + j) * d + c];
+      f32x4* dst = reinterpret_cast<f32x4*>(dW2 + ((int64_t)e * d + c) * h + r);
+      f32x4 v = *dst;
+      v[0] = fmaf(w, a[0], v[0]); v[1] = fmaf(w, a[1], v[1]); v[2] = fmaf(w, a[2], v[2]); v[3] = fmaf(w, a[3], v[3]);
+      *dst = v;
+    }
+  }
+  const int64_t nb2 = db2 ? (int64_t)E * d : 0, nb1 = db1 ? (int64_t)E * h : 0;
+  if (gid < nb2 + nb1) {
+    const bool two = gid < nb2;
+    const int64_t i = two ? gid : gid - nb2;
+    const int C = two ? d : h;
+    const float* cs = two ? cs2 : cs1;
+    const int e = (int)(i / C), c = (int)(i % C);
+    float acc = cs[(int64_t)e * C + c];
+    for (int j = 0; j < Z; ++j)
+      if (gmap[E + j] == e) acc += cs[(int64_t)(E + j) * C + c];
+    (two ? db2 : db1)[i] = acc;
+  }
+}
+
 template <typename F> int by_dtype(int code, F&& f) {
   switch (code) {
     case SMOE_F32: return f((float*)nullptr);
@@ -587,6 +631,28 @@ extern "C" int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int6
     SMOE_CHECK_LAUNCH("smoe_gate_wgrad/partial");
     hipLaunchKernelGGL(gate_wgrad_final_kernel, grid2, dim3(256), 0, s, partial, (int)chunks, E, C, out, bpart, db);
     SMOE_CHECK_LAUNCH("smoe_gate_wgrad/final");
+    return 0;
+  });
+}
+
+// see zero_group_fold_kernel.  cs2 f32 [E + Z, d], cs1 f32 [E + Z, h] (the column sums of dY / dH over ALL groups), A [n_rows, h]
+// (f16 / bf16 / f32: the kept activations), offsets i32 [E + Z + 1], gmap i32 [E + Z]; dW2 f32 [E, d, h] is updated IN PLACE;
+// db2 f32 [E, d] / db1 f32 [E, h] (either may be NULL; db1 needs cs1) are written.  h % 4 == 0.
+extern "C" int smoe_zero_group_fold(const float* cs2, const float* cs1, const void* A, int a_dtype, const int32_t* offsets,
+                                    const int32_t* gmap, int E, int Z, int d, int h, int64_t n_rows, float* dW2, float* db2,
+                                    float* db1, void* stream) {
+  SMOE_REQUIRE(E >= 1 && Z >= 0 && d > 0 && h > 0 && h % 4 == 0 && n_rows >= 0, "smoe_zero_group_fold: bad sizes");
+  SMOE_REQUIRE(cs2 && offsets && gmap && dW2 && (!db1 || cs1) && (n_rows == 0 || A), "smoe_zero_group_fold: null pointer");
+  if (n_rows == 0) Z = 0;
+  const int64_t work = (int64_t)d * (h / 4) > (int64_t)E * (d + h) ? (int64_t)d * (h / 4) : (int64_t)E * (d + h);
+  const int64_t blocks = (work + 255) / 256;
+  SMOE_REQUIRE(blocks <= 0x7fffffff, "smoe_zero_group_fold: too large");
+  hipStream_t s = (hipStream_t)stream;
+  return by_dtype(a_dtype, [&](auto* tag) {
+    using T = std::remove_pointer_t<decltype(tag)>;
+    hipLaunchKernelGGL((zero_group_fold_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, cs2, cs1, (const T*)A, offsets, gmap, E, Z,
+                       d, h, n_rows, dW2, db2, db1);
+    SMOE_CHECK_LAUNCH("smoe_zero_group_fold");
     return 0;
   });
 }

@@ -956,6 +956,34 @@ def gate_dgrad(dl: torch.Tensor, w: torch.Tensor, out_dtype: torch.dtype) -> tor
     return out
 
 
+def zero_group_fold(cs2: torch.Tensor, cs1: Optional[torch.Tensor], A: torch.Tensor, offsets: torch.Tensor, gmap: torch.Tensor,
+                    E: int, dW2: torch.Tensor, want_b2: bool = True, want_b1: bool = True):
+    """The zero-row groups' share of the expert gradients in one launch (smoe_zero_group_fold): ``dW2`` [E, d, h] gets the rank-1
+    terms colsum(dY_g) (x) A_row IN PLACE; returns (db2 [E, d] | None, db1 [E, h] | None) = own group's column sums + those of the
+    zero groups mapped to the expert.  cs2 [G, d] / cs1 [G, h]: column sums over all G = E + Z groups."""
+    _chk(cs2, "cs2", torch.float32, 2)
+    _chk(A, "A", ndim=2)
+    _chk(offsets, "offsets", torch.int32, 1, align=4)
+    _chk(gmap, "gmap", torch.int32, 1, align=4)
+    _chk(dW2, "dW2", torch.float32, 3)
+    G, d = cs2.shape
+    h = A.shape[1]
+    Z = G - E
+    if Z < 0 or offsets.numel() != G + 1 or gmap.numel() != G or tuple(dW2.shape) != (E, d, h) or h % 4:
+        raise RuntimeError("zero_group_fold: shapes disagree")
+    if cs1 is not None:
+        _chk(cs1, "cs1", torch.float32, 2)
+        if tuple(cs1.shape) != (G, h):
+            raise RuntimeError("zero_group_fold: cs1 must be [G, h]")
+    want_b1 = want_b1 and cs1 is not None
+    db2 = torch.empty((E, d), dtype=torch.float32, device=cs2.device) if want_b2 else None
+    db1 = torch.empty((E, h), dtype=torch.float32, device=cs2.device) if want_b1 else None
+    rc = _lib.load().smoe_zero_group_fold(_ptr(cs2), _ptr(cs1), _ptr(A), dtype_code(A.dtype), _ptr(offsets), _ptr(gmap), E, Z, d, h,
+                                          A.shape[0], _ptr(dW2), _ptr(db2), _ptr(db1), _stream(cs2))
+    _lib.check(rc, "smoe_zero_group_fold")
+    return db2, db1
+
+
 def group_colsum(src: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     """out[e, c] = sum of the rows of group e (bias gradients); deterministic two-pass reduction."""
     _chk(src, "src", ndim=2)

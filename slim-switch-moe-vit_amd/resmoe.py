@@ -181,11 +181,14 @@ class _GateLNFn(th.autograd.Function):
         ctx.save_for_backward(x, ln_w, gate_w, gate_b if gate_b is not None else th.empty(0, device=x.device), xn, mask)
         ctx.has_gb, ctx.has_lb = gate_b is not None, ln_b is not None
         ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)     # no zero tensor for the mask's (never used) gradient, nor for an unused branch
         return xn, tk, mask
 
     @staticmethod
     def backward(ctx, d_xn, d_tk, _d_mask):
         x, ln_w, gate_w, gate_b, xn, mask = ctx.saved_tensors
+        if d_tk is None and d_xn is None:
+            return (None,) * 9
         if d_tk is None:
             d_tk = th.zeros_like(xn)
         d_tk = d_tk.contiguous()
@@ -195,8 +198,10 @@ class _GateLNFn(th.autograd.Function):
         dx, dg, dbeta = ops.layernorm_bwd(x, dxn, ln_w.detach().float(), ctx.eps)
         dgw = dgb = None
         if ctx.gate_on:
-            dgw = ops.gate_wgrad(dz.reshape(-1, 1), xn).reshape(gate_w.shape).to(gate_w.dtype)
-            dgb = dz.sum().reshape(gate_b.shape).to(gate_b.dtype) if ctx.has_gb else None
+            got = ops.gate_wgrad(dz.reshape(-1, 1), xn, want_bias=ctx.has_gb)      # the bias gradient sum(dz) from the same pass
+            dgw, dgb = got if ctx.has_gb else (got, None)
+            dgw = dgw.reshape(gate_w.shape).to(gate_w.dtype)
+            dgb = dgb.reshape(gate_b.shape).to(gate_b.dtype) if ctx.has_gb else None
         return dx, dg.to(ln_w.dtype), (dbeta if ctx.has_lb else None), dgw, dgb, None, None, None, None
 
 

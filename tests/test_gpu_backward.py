@@ -403,3 +403,106 @@ def test_switch_gate_bwd_matches_autograd_of_softmax_gather_and_linear_aux(T, E)
         obj.backward()
         got = ops.switch_gate_bwd(probs.to(DEV), idx.to(DEV), dscore.to(DEV) if use_ds else None, coef.to(DEV) if use_cf else None)
         assert (got.cpu().double() - l64.grad).abs().max().item() <= 2e-6 * max(1.0, float(l64.grad.abs().max()))
+
+
+@pytest.mark.parametrize("T,E", [(1, 8), (1000, 8), (25216, 8), (4097, 16), (333, 27), (5000, 256)])
+def test_switch_aux_kernel_matches_the_formula(T, E):
+    """smoe_switch_aux: aux = E sum_e frac_e prob_e and coef[e] = E frac_e / kept (fmoe.gates.SwitchGate) against the
+    float64 formula, with dropped tokens (counts that sum to less than T) and an all-dropped plan (kept clamps to 1)."""
+    g = _gen(T + 7 * E)
+    probs = torch.softmax(torch.randn(T, E, generator=g), -1)
+    idx = torch.randint(0, E, (T,), generator=g)
+    counts = torch.bincount(idx, minlength=E).to(torch.int32)
+    counts = (counts.float() * 0.8).floor().to(torch.int32)          # a capacity dropped some
+    for cnt in (counts, torch.zeros_like(counts)):
+        aux, coef = ops.switch_aux(probs.to(DEV), cnt.to(DEV))
+        kept = max(int(cnt.sum()), 1)
+        frac = cnt.double() / kept
+        ref_aux = E * (frac * (probs.double().sum(0) / kept)).sum()
+        ref_coef = E * frac / kept
+        assert abs(float(aux) - float(ref_aux)) <= 1e-5 * max(1.0, abs(float(ref_aux)))
+        assert (coef.cpu().double() - ref_coef).abs().max().item() <= 1e-6 * max(1.0, float(ref_coef.abs().max()))
+        again = ops.switch_aux(probs.to(DEV), cnt.to(DEV))
+        assert torch.equal(again[0], aux) and torch.equal(again[1], coef)                      # deterministic
+
+
+def test_switch_gate_bwd_scales_the_aux_coefficients_on_the_device():
+    g = _gen(77)
+    T, E = 3000, 8
+    probs = torch.softmax(torch.randn(T, E, generator=g), -1).to(DEV)
+    idx = torch.randint(0, E, (T,), generator=g).to(DEV)
+    ds = torch.randn(T, generator=g).to(DEV)
+    coef = (torch.randn(E, generator=g) * 0.1).to(DEV)
+    scale = torch.tensor([0.37], device=DEV)
+    a = ops.switch_gate_bwd(probs, idx, ds, coef, scale)
+    b = ops.switch_gate_bwd(probs, idx, ds, (coef * scale).contiguous())
+    assert (a - b).abs().max().item() <= 1e-7
+    assert torch.equal(ops.switch_gate_bwd(probs, idx, ds, coef, None), ops.switch_gate_bwd(probs, idx, ds, coef))
+
+
+@pytest.mark.parametrize("T,E,d,dtype", [(1, 4, 64, torch.float32), (5000, 8, 768, torch.float32), (1537, 16, 192, torch.float16),
+                                          (25216, 1, 768, torch.float32)])
+def test_gate_wgrad_bias_column_is_the_column_sum_of_dl(T, E, d, dtype):
+    g = _gen(T + E + 1)
+    dl = torch.randn(T, E, generator=g)
+    x = torch.randn(T, d, generator=g).to(dtype)
+    dw, db = ops.gate_wgrad(dl.to(DEV), x.to(DEV), want_bias=True)
+    assert torch.equal(dw, ops.gate_wgrad(dl.to(DEV), x.to(DEV)))                              # the weights' pass is unchanged
+    ref = dl.double().sum(0)
+    assert (db.cpu().double() - ref).abs().max().item() <= 1e-5 * max(1.0, float(ref.abs().max())) * (T ** 0.5)
+    assert torch.equal(ops.gate_wgrad(dl.to(DEV), x.to(DEV), want_bias=True)[1], db)
+
+
+@pytest.mark.parametrize("xdt,odt", [(torch.float32, torch.float16), (torch.float16, torch.float16), (torch.float32, torch.float32)])
+def test_scatter_rows_clears_the_slots_no_token_maps_to(xdt, odt):
+    """``zero_fill``: slots with pos < 0 (past the kept count under a capacity) become zero rows in the scatter pass itself; without
+    it they are left alone."""
+    g = _gen(5)
+    T, d, k = 700, 192, 1
+    x = torch.randn(T, d, generator=g).to(xdt).to(DEV)
+    pos = torch.randperm(T, generator=g)
+    pos[500:] = -1
+    pos = pos.to(DEV)
+    junk = torch.full((T, d), 7.0, dtype=odt, device=DEV)
+    out = ops.scatter_rows(x, pos, k, odt, out=junk.clone(), zero_fill=True)
+    ref = torch.zeros(T, d, dtype=odt, device=DEV)
+    ref[:500] = x[pos[:500]].to(odt)
+    assert torch.equal(out, ref)
+    kept = ops.scatter_rows(x, pos, k, odt, out=junk.clone())
+    assert torch.equal(kept[:500], ref[:500]) and torch.equal(kept[500:], junk[500:])
+    scale = torch.rand(T, generator=g).to(DEV)
+    sc = ops.scatter_rows(x, pos, k, odt, zero_fill=True, scale=scale)
+    assert torch.equal(sc[500:], ref[500:])
+    assert torch.allclose(sc[:500].float(), (x[pos[:500]].float() * scale[pos[:500], None]), rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("E,Z,adt", [(8, 1, torch.float16), (4, 2, torch.float16), (8, 2, torch.float32)])
+def test_zero_group_fold_equals_the_index_add_composition(E, Z, adt):
+    """smoe_zero_group_fold against the torch composition it replaces (rank-1 index_add_ into dW2, index_add of the column sums),
+    two zero groups aimed at the same expert, an empty zero group."""
+    g = _gen(E * 10 + Z)
+    d, h = 192, 768
+    counts = [int(c) for c in torch.randint(50, 300, (E,), generator=g)] + ([400, 0] if Z == 2 else [400])
+    G = E + Z
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device=DEV)
+    n = sum(counts)
+    A = torch.randn(n, h, generator=g).to(adt).to(DEV)
+    cs2 = torch.randn(G, d, generator=g).to(DEV)
+    cs1 = torch.randn(G, h, generator=g).to(DEV)
+    if Z == 2:
+        cs2[G - 1] = 0
+        cs1[G - 1] = 0                                              # (the column sums of an empty group)
+    tgt = torch.full((Z,), 3, dtype=torch.int64) if Z == 2 else torch.tensor([E - 1])
+    gmap = torch.cat((torch.arange(E), tgt)).to(torch.int32).to(DEV)
+    dW2 = torch.randn(E, d, h, generator=g).to(DEV)
+    ref = dW2.clone()
+    first = offsets[E:G].long().clamp(max=n - 1)
+    a_rows = A.index_select(0, first).float()
+    ref.index_add_(0, tgt.to(DEV), cs2[E:, :, None] * a_rows[:, None, :])
+    ref_b2 = cs2[:E].index_add(0, tgt.to(DEV), cs2[E:])
+    ref_b1 = cs1[:E].index_add(0, tgt.to(DEV), cs1[E:])
+    db2, db1 = ops.zero_group_fold(cs2, cs1, A, offsets, gmap, E, dW2)
+    assert torch.allclose(dW2, ref, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(db2, ref_b2, rtol=1e-6, atol=1e-6) and torch.allclose(db1, ref_b1, rtol=1e-6, atol=1e-6)
+    only2, none1 = ops.zero_group_fold(cs2, None, A, offsets, gmap, E, dW2.clone(), want_b1=False)
+    assert none1 is None and torch.equal(only2, db2)
