@@ -123,6 +123,15 @@ int smoe_zero_row_output(const float* bg, int E, int k, const float* w2, const f
  * The gate's parameter gradients follow from dz: dW = dz^T xn (smoe_gate_wgrad with E = 1), db = sum dz.                      */
 int smoe_skip_gate_bwd(const float* xn, const void* g_f, int g_f_dtype, const float* g_out, const float* gate_w,
                        const float* gate_b, const float* mask, int gate_on, int64_t T, int d, float* dxn, float* dz, void* stream);
+/* smoe_gate_ln_bwd: smoe_skip_gate_bwd, the LayerNorm backward in front of it and the gate's parameter gradients as ONE pass over the
+ * half's INPUT x [T,d] f32 (the normed activations, p and the gate logit are recomputed from x in registers; nothing but x and the
+ * forward's decisions is read):  dx [T,d] f32 = LayerNorm backward of dxn;  out f32 [3 d + 4] = dgamma [d] | dbeta [d] | dgate_w [d] |
+ * dgate_b, 0, 0, 0;  dz f32 [T] or NULL.  gamma / beta f32 [d] (NULL = 1 / 0); the other operands as in smoe_skip_gate_bwd; d % 4 == 0,
+ * d <= 1024.  Deterministic (per-workgroup partial rows, two-stage ordered reduction).                                              */
+size_t smoe_gate_ln_bwd_workspace_bytes(int64_t T, int d);
+int smoe_gate_ln_bwd(const float* x, const void* g_f, int g_f_dtype, const float* g_out, const float* gamma, const float* beta,
+                     float eps, const float* gate_w, const float* gate_b, const float* mask, int gate_on, int64_t T, int d, float* dx,
+                     float* dz, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the embedding stage and the last LayerNorm of the ViT forward (models/vision_transformer.py:818-830) ----
  * smoe_patchify_cast:  images f32 [B, C, H, W] -> patch rows [B * (H/ph) * (W/pw), C * ph * pw] (f16 / bf16), row (b, gy, gx) =

@@ -119,6 +119,152 @@ __global__ __launch_bounds__(LNB_THREADS) void layernorm_bwd_kernel(const float*
   }
 }
 
+// One gated half of the residual-MoE block, backward, in ONE pass (models/resMoE.py:126-131 / 137-140 with Gate.forward's hard
+// branch, 68-77): the gate's straight-through gradients (gate.hip skip_gate_bwd_kernel's arithmetic), the LayerNorm backward above
+// and the gate's parameter gradients -- as three passes they wrote and re-read the [T, d] gradient of the normed activations and
+// read the normed activations twice more.  Everything is recomputed from x in registers:
+//     xhat = (x - mean) rstd,  xn = xhat gamma + beta,  p = sigmoid(<xn, w> + b),
+//     dz = -<g_f, xn> p (1 - p),  dxn = g_f keep + g_out + dz w,              (gate_on = 0: dz = 0, dxn = g_f + g_out)
+//     dx = rstd (dxn gamma - mean(dxn gamma) - xhat mean(dxn gamma xhat)),
+//     dgamma = sum dxn xhat,  dbeta = sum dxn,  dw = sum dz xn,  db = sum dz.
+// g_f = dL/d(the operator's masked input), g_out = dL/d(the half's output, i.e. of the residual xn), keep = mask[t, 1].
+// Partial rows per workgroup: [dgamma d | dbeta d | dw d | db, 0, 0, 0]; the same two-stage reduction as the LayerNorm's.
+template <typename GT, int NJ>
+__global__ __launch_bounds__(LNB_THREADS) void gate_ln_bwd_kernel(const float* __restrict__ x, const GT* __restrict__ g_f,
+                                                                  const float* __restrict__ g_out, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps,
+                                                                  const float* __restrict__ gate_w, const float* __restrict__ gate_b,
+                                                                  const float* __restrict__ mask, int gate_on, int64_t T, int d,
+                                                                  float* __restrict__ dx, float* __restrict__ dz_out,
+                                                                  float* __restrict__ partial) {
+  __shared__ float red[LNB_WAVES][3][NJ * 256];
+  __shared__ float red_b[LNB_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunk = d >> 2;
+  const int L = 3 * d + 4;
+  float ag[NJ][4], ab[NJ][4], aw[NJ][4];
+  float agb = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ag[j][i] = ab[j][i] = aw[j][i] = 0.f;
+  f32x4 gm[NJ], bt[NJ], wv[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = lane + 64 * j;
+    const bool in = c < nchunk;
+    gm[j] = (gamma && in) ? *reinterpret_cast<const f32x4*>(gamma + c * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bt[j] = (beta && in) ? *reinterpret_cast<const f32x4*>(beta + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    wv[j] = in ? *reinterpret_cast<const f32x4*>(gate_w + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float bias = (gate_b && gate_on) ? *gate_b : 0.f;
+  const float inv_d = 1.0f / (float)d;
+  const int64_t row0 = (int64_t)blockIdx.x * LNB_WAVES + wave, stride = (int64_t)gridDim.x * LNB_WAVES;
+  for (int64_t t = row0; t < T; t += stride) {
+    float xv[NJ][4], gv[NJ][4], go[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nchunk) {
+        load4(x + t * (int64_t)d + c * 4, xv[j]);
+        load4(g_f + t * (int64_t)d + c * 4, gv[j]);
+        if (g_out) load4(g_out + t * (int64_t)d + c * 4, go[j]);
+        else go[j][0] = go[j][1] = go[j][2] = go[j][3] = 0.f;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[j][i] = gv[j][i] = go[j][i] = 0.f;
+      }
+    }
+    const float keep = gate_on ? mask[t * 2 + 1] : 1.f;
+    float s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s1 += (xv[j][0] + xv[j][1]) + (xv[j][2] + xv[j][3]);
+    const float mean = wave_sum(s1) * inv_d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (lane + 64 * j < nchunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float dv = xv[j][i] - mean; s2 = fmaf(dv, dv, s2); }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(s2) * inv_d + eps);
+    // the gate: logit and <g_f, xn> on the recomputed normed row (xv becomes xhat, xn kept beside it)
+    float xn[NJ][4];
+    float az = 0.f, ad = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const bool in = lane + 64 * j < nchunk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xh = in ? (xv[j][i] - mean) * rstd : 0.f;
+        xv[j][i] = xh;
+        xn[j][i] = in ? fmaf(xh, gm[j][i], bt[j][i]) : 0.f;
+        az = fmaf(xn[j][i], wv[j][i], az);
+        ad = fmaf(gv[j][i], xn[j][i], ad);
+      }
+    }
+    const float z = wave_sum(az) + bias, dot = wave_sum(ad);
+    const float p = 1.0f / (1.0f + expf(-z));
+    const float dz = gate_on ? -dot * p * (1.0f - p) : 0.f;
+    agb += dz;
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float dyv = fmaf(gv[j][i], keep, fmaf(dz, wv[j][i], go[j][i]));     // dxn
+        const float xh = xv[j][i];
+        ag[j][i] = fmaf(dyv, xh, ag[j][i]);
+        ab[j][i] += dyv;
+        aw[j][i] = fmaf(dz, xn[j][i], aw[j][i]);
+        const float g = dyv * gm[j][i];
+        c1 += g;
+        c2 = fmaf(g, xh, c2);
+        gv[j][i] = g;
+      }
+    }
+    c1 = wave_sum(c1) * inv_d;
+    c2 = wave_sum(c2) * inv_d;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nchunk) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = rstd * (gv[j][i] - c1 - xv[j][i] * c2);
+        *reinterpret_cast<f32x4*>(dx + t * (int64_t)d + c * 4) = o;
+      }
+    }
+    if (lane == 0 && dz_out) dz_out[t] = dz;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[wave][0][(lane + 64 * j) * 4 + i] = ag[j][i];
+      red[wave][1][(lane + 64 * j) * 4 + i] = ab[j][i];
+      red[wave][2][(lane + 64 * j) * 4 + i] = aw[j][i];
+    }
+  if (lane == 0) red_b[wave] = agb;
+  __syncthreads();
+  for (int c = tid; c < 3 * d; c += LNB_THREADS) {
+    const int which = c / d, col = c - which * d;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNB_WAVES; ++w) s += red[w][which][col];
+    partial[(int64_t)blockIdx.x * L + c] = s;
+  }
+  if (tid < 4) {
+    float s = 0.f;
+    if (tid == 0) {
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) s += red_b[w];
+    }
+    partial[(int64_t)blockIdx.x * L + 3 * d + tid] = s;
+  }
+}
+
 // dgamma_dbeta[c] (c < 2 d: dgamma then dbeta) = sum over the workgroups' partial rows.  A workgroup takes 32 columns (one
 // 128-byte segment of every partial row); thread (column c, slice r of 8) adds rows r, r + 8, ... in order, the eight slices meet
 // in LDS in slice order: deterministic, and the 6-MB table is read at streaming rate (the first version gave every column to one
@@ -175,6 +321,31 @@ int lnb_launch(const float* x, const void* dy, const float* gamma, const float* 
   hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * d + 31) / 32, 1), dim3(256), 0, s, stage1, LNB_STAGE1, 2 * d, LNB_STAGE1,
                      dgamma_dbeta);
   SMOE_CHECK_LAUNCH("smoe_layernorm_bwd/reduce");
+  return 0;
+}
+
+template <typename GT>
+int glnb_launch(const float* x, const void* g_f, const float* g_out, const float* gamma, const float* beta, float eps,
+                const float* gate_w, const float* gate_b, const float* mask, int gate_on, int64_t T, int d, float* dx, float* dz,
+                float* partial, float* out, hipStream_t s) {
+  const int grid = lnb_grid(T);
+  const int L = 3 * d + 4;
+#define GLNB(NJ) hipLaunchKernelGGL((gate_ln_bwd_kernel<GT, NJ>), dim3(grid), dim3(LNB_THREADS), 0, s, x, (const GT*)g_f, g_out, gamma, beta, eps, gate_w, gate_b, mask, gate_on, T, d, dx, dz, partial)
+  const int nj = (d / 4 + 63) / 64;
+  switch (nj) {
+    case 1: GLNB(1); break;
+    case 2: GLNB(2); break;
+    case 3: GLNB(3); break;
+    case 4: GLNB(4); break;
+    default: smoe_set_error("smoe_gate_ln_bwd: d=%d out of range (d <= 1024)", d); return 1;
+  }
+#undef GLNB
+  SMOE_CHECK_LAUNCH("smoe_gate_ln_bwd");
+  float* stage1 = partial + (size_t)grid * L;
+  const int rpb = (grid + LNB_STAGE1 - 1) / LNB_STAGE1;
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((L + 31) / 32, LNB_STAGE1), dim3(256), 0, s, partial, grid, L, rpb, stage1);
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((L + 31) / 32, 1), dim3(256), 0, s, stage1, LNB_STAGE1, L, LNB_STAGE1, out);
+  SMOE_CHECK_LAUNCH("smoe_gate_ln_bwd/reduce");
   return 0;
 }
 
@@ -266,6 +437,34 @@ extern "C" int smoe_gate_dgrad(const float* dl, const float* w, int64_t T, int E
   }
   SMOE_CHECK_LAUNCH("smoe_gate_dgrad");
   return 0;
+}
+
+extern "C" size_t smoe_gate_ln_bwd_workspace_bytes(int64_t T, int d) {
+  if (T < 0 || d <= 0) return 0;
+  return ((size_t)lnb_grid(T) + LNB_STAGE1) * (3 * (size_t)d + 4) * sizeof(float);
+}
+
+// see gate_ln_bwd_kernel.  x f32 [T, d] (the half's input), g_f [T, d] (f32 / f16 / bf16), g_out f32 [T, d] or NULL, gamma / beta f32 [d]
+// (NULL = 1 / 0), gate_w f32 [d], gate_b f32 [1] or NULL, mask f32 [T, 2] (the forward's decisions; needed when gate_on);
+// dx f32 [T, d]; out f32 [3 d + 4] = dgamma | dbeta | dgate_w | dgate_b, 0, 0, 0; dz f32 [T] or NULL (d loss / d gate logit).
+extern "C" int smoe_gate_ln_bwd(const float* x, const void* g_f, int g_f_dtype, const float* g_out, const float* gamma,
+                                const float* beta, float eps, const float* gate_w, const float* gate_b, const float* mask,
+                                int gate_on, int64_t T, int d, float* dx, float* dz, float* out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  SMOE_REQUIRE(T >= 0 && d > 0 && d % 4 == 0 && d <= 1024, "smoe_gate_ln_bwd: bad sizes T=%lld d=%d (d %% 4 == 0, d <= 1024)",
+               (long long)T, d);
+  SMOE_REQUIRE(out && workspace && gate_w, "smoe_gate_ln_bwd: null pointer");
+  SMOE_REQUIRE(workspace_bytes >= smoe_gate_ln_bwd_workspace_bytes(T, d), "smoe_gate_ln_bwd: workspace too small");
+  SMOE_REQUIRE(T == 0 || (x && g_f && dx), "smoe_gate_ln_bwd: null pointer");
+  SMOE_REQUIRE(!gate_on || mask, "smoe_gate_ln_bwd: an enabled gate needs the forward's decisions (mask)");
+  SMOE_REQUIRE(smoe_dtype_ok(g_f_dtype), "smoe_gate_ln_bwd: bad g_f dtype");
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = reinterpret_cast<float*>(workspace);
+  switch (g_f_dtype) {
+    case SMOE_F32: return glnb_launch<float>(x, g_f, g_out, gamma, beta, eps, gate_w, gate_b, mask, gate_on, T, d, dx, dz, partial, out, s);
+    case SMOE_F16: return glnb_launch<f16>(x, g_f, g_out, gamma, beta, eps, gate_w, gate_b, mask, gate_on, T, d, dx, dz, partial, out, s);
+    default: return glnb_launch<bf16_bits>(x, g_f, g_out, gamma, beta, eps, gate_w, gate_b, mask, gate_on, T, d, dx, dz, partial, out, s);
+  }
 }
 
 extern "C" size_t smoe_layernorm_bwd_workspace_bytes(int64_t T, int d) {

@@ -393,6 +393,41 @@ def gate_ln_router(x: torch.Tensor, gate_w: torch.Tensor, gate_b: Optional[torch
     return {"xn16": xn16, "xn32": xn32, "idx": idx, "idx_plan": idx_plan, "score": score, "mask": mask}
 
 
+def gate_ln_bwd(x: torch.Tensor, g_f: torch.Tensor, g_out: Optional[torch.Tensor], ln_w: Optional[torch.Tensor],
+                ln_b: Optional[torch.Tensor], eps: float, gate_w: torch.Tensor, gate_b: Optional[torch.Tensor],
+                mask: Optional[torch.Tensor], gate_on: bool = True, want_dz: bool = False):
+    """Backward of one gated half's front end (LayerNorm -> token-skip gate) in one pass over its input x (smoe_gate_ln_bwd):
+    (dx f32 [T,d], dln_w [d], dln_b [d], dgate_w [d], dgate_b [1], dz [T] | None)."""
+    _chk(x, "x", torch.float32, 2)
+    _chk(g_f, "g_f", ndim=2)
+    T, d = x.shape
+    if tuple(g_f.shape) != (T, d):
+        raise RuntimeError("gate_ln_bwd: g_f must have x's shape")
+    if g_out is not None:
+        _chk(g_out, "g_out", torch.float32, 2)
+    gw = gate_w.detach().reshape(-1)
+    _chk(gw, "gate_w", torch.float32, 1, align=4)
+    gb = gate_b.detach().reshape(-1) if gate_b is not None else None
+    if gb is not None:
+        _chk(gb, "gate_b", torch.float32, 1, align=4)
+    if mask is not None:
+        _chk(mask, "mask", torch.float32, 2, align=4)
+    for nm, t in (("ln_w", ln_w), ("ln_b", ln_b)):
+        if t is not None:
+            _chk(t, nm, torch.float32, 1)
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    out = torch.empty(3 * d + 4, dtype=torch.float32, device=x.device)
+    dz = torch.empty(T, dtype=torch.float32, device=x.device) if want_dz else None
+    ws_bytes = lib.smoe_gate_ln_bwd_workspace_bytes(T, d)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    rc = lib.smoe_gate_ln_bwd(_ptr(x), _ptr(g_f), dtype_code(g_f.dtype), _ptr(g_out), _ptr(ln_w), _ptr(ln_b), float(eps), _ptr(gw),
+                              _ptr(gb), _ptr(mask), 1 if gate_on else 0, T, d, _ptr(dx), _ptr(dz), _ptr(out), _ptr(ws), ws_bytes,
+                              _stream(x))
+    _lib.check(rc, "smoe_gate_ln_bwd")
+    return dx, out[:d], out[d:2 * d], out[2 * d:3 * d], out[3 * d:3 * d + 1], dz
+
+
 def skip_gate_bwd(xn: torch.Tensor, g_f: torch.Tensor, g_out: Optional[torch.Tensor], gate_w: torch.Tensor,
                   gate_b: Optional[torch.Tensor], mask: Optional[torch.Tensor], gate_on: bool = True):
     """Backward of one gated half of the residual-MoE block in training (smoe_skip_gate_bwd): (dxn f32 [T,d], dz f32 [T])."""

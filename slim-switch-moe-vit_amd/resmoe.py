@@ -163,8 +163,9 @@ class _GateLNFn(th.autograd.Function):
         xn = norm(x);  m = gate(xn);  tk = xn * m[..., 1:]          ->  (xn f32, tk, mask)
 
     forward: ONE HIP pass (smoe_gate_ln_router: LayerNorm, gate logit, decision on the f64-accurate logit, the 16-bit masked
-    operand image for the attention half / + one scaled copy for the f32 image the MoE router reads); backward: smoe_skip_gate_bwd
-    (straight-through estimator: d m1 / d p = -1, d m0 / d p = +1; p recomputed) -> smoe_layernorm_bwd -> smoe_gate_wgrad.  The
+    operand image for the attention half / + one scaled copy for the f32 image the MoE router reads); backward: ONE pass too
+    (smoe_gate_ln_bwd: straight-through estimator d m1 / d p = -1, d m0 / d p = +1 with p, xn recomputed from x; LayerNorm backward;
+    the gate's and the LayerNorm's parameter gradients).  The
     caller computes out = f(tk) + xn (the reference's f(tk) + tk + skip_tk in value; the mask gradients are this Function's)."""
 
     @staticmethod
@@ -178,7 +179,8 @@ class _GateLNFn(th.autograd.Function):
             ident = _ident_rows(x.shape[0], x.device)
             tk = ops.scatter_rows(xn, ident, 1, th.float32, scale=mask[:, 1].contiguous())
         ctx.eps, ctx.gate_on = eps, thr is not None
-        ctx.save_for_backward(x, ln_w, gate_w, gate_b if gate_b is not None else th.empty(0, device=x.device), xn, mask)
+        ctx.save_for_backward(x, ln_w, gate_w, gate_b if gate_b is not None else th.empty(0, device=x.device), mask,
+                              ln_b if ln_b is not None else th.empty(0, device=x.device))
         ctx.has_gb, ctx.has_lb = gate_b is not None, ln_b is not None
         ctx.mark_non_differentiable(mask)
         ctx.set_materialize_grads(False)     # no zero tensor for the mask's (never used) gradient, nor for an unused branch
@@ -186,22 +188,24 @@ class _GateLNFn(th.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_xn, d_tk, _d_mask):
-        x, ln_w, gate_w, gate_b, xn, mask = ctx.saved_tensors
+        x, ln_w, gate_w, gate_b, mask, ln_b = ctx.saved_tensors
         if d_tk is None and d_xn is None:
             return (None,) * 9
         if d_tk is None:
-            d_tk = th.zeros_like(xn)
+            d_tk = th.zeros_like(x)
         d_tk = d_tk.contiguous()
         if d_xn is not None and not (d_xn.dtype == th.float32 and d_xn.is_contiguous()):
             d_xn = d_xn.float().contiguous()
-        dxn, dz = ops.skip_gate_bwd(xn, d_tk, d_xn, gate_w, gate_b if ctx.has_gb else None, mask, ctx.gate_on)
-        dx, dg, dbeta = ops.layernorm_bwd(x, dxn, ln_w.detach().float(), ctx.eps)
-        dgw = dgb = None
+        # ONE pass over x: the gate's straight-through gradients, the LayerNorm backward and both modules' parameter gradients
+        # (smoe_gate_ln_bwd; as three kernels -- smoe_skip_gate_bwd -> smoe_layernorm_bwd -> smoe_gate_wgrad -- the [T, d] gradient
+        # of the normed activations made a round trip through HBM and xn was read twice more)
+        dx, dg, dbeta, dgw, dgb, _ = ops.gate_ln_bwd(x, d_tk, d_xn, ln_w.detach().float(), ln_b.detach().float() if ctx.has_lb else None,
+                                                     ctx.eps, gate_w, gate_b if ctx.has_gb else None, mask, ctx.gate_on)
         if ctx.gate_on:
-            got = ops.gate_wgrad(dz.reshape(-1, 1), xn, want_bias=ctx.has_gb)      # the bias gradient sum(dz) from the same pass
-            dgw, dgb = got if ctx.has_gb else (got, None)
             dgw = dgw.reshape(gate_w.shape).to(gate_w.dtype)
             dgb = dgb.reshape(gate_b.shape).to(gate_b.dtype) if ctx.has_gb else None
+        else:
+            dgw = dgb = None
         return dx, dg.to(ln_w.dtype), (dbeta if ctx.has_lb else None), dgw, dgb, None, None, None, None
 
 

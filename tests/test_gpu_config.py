@@ -153,7 +153,7 @@ def test_resmoe_training_with_default_flags_on_own_kernels_matches_the_composed_
         warnings.simplefilter("error", vit.SlimMoEFallbackWarning)
         (l_own, g_own), names = _profiled(lambda: _train_step(a, images, target, "own"))
     assert not _vendor_symbols(names), _vendor_symbols(names)
-    assert any("skip_gate_bwd_kernel" in n for n in names) and any("router16_kernel" in n for n in names), names
+    assert any("gate_ln_bwd_kernel" in n for n in names) and any("router16_kernel" in n for n in names), names
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", vit.SlimMoEFallbackWarning)
         l_ref, g_ref = _train_step(ref, images, target, "torch")

@@ -382,6 +382,58 @@ def test_skip_gate_backward_kernel_matches_float64_autograd_of_the_reference_for
     assert _rel(dxn0, g_f.double() + g_out.double()) <= 1e-6 and float(dz0.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("d,gdt,with_out,T", [(192, torch.float32, True, 777), (768, torch.float16, True, 2500),
+                                              (768, torch.float32, False, 1301), (1024, torch.float16, True, 333),
+                                              (384, torch.float32, True, 64)])
+def test_gate_ln_backward_in_one_pass_matches_float64_autograd_of_the_reference_formula(d, gdt, with_out, T):
+    """smoe_gate_ln_bwd (LayerNorm backward + the gate's straight-through gradients + both modules' parameter gradients from the
+    half's input x alone) against float64 autograd through LayerNorm and the reference's expressions (resMoE.py:69-77, 126-136):
+    xn = norm(x), tk = xn * m1, skip_tk = xn * m0, L = <g_f, tk> + <g_out, tk + skip_tk>; and a disabled gate."""
+    g = _gen(d + T)
+    x = torch.randn(T, d, generator=g) * 1.7 + 0.3
+    gam, bet = 1.0 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    w, b = torch.randn(d, generator=g) * 0.1, torch.randn(1, generator=g) * 0.1
+    g_f = (torch.randn(T, d, generator=g) * 0.3).to(gdt)
+    g_out = torch.randn(T, d, generator=g) * 0.2 if with_out else None
+    thr, eps = 0.55, 1e-6
+    leaves = [t.double().requires_grad_(True) for t in (x, gam, bet, w, b)]
+    xr, gr, btr, wr, br = leaves
+    xn = torch.nn.functional.layer_norm(xr, (d,), gr, btr, eps)
+    prob = torch.sigmoid(xn @ wr + br)[:, None]
+    _prob = 1 - prob
+    skip_tk = (prob > thr).double() + _prob.detach() - _prob
+    tk = (prob <= thr).double() + prob.detach() - prob
+    loss = (g_f.double() * (xn * tk)).sum()
+    if with_out:
+        loss = loss + (g_out.double() * (xn * tk + xn * skip_tk)).sum()
+    loss.backward()
+    mask = torch.cat([(prob > thr).float(), (prob <= thr).float()], dim=1).detach().float()
+    dev = lambda t: t.to(DEV) if t is not None else None  # noqa: E731
+    dx, dg, db_, dgw, dgb, dz = ops.gate_ln_bwd(dev(x), dev(g_f), dev(g_out), dev(gam), dev(bet), eps, dev(w), dev(b), dev(mask),
+                                                want_dz=True)
+    tol = 3e-5 if gdt == torch.float32 else 3e-5
+    assert _rel(dx, xr.grad) <= tol, _rel(dx, xr.grad)
+    assert _rel(dg, gr.grad) <= tol and _rel(db_, btr.grad) <= tol
+    assert _rel(dgw, wr.grad) <= tol and abs(float(dgb) - float(br.grad)) <= tol * max(1.0, abs(float(br.grad)))
+    assert abs(float(dz.sum()) - float(br.grad)) <= tol * max(1.0, abs(float(br.grad)))
+    again = ops.gate_ln_bwd(dev(x), dev(g_f), dev(g_out), dev(gam), dev(bet), eps, dev(w), dev(b), dev(mask))
+    assert all(torch.equal(a, c) for a, c in zip(again[:5], (dx, dg, db_, dgw, dgb)))          # deterministic
+    # the three-kernel composition it replaces (saved xn from the forward kernel's own LayerNorm)
+    xn32 = ops.layernorm(dev(x), dev(gam), dev(bet), eps, torch.float32)
+    dxn, dz3 = ops.skip_gate_bwd(xn32, dev(g_f), dev(g_out), dev(w), dev(b), dev(mask))
+    dx3, dg3, db3 = ops.layernorm_bwd(dev(x), dxn, dev(gam), eps)
+    assert _rel(dx, dx3) <= 1e-5 and _rel(dg, dg3) <= 1e-5 and _rel(db_, db3) <= 1e-5 and _rel(dz, dz3) <= 1e-5
+    # a disabled gate: constant masks, no gate gradient; dx = LayerNorm backward of g_f + g_out
+    leaves0 = [t.double().requires_grad_(True) for t in (x, gam, bet)]
+    xn0 = torch.nn.functional.layer_norm(leaves0[0], (d,), leaves0[1], leaves0[2], eps)
+    l0 = (g_f.double() * xn0).sum() + ((g_out.double() * xn0).sum() if with_out else 0.0)
+    l0.backward()
+    dx0, dg0, db0, dgw0, dgb0, _ = ops.gate_ln_bwd(dev(x), dev(g_f), dev(g_out), dev(gam), dev(bet), eps, dev(w), dev(b), None,
+                                                   gate_on=False)
+    assert _rel(dx0, leaves0[0].grad) <= tol and _rel(dg0, leaves0[1].grad) <= tol and _rel(db0, leaves0[2].grad) <= tol
+    assert float(dgw0.abs().max()) == 0.0 and float(dgb0.abs().max()) == 0.0
+
+
 def test_residual_block_training_against_the_reference_forward_residule_moe_gradients():
     """fp16-autocast TRAINING of the block on the library's kernels (resmoe._residual_block_train) against output AND gradients of
     the reference's own ``forward_residule_moe`` in train mode (hard gates on ``_threshold``, straight-through estimator;
