@@ -106,6 +106,8 @@ int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, const float* ln
                         float* xn32, const float* zero_out, const float* wg, const float* bg, int64_t T, int d, int E,
                         int k, int64_t* idx, int64_t* idx_plan, float* score, float* mask, int32_t* skip_count,
                         int32_t* chunk_hist /* as smoe_ln_router_topk's; counts idx_plan's dispatched entries; may be NULL */,
+                        float* tk32 /* [T,d] f32 or NULL: the (normed) row, ZEROS for a skipped token -- `x * mask[..., 1:]` of
+                                       models/resMoE.py:141, the masked f32 image the training path's router and scatter read */,
                         void* workspace, size_t workspace_bytes, void* stream);
 /* What the MoE returns for an all-zero input row (every token the skip gate masks, resMoE.py:140-143):
  *   out[d] = sum_j score_j (W2[e_j] gelu(b1[e_j]) + b2[e_j]),  (e_j, score_j) = NaiveGate top-k of the gate bias bg.

@@ -86,7 +86,7 @@ SIGNATURES = {
     "smoe_gate_ln_router_supported": (c_int, [c_int, c_int, c_int]),
     "smoe_gate_ln_router": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_grad_sumsq_blocks": (c_int64, [c_int64]),
     "smoe_grad_sumsq": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_adamw_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, ctypes.c_float, ctypes.c_float,

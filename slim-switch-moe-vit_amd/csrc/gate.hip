@@ -223,8 +223,8 @@ extern "C" int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, cons
                                    float ln_eps, const float* gate_w, const float* gate_b, const float* threshold,
                                    void* xn16, int xn16_dtype, float* xn32, const float* zero_out, const float* wg,
                                    const float* bg, int64_t T, int d, int E, int k, int64_t* idx, int64_t* idx_plan,
-                                   float* score, float* mask, int32_t* skip_count, int32_t* chunk_hist, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+                                   float* score, float* mask, int32_t* skip_count, int32_t* chunk_hist, float* tk32,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
   if (T == 0) return 0;
   SMOE_REQUIRE(x && gate_w, "smoe_gate_ln_router: null pointer");
   SMOE_REQUIRE(x_dtype == SMOE_F32, "smoe_gate_ln_router: x must be f32 (the residual stream / the normed activations)");
@@ -237,7 +237,7 @@ extern "C" int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, cons
   int32_t* rl = reinterpret_cast<int32_t*>((char*)workspace + 16);
   GLnArgs ln{ln_gamma, ln_beta, ln_eps, xn16, xn16_dtype, xn32};
   ln.hist = (chunk_hist && E > 0 && 1024 % (R16_HIST_TOK * k) == 0) ? chunk_hist : nullptr;
-  SkipGateArgs ga{gate_w, gate_b, threshold, skip_count, mask, zero_out, E > 0 ? idx_plan : nullptr};
+  SkipGateArgs ga{gate_w, gate_b, threshold, skip_count, mask, zero_out, E > 0 ? idx_plan : nullptr, tk32};
   hipStream_t s = (hipStream_t)stream;
   const bool ws_zero = (with_ln & 2) != 0;   // bit 1: the caller keeps the workspace's counter words zero between calls
   if (E == 0) return gate_by_ln<2>((with_ln & 1) != 0, (const float*)x, ln, ga, nullptr, nullptr, T, d, 0, 1, rc, rl, nullptr, nullptr, s, ws_zero);

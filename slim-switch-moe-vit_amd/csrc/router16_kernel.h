@@ -36,6 +36,7 @@ struct SkipGateArgs {
   float* mask;             // [T,2] f32 (skip, keep), or NULL
   const float* zero_out;   // [d] f32 added to the f32 image of skipped rows, or NULL
   int64_t* idx_plan;       // [T,k] idx, -1 for skipped tokens; NULL when there is no router
+  float* tk32;             // [T,d] f32: the row, zeros for a skipped token (the training path's masked operand image), or NULL
 };
 
 // Chunk histogram for the dispatch plan (smoe_dispatch_plan_hist): hist[c][e] = dispatched entries of expert e among the tokens
@@ -314,6 +315,13 @@ __global__ __launch_bounds__(NTH, (NTH / R16_THREADS) * (MODE == 0 ? (EB <= 8 ? 
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
             store4_16<NT>(xn16 + rowoff + 64 * j, (GATE != 0 && skip) ? f32x4{0.f, 0.f, 0.f, 0.f} : xv[j]);
+        }
+        if constexpr (GATE != 0) {
+          if (ga.tk32) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              *reinterpret_cast<f32x4*>(ga.tk32 + rowoff + 64 * j) = skip ? f32x4{0.f, 0.f, 0.f, 0.f} : xv[j];
+          }
         }
       }
     }

@@ -337,10 +337,11 @@ def gate_ln_router(x: torch.Tensor, gate_w: torch.Tensor, gate_b: Optional[torch
                    k: int = 1, xn16_dtype: Optional[torch.dtype] = None, want_xn32: bool = False,
                    zero_out: Optional[torch.Tensor] = None, want_mask: bool = False,
                    skip_count: Optional[torch.Tensor] = None, xn32_out: Optional[torch.Tensor] = None,
-                   hist: Optional[torch.Tensor] = None):
+                   hist: Optional[torch.Tensor] = None, want_tk32: bool = False):
     """[LayerNorm +] token-skip gate (+ NaiveGate router) in one pass (smoe_gate_ln_router).  ``ln`` = (weight, bias,
     eps) or None; ``threshold`` = the gate's 0-dim DEVICE buffer (None = gate disabled); ``wg`` None = no router.
-    Returns a dict: xn16, xn32, idx, idx_plan, score, mask (entries that were not asked for are None)."""
+    Returns a dict: xn16, xn32, idx, idx_plan, score, mask, tk32 (entries that were not asked for are None); ``tk32`` = the f32 row
+    with zeros for the skipped tokens (``want_tk32``)."""
     _chk(x, "x", torch.float32, 2)
     T, d = x.shape
     dev = x.device
@@ -376,21 +377,22 @@ def gate_ln_router(x: torch.Tensor, gate_w: torch.Tensor, gate_b: Optional[torch
     idx_plan = torch.empty((T, k), dtype=torch.int64, device=dev) if E else None
     score = torch.empty((T, k), dtype=torch.float32, device=dev) if E else None
     mask = torch.empty((T, 2), dtype=torch.float32, device=dev) if want_mask else None
+    tk32 = torch.empty((T, d), dtype=torch.float32, device=dev) if want_tk32 else None
     if skip_count is not None:
         _chk(skip_count, "skip_count", torch.int32, align=4)
     lib = _lib.load()
     ws_bytes = lib.smoe_router_workspace_bytes(T)
     ws = _router_workspace(dev, ws_bytes)
-    nbytes = T * d * (4 + (2 if xn16 is not None else 0) + (4 if xn32 is not None else 0))
+    nbytes = T * d * (4 + (2 if xn16 is not None else 0) + (4 if xn32 is not None else 0) + (4 if tk32 is not None else 0))
     with _timed("gate_ln_router" if E else "gate_ln", {"bytes": nbytes}, x):
         rc = lib.smoe_gate_ln_router(_ptr(x), F32, (1 if ln is not None else 0) | 2, _ptr(lg), _ptr(lb), float(eps), _ptr(gw),
                                      _ptr(gb), _ptr(thr), _ptr(xn16),
                                      dtype_code(xn16_dtype) if xn16_dtype is not None else F16, _ptr(xn32),
                                      _ptr(zero_out), _ptr(wg), _ptr(bg), T, d, E, k, _ptr(idx), _ptr(idx_plan),
-                                     _ptr(score), _ptr(mask), _ptr(skip_count), _ptr(hist if E else None), _ptr(ws), ws_bytes,
-                                     _stream(x))
+                                     _ptr(score), _ptr(mask), _ptr(skip_count), _ptr(hist if E else None), _ptr(tk32), _ptr(ws),
+                                     ws_bytes, _stream(x))
     _lib.check(rc, "smoe_gate_ln_router")
-    return {"xn16": xn16, "xn32": xn32, "idx": idx, "idx_plan": idx_plan, "score": score, "mask": mask}
+    return {"xn16": xn16, "xn32": xn32, "idx": idx, "idx_plan": idx_plan, "score": score, "mask": mask, "tk32": tk32}
 
 
 def gate_ln_bwd(x: torch.Tensor, g_f: torch.Tensor, g_out: Optional[torch.Tensor], ln_w: Optional[torch.Tensor],

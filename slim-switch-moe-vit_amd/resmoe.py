@@ -163,7 +163,7 @@ class _GateLNFn(th.autograd.Function):
         xn = norm(x);  m = gate(xn);  tk = xn * m[..., 1:]          ->  (xn f32, tk, mask)
 
     forward: ONE HIP pass (smoe_gate_ln_router: LayerNorm, gate logit, decision on the f64-accurate logit, the 16-bit masked
-    operand image for the attention half / + one scaled copy for the f32 image the MoE router reads); backward: ONE pass too
+    operand image for the attention half / the masked f32 image the MoE router reads); backward: ONE pass too
     (smoe_gate_ln_bwd: straight-through estimator d m1 / d p = -1, d m0 / d p = +1 with p, xn recomputed from x; LayerNorm backward;
     the gate's and the LayerNorm's parameter gradients).  The
     caller computes out = f(tk) + xn (the reference's f(tk) + tk + skip_tk in value; the mask gradients are this Function's)."""
@@ -171,13 +171,12 @@ class _GateLNFn(th.autograd.Function):
     @staticmethod
     def forward(ctx, x, ln_w, ln_b, gate_w, gate_b, eps, thr, skip_count, want16):
         r = ops.gate_ln_router(x, gate_w, gate_b, thr, ln=(ln_w.detach().float(), ln_b.detach().float() if ln_b is not None else None, eps),
-                               xn16_dtype=th.float16 if want16 else None, want_xn32=True, want_mask=True, skip_count=skip_count)
+                               xn16_dtype=th.float16 if want16 else None, want_xn32=True, want_mask=True, skip_count=skip_count,
+                               want_tk32=not want16)
         xn, mask = r["xn32"], r["mask"]
-        if want16:
-            tk = r["xn16"]
-        else:   # the f32 image with the skipped rows zeroed: what the MoE's router and scatter read
-            ident = _ident_rows(x.shape[0], x.device)
-            tk = ops.scatter_rows(xn, ident, 1, th.float32, scale=mask[:, 1].contiguous())
+        # the masked operand image: 16-bit rows for the attention half; the f32 image with the skipped rows zeroed -- what the MoE's
+        # router and scatter read -- for the MoE half (a second f32 store of the same pass)
+        tk = r["xn16"] if want16 else r["tk32"]
         ctx.eps, ctx.gate_on = eps, thr is not None
         ctx.save_for_backward(x, ln_w, gate_w, gate_b if gate_b is not None else th.empty(0, device=x.device), mask,
                               ln_b if ln_b is not None else th.empty(0, device=x.device))
@@ -207,17 +206,6 @@ class _GateLNFn(th.autograd.Function):
         else:
             dgw = dgb = None
         return dx, dg.to(ln_w.dtype), (dbeta if ctx.has_lb else None), dgw, dgb, None, None, None, None
-
-
-_ident_cache = {}
-
-
-def _ident_rows(n: int, device) -> th.Tensor:
-    key = (n, str(device))
-    t = _ident_cache.get(key)
-    if t is None:
-        t = _ident_cache[key] = th.arange(n, dtype=th.int64, device=device)
-    return t
 
 
 def _train_ok(blk, x) -> bool:

@@ -503,3 +503,20 @@ def test_zero_row_groups_change_no_result_of_the_training_operator(E, k):
     assert set(g1) == set(g2)
     for n in g1:
         assert _rel(g1[n], g2[n]) <= 2e-3, (n, _rel(g1[n], g2[n]))
+
+
+@pytest.mark.parametrize("d,with_ln", [(768, True), (192, False)])
+def test_gate_kernel_writes_the_masked_f32_image_in_the_same_pass(d, with_ln):
+    """``tk32`` of smoe_gate_ln_router = the (normed) f32 row with zeros for the skipped tokens: bit for bit ``xn32 * mask[:, 1:]``
+    (models/resMoE.py:141 `x * mask[..., 1:]`), including the tokens the f64 redo pass decides."""
+    T = 5000
+    g = _gen(d + 1)
+    x = torch.randn(T, d, generator=g).to(DEV)
+    w, b = (torch.randn(d, generator=g) * 0.2).to(DEV), torch.zeros(1, device=DEV)
+    thr = torch.tensor(0.5, device=DEV)
+    ln = (torch.ones(d, device=DEV) + 0.1 * torch.randn(d, generator=g).to(DEV), 0.1 * torch.randn(d, generator=g).to(DEV), 1e-6) if with_ln else None
+    r = ops.gate_ln_router(x, w, b, thr, ln=ln, want_xn32=True, want_mask=True, want_tk32=True)
+    assert 0.2 < float(r["mask"][:, 0].mean()) < 0.8
+    assert torch.equal(r["tk32"], r["xn32"] * r["mask"][:, 1:])
+    both = ops.gate_ln_router(x, w, b, thr, ln=ln, xn16_dtype=torch.float16, want_xn32=True, want_mask=True, want_tk32=True)
+    assert torch.equal(both["tk32"], r["tk32"]) and torch.equal(both["xn16"], r["tk32"].half())

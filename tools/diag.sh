@@ -10,6 +10,7 @@
 #   tools/diag.sh order-ab OUT                       tile orders of the four bench GEMM shapes, warm and cold (tools/gemm_ab.py)
 #   tools/diag.sh order-pmc OUTDIR                   L2 counters of GEMM-1 under three tile orders
 #   tools/diag.sh bench-order-ab OUT                 tile order inside the model (bench.py per-kernel times)
+#   tools/diag.sh train-profile TAG                  rocprofv3 kernel stats of the two training steps only
 #   tools/diag.sh profile TAG                        rocprofv3 kernel stats of bench / train / dispatch + PMC sets of both GEMMs
 #                                                    -> gpurun_out/prof_TAG   (counters in passes of their own: --pmc alone)
 # `stamps`, `order-*` and `bench-order-ab` use a DIAGNOSTIC build of the library made in /tmp (the production .so stays untouched).
@@ -89,6 +90,11 @@ print(d['ms_per_step'], {k: v['avg_ms'] for k, v in d['kernels'].items() if 'gem
       rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/tcc_$shape -o t -- python3 tools/gemm_prof.py 9 $shape 3 > $O/tcc_$shape.log 2>&1
     done
     find $O -name "*.csv" | wc -l ;;
+  train-profile)   # the two training steps only (kernel tables): tools/diag.sh train-profile TAG
+    TAG=$1; O=gpurun_out/prof_$TAG; mkdir -p $O
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o train -- python3 tools/train_bench.py model 128 6 > $O/train.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_resmoe -o train -- python3 tools/train_bench.py model 128 6 resmoe_base_patch16_224_expert8_top1 > $O/train_resmoe.log 2>&1
+    tail -n 1 $O/train.log; tail -n 1 $O/train_resmoe.log ;;
   *)
     sed -n 2,22p "$0"; exit 1 ;;
 esac
