@@ -124,6 +124,21 @@ class PendingCounts:
         torch.cumsum(n, 0, dtype=torch.int32, out=offs[1:])
         return offs
 
+    def finish_rows(self) -> Tuple[List[List[int]], List[List[int]]]:
+        """The host sync, then only what the all-to-all-v needs: (send_rows[c][w], recv_rows[c][w]) as Python ints -- one
+        ``tolist`` and integer sums (a handful of numbers) instead of six small CPU tensor ops between the GPU going idle and
+        the exchange's launch."""
+        if self.event is not None:
+            self.event.synchronize()
+        both = self.host.tolist()                                   # [2][W][C][E_local]
+        if self.pooled:
+            _pinned.give(self.host)
+            self.pooled = False
+        W, C = len(both[0]), len(both[0][0])
+        send = [[sum(both[0][w][c]) for w in range(W)] for c in range(C)]
+        recv = [[sum(both[1][w][c]) for w in range(W)] for c in range(C)]
+        return send, recv
+
     def finish(self) -> Tuple[torch.Tensor, torch.Tensor]:
         if self.event is not None:
             self.event.synchronize()
@@ -478,18 +493,23 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
         g.set_loss(switch_aux_loss(pruned, probs, g.tot_expert))
 
     pending = exchange_counts_start([p[0] for p in plans], W, group)
-    # the send buffers do not depend on the counts: enqueue their scatter before the host goes to wait
+    # Nothing below depends on the HOST knowing the counts: the send buffers' scatter, the received groups' row offsets (built on
+    # the device from the received counts) and the output buffer are all enqueued / allocated before the host goes to wait, so
+    # that after the wait only the exchange's own launch stands between the idle GPU and its next work
     sends = [ops.scatter_rows(src[t0:t1], plans[c][2], k, cd) for c, (t0, t1) in enumerate(bounds)]
-    out = torch.empty((T, d), dtype=x.dtype, device=x.device)
+    offs_dev = [pending.group_offsets(c) for c in range(len(bounds))]
+    gexp_dev = _group_expert_ids(W, E_local, x.device)
+    out = None
+    if not (next_norm is not None and len(bounds) == 1):
+        out = torch.empty((T, d), dtype=x.dtype, device=x.device)
     yield                                                                # (1) counts in flight to the host
-    lec, gec = pending.finish()                                          # host [C, W, E_local]; the only host sync
+    send_rows_c, recv_rows_c = pending.finish_rows()                     # the only host sync: [C][W] Python ints
 
     # stage A: dispatch all-to-all (async; chunk c+1 travels under chunk c's GEMMs)
     inflight = []
     for c, (t0, t1) in enumerate(bounds):
         send = sends[c]
-        send_rows = lec[c].sum(1).tolist()
-        recv_rows = gec[c].sum(1).tolist()
+        send_rows, recv_rows = send_rows_c[c], recv_rows_c[c]
         recv, work = all_to_all_rows(send, send_rows, recv_rows, group, async_op=True)
         inflight.append((send, recv, work, send_rows, recv_rows))
     yield                                                                # (2) dispatch all-to-all in flight
@@ -500,9 +520,7 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
         work.wait()
         n_recv = recv.shape[0]
         if n_recv > 0:
-            offs_dev = pending.group_offsets(c)
-            gexp_dev = _group_expert_ids(W, E_local, x.device)
-            y = mod._experts_fwd(recv, offs_dev, cd, out_dtype=cd, group_expert=gexp_dev)
+            y = mod._experts_fwd(recv, offs_dev[c], cd, out_dtype=cd, group_expert=gexp_dev)
         else:
             y = recv
         back, work2 = all_to_all_rows(y, recv_rows, send_rows, group, async_op=True)
@@ -513,6 +531,8 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
         y, back, work2 = returning[0]
         work2.wait()
         return _combine_maybe_ln(back, plans[0][3], score, T, k, x, residual, next_norm)
+    if out is None:
+        out = torch.empty((T, d), dtype=x.dtype, device=x.device)
     for c, (t0, t1) in enumerate(bounds):
         y, back, work2 = returning[c]
         work2.wait()
