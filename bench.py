@@ -447,6 +447,7 @@ def main():
             out["speedup_vs_cpu"] = round(out["value"] / ips, 1)
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
                 gl = model(images[: args.cpu_batch]).float().cpu()
+            forced = [blk.mlp.last_plan[0].reshape(-1, 1).cpu() for blk in model.blocks]   # the GPU's routing of THIS forward
             out["parity"] = hot_path_parity(model, sd_cpu, device)
             # whole model, fp16 autocast on the GPU against the fp32 CPU oracle: NOT a parity bar -- a top-1 router turns a
             # last-bit difference in a near-tied token into a different expert, and that image's logits then differ visibly
@@ -455,6 +456,20 @@ def main():
             out["parity"]["model_logits_max_abs_diff_vs_cpu_fp32"] = float(per_img.max())
             out["parity"]["model_logits_per_image_median_max_abs_diff"] = float(per_img.median())
             out["parity"]["model_images_within_2e-2_of_cpu_fp32"] = f"{int((per_img <= 2e-2).sum())} / {per_img.numel()}"
+            # ... and the same comparison with the routing taken out of it: the oracle run again on the decisions the GPU made
+            # (every block's [T, 1] expert choice).  What is left is arithmetic (fp16 operands against fp32); the flipped tokens
+            # are listed with the oracle's own logit gap between its choice and the GPU's -- a precision flip has a tiny one.
+            from oracle import moe_oracle as mo
+            tr = []
+            with torch.no_grad():
+                fl = mo.vit_forward(images_cpu[: args.cpu_batch], sd_cpu, depth=12, num_heads=12, k=1, residual_moe=False,
+                                    forced=forced, trace=tr)
+            per_img_f = (gl - fl).abs().amax(dim=1)
+            out["parity"]["same_routing"] = {
+                "model_logits_max_abs_diff": float(per_img_f.max()), "per_image_median": float(per_img_f.median()),
+                "images_within_2e-2": f"{int((per_img_f <= 2e-2).sum())} / {per_img_f.numel()}",
+                "tokens_routed_differently": f"{sum(t['flips'] for t in tr)} / {sum(t['tokens'] for t in tr)}",
+                "max_oracle_logit_gap_of_a_flipped_token": max((t["max_margin"] for t in tr), default=0.0)}
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_ep:
         dist.destroy_process_group()

@@ -203,8 +203,14 @@ class MoEOut:
 
 
 def moe_forward(x, wg, bg, w1, b1, w2, b2, k: int, gate: int = GATE_NAIVE,
-                capacity: int = -1, noise=None, dtype=torch.float32) -> MoEOut:
-    """FMoETransformerMLP.forward on one rank (world_size = 1).  SURVEY.md Appendix B."""
+                capacity: int = -1, noise=None, dtype=torch.float32, forced_idx=None, trace=None) -> MoEOut:
+    """FMoETransformerMLP.forward on one rank (world_size = 1).  SURVEY.md Appendix B.
+
+    ``forced_idx`` (int64 [T, k], NaiveGate only; a checking aid, not part of the operator): route as THESE decisions say instead
+    of the oracle's own top-k -- the score is still the softmax of the oracle's logits at the forced experts.  With the routing of a
+    reduced-precision implementation forced, what is left of the difference between the two is arithmetic alone; ``trace`` (a list)
+    receives per call {"tokens", "flips": entries routed differently from the oracle's own choice, "max_margin": the largest gap
+    (own best logit - logit of the forced expert) among them}: a flip is explained by precision iff its margin is tiny."""
     shape = x.shape
     d = shape[-1]
     X = x.reshape(-1, d).float()
@@ -212,8 +218,17 @@ def moe_forward(x, wg, bg, w1, b1, w2, b2, k: int, gate: int = GATE_NAIVE,
     E = wg.shape[0]
     if gate == GATE_NAIVE:
         idx, score, aux_in = naive_gate(X, wg, bg, k)
+        if forced_idx is not None:
+            logits = router_logits(X, wg, bg)
+            f = forced_idx.reshape(T, k).to(torch.int64)
+            if trace is not None:
+                own, forced = logits.gather(1, idx), logits.gather(1, f)
+                diff = (torch.sort(idx, 1).values != torch.sort(f, 1).values).any(1)
+                margin = (own.max(1).values - forced.min(1).values)[diff]
+                trace.append({"tokens": T, "flips": int(diff.sum()), "max_margin": float(margin.max()) if margin.numel() else 0.0})
+            idx, score = f, torch.softmax(logits.gather(1, f), dim=-1)
     else:
-        assert k == 1
+        assert k == 1 and forced_idx is None
         idx, score, aux_in = switch_gate(X, wg, bg, noise)
     plan = dispatch_plan(idx.numpy(), E, capacity)
     kept = int(plan.offsets[E])
@@ -278,7 +293,7 @@ def attention(x, qkv_w, qkv_b, proj_w, proj_b, num_heads):
     return F.linear(x, proj_w, proj_b)
 
 
-def block_forward(x, p: dict, num_heads: int, k: int, residual_moe: bool, eps: float = 1e-6):
+def block_forward(x, p: dict, num_heads: int, k: int, residual_moe: bool, eps: float = 1e-6, forced_idx=None, trace=None):
     """One ViT block with the MoE MLP.  ``residual_moe`` selects forward_residule_moe
     (resMoE.py:126-145: residual taken from the *normed* activations, token-skip gates)
     versus the stock Block.forward (vision_transformer.py:319-322)."""
@@ -287,7 +302,8 @@ def block_forward(x, p: dict, num_heads: int, k: int, residual_moe: bool, eps: f
     def moe(t):
         return moe_forward(t, p["mlp.gate.gate.weight"], p["mlp.gate.gate.bias"],
                            p["mlp.experts.htoh4.weight"], p["mlp.experts.htoh4.bias"],
-                           p["mlp.experts.h4toh.weight"], p["mlp.experts.h4toh.bias"], k).out
+                           p["mlp.experts.h4toh.weight"], p["mlp.experts.h4toh.bias"], k, forced_idx=forced_idx,
+                           trace=trace).out
 
     def attn(t):
         return attention(t, p["attn.qkv.weight"], p["attn.qkv.bias"], p["attn.proj.weight"],
@@ -311,9 +327,10 @@ def block_forward(x, p: dict, num_heads: int, k: int, residual_moe: bool, eps: f
 
 
 def vit_forward(images, sd: dict, depth: int, num_heads: int, k: int, residual_moe: bool,
-                patch: int = 16, eps: float = 1e-6):
+                patch: int = 16, eps: float = 1e-6, forced=None, trace=None):
     """VisionTransformer.forward (vision_transformer.py:818-848), non-distilled, eval mode,
-    from a flat state-dict ``sd`` with the reference's key layout."""
+    from a flat state-dict ``sd`` with the reference's key layout.
+    ``forced`` (a list of per-block routing decisions) / ``trace``: see moe_forward's ``forced_idx``."""
     x = F.conv2d(images, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=patch)
     x = x.flatten(2).transpose(1, 2)
     x = torch.cat((sd["cls_token"].expand(x.shape[0], -1, -1), x), dim=1)
@@ -321,7 +338,7 @@ def vit_forward(images, sd: dict, depth: int, num_heads: int, k: int, residual_m
     for i in range(depth):
         pre = f"blocks.{i}."
         p = {key[len(pre):]: v for key, v in sd.items() if key.startswith(pre)}
-        x = block_forward(x, p, num_heads, k, residual_moe, eps)
+        x = block_forward(x, p, num_heads, k, residual_moe, eps, forced_idx=None if forced is None else forced[i], trace=trace)
     d = x.shape[-1]
     x = F.layer_norm(x, (d,), sd["norm.weight"], sd["norm.bias"], eps)
     return F.linear(x[:, 0], sd["head.weight"], sd["head.bias"])

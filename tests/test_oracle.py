@@ -258,3 +258,28 @@ def test_block_forward_residual_against_the_reference_fixture(golden_dir):
     assert 0.3 <= float(m1[..., 0].mean()) <= 0.7
     assert np.array_equal(np.rint(g["eval_moe_mask"])[..., 0] + np.rint(g["eval_moe_mask"])[..., 1], np.ones(x.shape[:2]))
     assert torch.allclose(y, ref, rtol=0, atol=2e-5), float((y - ref).abs().max())
+
+
+def test_forced_routing_is_the_identity_on_the_oracles_own_decisions_and_traces_flips():
+    """``forced_idx`` (the bench's same-routing comparison): forcing the oracle's own decisions changes nothing; forcing another
+    expert for some tokens changes exactly those tokens' rows, and the trace reports them with the logit gap they gave up."""
+    g = torch.Generator().manual_seed(4)
+    T, d, h, E = 300, 32, 64, 4
+    x = torch.randn(T, d, generator=g)
+    wg, bg = torch.randn(E, d, generator=g) * 0.3, torch.zeros(E)
+    w1, b1 = torch.randn(E, h, d, generator=g) * 0.1, torch.zeros(E, h)
+    w2, b2 = torch.randn(E, d, h, generator=g) * 0.1, torch.zeros(E, d)
+    own = mo.moe_forward(x, wg, bg, w1, b1, w2, b2, 1)
+    tr = []
+    same = mo.moe_forward(x, wg, bg, w1, b1, w2, b2, 1, forced_idx=own.idx, trace=tr)
+    assert torch.equal(same.out, own.out) and tr == [{"tokens": T, "flips": 0, "max_margin": 0.0}]
+    forced = own.idx.clone()
+    forced[::50] = (forced[::50] + 1) % E
+    tr = []
+    other = mo.moe_forward(x, wg, bg, w1, b1, w2, b2, 1, forced_idx=forced, trace=tr)
+    changed = (other.out != own.out).any(1)
+    assert changed[::50].all() and int(changed.sum()) == len(range(0, T, 50))
+    assert tr[0]["flips"] == len(range(0, T, 50)) and tr[0]["max_margin"] > 0
+    logits = mo.router_logits(x, wg, bg)
+    gap = (logits.max(1).values - logits.gather(1, forced).squeeze(1))[::50].max()
+    assert abs(tr[0]["max_margin"] - float(gap)) < 1e-6
