@@ -361,12 +361,15 @@ def main():
                 and args.compute_dtype in ("f16", "bf16")):
             import subprocess
             env = dict(os.environ, SLIMMOE_LIB=clock_lib)
+            cp = None
             try:
                 cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_clock.py"), str(args.clock_seconds),
                                      str(args.batch)], env=env, capture_output=True, text=True, timeout=120)
                 clk = json.loads(cp.stdout.strip().splitlines()[-1])
             except Exception as exc:   # the probe is a report, never a reason to lose the bench line
-                clk = {"error": f"{type(exc).__name__}: {exc}"}
+                clk = {"error": f"{type(exc).__name__}: {exc}", "child_stderr_tail": (cp.stderr[-400:] if cp is not None else "")}
+                print(f"bench.py: clock probe failed ({clk['error']}); is libslimmoe_hip_clock.so built from these sources "
+                      "(make -C slim-switch-moe-vit_amd/csrc clock)?", file=sys.stderr)
             roofline["clock_probe"] = clk
             per_mhz = 1024 * 1024 * 1e6 / 1e12          # TFLOP/s per MHz: 1,024 SIMDs x 1,024 FLOP per cycle (2.4 GHz -> 2,517)
             f1, f2, ff = agg.get("grouped_gemm_fc1"), agg.get("grouped_gemm_fc2"), agg.get("expert_ffn")
