@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--experts", type=int, default=8, help="global number of experts")
     ap.add_argument("--compute-dtype", default=os.environ.get("SLIMMOE_COMPUTE_DTYPE", "f16"), choices=["f16", "bf16", "f32"])
-    ap.add_argument("--ep-chunks", type=int, default=1)
+    ap.add_argument("--ep-chunks", type=int, default=0,
+                    help="expert parallel only: token chunks per MoE layer (chunk c + 1's all-to-all travels under chunk c's expert "
+                         "GEMMs; 1 = off; 0 = timed together with --ep-micro-batches during warm-up)")
     ap.add_argument("--ep-micro-batches", type=int, default=0,
                     help="expert parallel only: micro-batches of the local batch interleaved through the model so that "
                          "count read-backs and all-to-alls of one run under the other's compute (1 = off; 0 = time "
@@ -88,7 +90,7 @@ def build_model(args, world, rank, device):
             sl = slice(rank * E_local, (rank + 1) * E_local)
             blk.mlp.experts.htoh4.weight.copy_(w1[sl]); blk.mlp.experts.htoh4.bias.zero_()
             blk.mlp.experts.h4toh.weight.copy_(w2[sl]); blk.mlp.experts.h4toh.bias.zero_()
-            blk.mlp.ep_chunks = args.ep_chunks
+            blk.mlp.ep_chunks = max(1, args.ep_chunks)
             blk.mlp.force_ep = bool(getattr(args, "force_ep", False))
             # the head is zero-initialised in the reference (vision_transformer.py:859-861); give it signal
         torch.nn.init.trunc_normal_(model.head.weight, std=0.02, a=-2, b=2, generator=g)
@@ -228,25 +230,39 @@ def main():
             torch.cuda.synchronize(device)
 
     ep_tuning = None
-    if (world > 1 or args.force_ep) and args.ep_micro_batches == 0:
-        # pipeline depth: fewer micro-batches = bigger, more efficient kernels; more = more transfer hidden.  Which
-        # wins depends on the xGMI rate at this world size, so measure (every rank takes the same, all-reduced, decision)
+    moes = [blk.mlp for blk in model.blocks]
+    if (world > 1 or args.force_ep) and (args.ep_micro_batches == 0 or args.ep_chunks == 0):
+        # pipeline shape: micro-batches of the local batch interleaved through the whole model (count read-backs and all-to-alls of
+        # one run under the other's attention / GEMMs) x token chunks inside a MoE layer (chunk c + 1 travels under chunk c's expert
+        # GEMMs).  Fewer / bigger = more efficient kernels; more = more transfer hidden.  Which wins depends on the xGMI rate at this
+        # world size, so measure (every rank takes the same, all-reduced, decision)
         ep_tuning = {}
-        for n in (1, 2, 3):
-            model.ep_micro_batches = n
-            for _ in range(2):
-                step()
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                step()
-            fence()
-            t = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device=device)
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ep_tuning[n] = round(float(t.item()) * 1e3, 3)
-        args.ep_micro_batches = min(ep_tuning, key=ep_tuning.get)
+        mbs = (1, 2, 3) if args.ep_micro_batches == 0 else (args.ep_micro_batches,)
+        chs = (1, 2, 3) if args.ep_chunks == 0 else (args.ep_chunks,)
+        for n in mbs:
+            for c in chs:
+                if n * c > 4:
+                    continue
+                model.ep_micro_batches = n
+                for m in moes:
+                    m.ep_chunks = c
+                for _ in range(2):
+                    step()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    step()
+                fence()
+                t = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device=device)
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ep_tuning[f"{n}x{c}"] = round(float(t.item()) * 1e3, 3)
+        best = min(ep_tuning, key=ep_tuning.get)
+        args.ep_micro_batches, args.ep_chunks = (int(v) for v in best.split("x"))
         model.ep_micro_batches = args.ep_micro_batches
+        for m in moes:
+            m.ep_chunks = args.ep_chunks
+    args.ep_chunks = max(1, args.ep_chunks)
     for _ in range(args.warmup):
         step()
     fence()
@@ -301,10 +317,12 @@ def main():
         ep_info = {"a2a_payload_mb_per_rank": round(rows * 768 * 2 / 1e6, 1), "a2a_ms": round(a2a_ms, 4),
                    "a2a_gb_s_per_link": round(per_peer / (a2a_ms * 1e-3) / 1e9, 1), "link_peak_gb_s_bidir": 153,
                    "a2a_per_step": 24, "a2a_ms_per_step_if_exposed": round(24 * a2a_ms, 3),
-                   "micro_batches": args.ep_micro_batches, "micro_batch_tuning_ms_per_step": ep_tuning}
+                   "micro_batches": args.ep_micro_batches, "chunks_per_layer": args.ep_chunks,
+                   "pipeline_tuning_ms_per_step (micro-batches x chunks)": ep_tuning}
 
     if ep_info is None and ep_tuning is not None:
-        ep_info = {"micro_batches": args.ep_micro_batches, "micro_batch_tuning_ms_per_step": ep_tuning}
+        ep_info = {"micro_batches": args.ep_micro_batches, "chunks_per_layer": args.ep_chunks,
+                   "pipeline_tuning_ms_per_step (micro-batches x chunks)": ep_tuning}
 
     # ---- per-kernel accounting from the HIP events recorded inside the timed region --------------------
     agg = {}
@@ -428,7 +446,7 @@ def main():
             "config": {"workload": f"ViT-B/16 Switch-MoE E={args.experts} top-1, 224^2, batch {args.batch}/GPU, "
                                    f"full eval forward (12 blocks: attention + MoE MLP), fp16 autocast",
                        "global_batch": args.batch * world, "tokens_per_image": 197, "compute_streams": args.compute_streams,
-                       "parallelism": ("single" if not args.force_ep else f"single (EP code path forced, {args.ep_micro_batches} interleaved micro-batches)") if world == 1 else f"ep{world} (experts/{world} per rank, all-to-all, {args.ep_micro_batches} interleaved micro-batches)"},
+                       "parallelism": ("single" if not args.force_ep else f"single (EP code path forced, {args.ep_micro_batches} interleaved micro-batches x {args.ep_chunks} chunks per layer)") if world == 1 else f"ep{world} (experts/{world} per rank, all-to-all, {args.ep_micro_batches} interleaved micro-batches x {args.ep_chunks} chunks per layer)"},
             "roofline": roofline,
             "kernels": kernels,
         }

@@ -423,13 +423,18 @@ def ep_forward(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.T
     return drain(ep_forward_steps(mod, x, cd, residual, norm))
 
 
+def _ln_fusable(next_norm, x, payload_dtype, k) -> bool:
+    d = x.shape[1]
+    return (next_norm is not None and x.dtype == torch.float32 and payload_dtype in (torch.float16, torch.bfloat16) and k <= 4
+            and d % 8 == 0 and d <= 1024 and next_norm.bias is not None)
+
+
 def _combine_maybe_ln(back, inv_pos, score, T, k, x, residual, next_norm):
     """The return side's last kernel: gather + combine (+ residual); with ``next_norm`` also that LayerNorm of the produced rows
     (16 bit) in the same pass -> (out, xn) instead of out."""
     from . import ops
     d = x.shape[1]
-    if (next_norm is not None and x.dtype == torch.float32 and back.dtype in (torch.float16, torch.bfloat16) and k <= 4
-            and d % 8 == 0 and d <= 1024 and next_norm.bias is not None):
+    if _ln_fusable(next_norm, x, back.dtype, k):
         return ops.gather_combine_ln(back, inv_pos, score, T, k, residual, next_norm.weight.detach().float(),
                                      next_norm.bias.detach().float(), next_norm.eps, torch.float16)
     out = torch.empty((T, d), dtype=x.dtype, device=x.device)
@@ -533,12 +538,21 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
         return _combine_maybe_ln(back, plans[0][3], score, T, k, x, residual, next_norm)
     if out is None:
         out = torch.empty((T, d), dtype=x.dtype, device=x.device)
+    # several chunks: the next block's LayerNorm still rides on every chunk's combine (rows are independent) when every chunk
+    # brought rows back -- a property of the routing, known on the host from the counts
+    fuse_ln = (_ln_fusable(next_norm, x, cd, k) and T > 0 and all(r[1].shape[0] > 0 for r in returning)
+               and all(t1 > t0 for (t0, t1) in bounds))
+    xn = torch.empty((T, d), dtype=torch.float16, device=x.device) if fuse_ln else None
     for c, (t0, t1) in enumerate(bounds):
         y, back, work2 = returning[c]
         work2.wait()
         if t1 > t0:
             inv_pos = plans[c][3]
-            if back.shape[0] == 0:  # every entry of the chunk was dropped
+            if fuse_ln:
+                ops.gather_combine_ln(back, inv_pos, score[t0:t1], t1 - t0, k, None if residual is None else residual[t0:t1],
+                                      next_norm.weight.detach().float(), next_norm.bias.detach().float(), next_norm.eps,
+                                      torch.float16, out=out[t0:t1], xn=xn[t0:t1])
+            elif back.shape[0] == 0:  # every entry of the chunk was dropped
                 if residual is not None:
                     out[t0:t1].copy_(residual[t0:t1])
                 else:
@@ -546,4 +560,4 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
             else:
                 ops.gather_combine(back, inv_pos, score[t0:t1], t1 - t0, k, x.dtype, out=out[t0:t1],
                                    residual=None if residual is None else residual[t0:t1])
-    return out
+    return (out, xn) if fuse_ln else out

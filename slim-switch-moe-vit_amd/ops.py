@@ -579,8 +579,10 @@ def gather_combine(y: torch.Tensor, inv_pos: torch.Tensor, score: torch.Tensor, 
 
 def gather_combine_ln(y: torch.Tensor, inv_pos: torch.Tensor, score: torch.Tensor, T: int, k: int,
                       residual: Optional[torch.Tensor], ln_weight: torch.Tensor, ln_bias: torch.Tensor, eps: float,
-                      xn_dtype: torch.dtype = torch.float16):
-    """(out f32 [T,d], xn [T,d] 16-bit): out[t] = residual[t] + sum_j score[t,j] y[inv_pos[t k + j]]; xn = LayerNorm(out)."""
+                      xn_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None,
+                      xn: Optional[torch.Tensor] = None):
+    """(out f32 [T,d], xn [T,d] 16-bit): out[t] = residual[t] + sum_j score[t,j] y[inv_pos[t k + j]]; xn = LayerNorm(out).
+    ``out`` / ``xn``: write into these (row slices of a layer's buffers: one call per token chunk)."""
     _chk(y, "y", ndim=2)
     _chk(inv_pos, "inv_pos", torch.int64, align=8)
     _chk(score, "score", torch.float32, align=4)
@@ -589,8 +591,16 @@ def gather_combine_ln(y: torch.Tensor, inv_pos: torch.Tensor, score: torch.Tenso
     d = y.shape[1]
     if residual is not None:
         _chk(residual, "residual", torch.float32, 2)
-    out = torch.empty((T, d), dtype=torch.float32, device=y.device)
-    xn = torch.empty((T, d), dtype=xn_dtype, device=y.device)
+    if out is None:
+        out = torch.empty((T, d), dtype=torch.float32, device=y.device)
+    else:
+        _chk(out, "out", torch.float32, 2)
+    if xn is None:
+        xn = torch.empty((T, d), dtype=xn_dtype, device=y.device)
+    else:
+        _chk(xn, "xn", xn_dtype, 2)
+    if tuple(out.shape) != (T, d) or tuple(xn.shape) != (T, d):
+        raise RuntimeError("gather_combine_ln: out / xn must be [T, d]")
     with _timed("combine_ln", {"bytes": T * d * (k * y.element_size() + 8 + 2)}, y):
         rc = _lib.load().smoe_gather_combine_ln(_ptr(y), dtype_code(y.dtype), _ptr(inv_pos), _ptr(score), T, k, d, _ptr(residual),
                                                 _ptr(out), _ptr(ln_weight), _ptr(ln_bias), float(eps), _ptr(xn), dtype_code(xn_dtype),

@@ -283,6 +283,16 @@ def test_expert_parallel_micro_batch_pipeline_equals_plain_forward():
             assert (got - ep1).abs().max().item() <= 1e-3
             tail = idxn[-1].reshape(-1)   # last micro-batch's routing of the last block = tail of the whole batch's
             assert torch.equal(tail, idx1[-1].reshape(-1)[-tail.numel():])
+        # token chunks inside a MoE layer (chunk c + 1's exchange under chunk c's expert GEMMs): every row's arithmetic is its own, so
+        # the chunked forward is the un-chunked one BIT FOR BIT -- also with the next block's LayerNorm riding on each chunk's combine
+        for chunks in (2, 3):
+            for blk in model.blocks:
+                blk.mlp.ep_chunks = chunks
+            got, idxc = run(True, 1)
+            assert torch.equal(got, ep1), chunks
+            assert all(torch.equal(a, b) for a, b in zip(idxc, idx1))
+        for blk in model.blocks:
+            blk.mlp.ep_chunks = 1
         # against the single-rank path the exchanged rows round differently (16-bit payload), so a token that sits on a
         # routing boundary may flip: every difference is attributed, end to end (see _flip_attribution)
         model.ep_micro_batches = 1
