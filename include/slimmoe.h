@@ -426,12 +426,15 @@ int smoe_adamw_step(float* p, const void* g, int g_dtype, float* m, float* v, in
  * AdamW play this role upstream).  tab = int64 [5][n_tensors] in device memory: rows p, g, exp_avg, exp_avg_sq (addresses) and
  * n (elements); the sumsq form reads rows g and n only.  hyp = f32 [2][n_tensors]: lr, weight_decay.  blk = int32 [2][n_blocks]:
  * the tensor of workgroup b and the 16,384-element block inside it, blocks in tensor order; partial[b] receives block b's sum.
- * Same arithmetic and the same partial sums as the single-tensor forms.                                                      */
+ * Same arithmetic and the same partial sums as the single-tensor forms.  shadow (may be NULL) = int64 [2][n_tensors]: the address of
+ * a 16-bit image of parameter t (0 = none) and its dtype code (SMOE_F16 / SMOE_BF16): the step writes the updated parameter there
+ * as well, so the MFMA operand copies the next forward reads need no cast pass of their own (autocast re-casts every weight on
+ * every forward upstream; engine.py:52-53).  A step skipped by found_inf leaves parameter and image untouched.               */
 int smoe_grad_sumsq_multi(const int64_t* tab, int n_tensors, const int32_t* blk, int64_t n_blocks, int g_dtype,
                           const float* inv_scale, float* partial, float* found_inf, void* stream);
 int smoe_adamw_step_multi(const int64_t* tab, const float* hyp, int n_tensors, const int32_t* blk, int64_t n_blocks,
                           int g_dtype, float beta1, float beta2, float eps, const float* step, const float* grad_mult,
-                          const float* found_inf, void* stream);
+                          const float* found_inf, const int64_t* shadow, void* stream);
 int smoe_amp_update(float* scale, float* growth_tracker, const float* found_inf, float growth_factor, float backoff_factor,
                     int growth_interval, void* stream);
 int smoe_step_advance(float* step, const float* found_inf, void* stream);

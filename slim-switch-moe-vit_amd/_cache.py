@@ -50,6 +50,52 @@ class StreamCache:
         return t
 
 
+    def peek(self, key: Hashable, version):
+        """The entry's tensor if it is current for ``version`` (no rebuild, no stream bookkeeping), else None."""
+        hit = self._c.get(key)
+        return hit[1] if hit is not None and hit[0] == version else None
+
+    def refresh(self, key: Hashable, tensor: torch.Tensor, version) -> None:
+        """``tensor`` (the entry's own, updated IN PLACE by a kernel enqueued on the current stream -- the optimizer's fused step
+        writes the 16-bit weight images together with the weights) is now current for ``version``: re-stamp the entry with that
+        version and an event behind the producing kernel."""
+        hit = self._c.get(key)
+        if hit is None or hit[1] is not tensor:
+            return
+        ev = sid = None
+        if tensor.is_cuda:
+            st = torch.cuda.current_stream(tensor.device)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            sid = st.cuda_stream
+        self._c[key] = (version, tensor, ev, sid)
+
+
+# parameter -> the 16-bit image a fused optimizer step may refresh in place: id(parameter) -> (weakref(parameter), cache, key).
+# Registered by whoever builds the image (FMoELinear.weight_as, vit._HalfCache.get); a dead parameter's entry is dropped on lookup.
+_SHADOWS = {}
+
+
+def register_shadow(p: torch.Tensor, cache: "StreamCache", key: Hashable) -> None:
+    _SHADOWS[id(p)] = (weakref.ref(p), cache, key)
+
+
+def shadow_of(p: torch.Tensor):
+    """(cache, key, image) of the plain 16-bit image of ``p`` that is CURRENT right now (same shape, contiguous), or None."""
+    ent = _SHADOWS.get(id(p))
+    if ent is None:
+        return None
+    ref, cache, key = ent
+    if ref() is not p:
+        _SHADOWS.pop(id(p), None)
+        return None
+    t = cache.peek(key, param_version(p))
+    if (t is None or t.shape != p.shape or not t.is_contiguous() or t.device != p.device
+            or t.dtype not in (torch.float16, torch.bfloat16)):
+        return None
+    return cache, key, t
+
+
 def param_version(p: torch.Tensor):
     return (p._version, p.data_ptr(), p.dtype)
 

@@ -93,7 +93,7 @@ SIGNATURES = {
                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_grad_sumsq_multi": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_adamw_step_multi": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, ctypes.c_float, ctypes.c_float,
-                                      ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_amp_update": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_int, c_void_p]),
     "smoe_step_advance": (c_int, [c_void_p, c_void_p, c_void_p]),
     "smoe_unique_id_bytes": (c_int, []),

@@ -77,10 +77,13 @@ __global__ __launch_bounds__(OPT_THREADS) void grad_sumsq_multi_kernel(const int
 }
 
 // elements [begin, end) of one parameter, `stride` apart per pass (begin = this thread's first element, a multiple of 4)
+// sh (optional): a 16-bit image of the parameter (the MFMA operand copy the forward reads), refreshed in the same pass -- the step
+// then needs no separate f32 -> 16-bit cast of every weight (4 bytes read + 2 written per element) before the next forward
 template <typename GT>
 __device__ __forceinline__ void adamw_range(float* __restrict__ p, const GT* __restrict__ g, float* __restrict__ m,
                                             float* __restrict__ v, int64_t begin, int64_t end, int64_t stride, int64_t n, float lr,
-                                            float b1, float b2, float eps, float wd, float t, float gm) {
+                                            float b1, float b2, float eps, float wd, float t, float gm, void* sh = nullptr,
+                                            int sh_dtype = SMOE_F16) {
   const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
   const float step_size = lr / bc1, decay = 1.0f - lr * wd;
   for (int64_t i = begin; i < end; i += stride) {
@@ -100,6 +103,15 @@ __device__ __forceinline__ void adamw_range(float* __restrict__ p, const GT* __r
       *reinterpret_cast<f32x4*>(p + i) = pv;
       *reinterpret_cast<f32x4*>(m + i) = mv;
       *reinterpret_cast<f32x4*>(v + i) = vv;
+      if (sh) {
+        if (sh_dtype == SMOE_F16) {
+          f16x4 h; h[0] = (f16)pv[0]; h[1] = (f16)pv[1]; h[2] = (f16)pv[2]; h[3] = (f16)pv[3];
+          *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(sh) + i) = h;
+        } else {
+          s16x4 h; h[0] = (short)f32_to_bf16(pv[0]); h[1] = (short)f32_to_bf16(pv[1]); h[2] = (short)f32_to_bf16(pv[2]); h[3] = (short)f32_to_bf16(pv[3]);
+          *reinterpret_cast<s16x4*>(reinterpret_cast<bf16_bits*>(sh) + i) = h;
+        }
+      }
     } else {
       for (int64_t j = i; j < n; ++j) {
         float gq;
@@ -110,6 +122,10 @@ __device__ __forceinline__ void adamw_range(float* __restrict__ p, const GT* __r
         float pj = p[j] * decay, mj = m[j] + (1.0f - b1) * (gq - m[j]), vj = fmaf(v[j], b2, (1.0f - b2) * gq * gq);
         pj -= step_size * (mj / (sqrtf(vj) / bc2_sqrt + eps));
         p[j] = pj; m[j] = mj; v[j] = vj;
+        if (sh) {
+          if (sh_dtype == SMOE_F16) reinterpret_cast<f16*>(sh)[j] = (f16)pj;
+          else reinterpret_cast<bf16_bits*>(sh)[j] = f32_to_bf16(pj);
+        }
       }
     }
   }
@@ -133,7 +149,8 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_multi_kernel(const int64_t*
                                                                   int n_t, const int32_t* __restrict__ blk, int64_t n_blocks,
                                                                   float b1, float b2, float eps, const float* __restrict__ step,
                                                                   const float* __restrict__ grad_mult,
-                                                                  const float* __restrict__ found_inf) {
+                                                                  const float* __restrict__ found_inf,
+                                                                  const int64_t* __restrict__ shadow) {
   if (found_inf && *found_inf != 0.f) return;
   const int t = blk[blockIdx.x];
   if (t < 0 || t >= n_t) return;
@@ -143,7 +160,8 @@ __global__ __launch_bounds__(OPT_THREADS) void adamw_multi_kernel(const int64_t*
   adamw_range<GT>(reinterpret_cast<float*>(tab[t]), reinterpret_cast<const GT*>(tab[(int64_t)n_t + t]),
                   reinterpret_cast<float*>(tab[2ll * n_t + t]), reinterpret_cast<float*>(tab[3ll * n_t + t]),
                   base + threadIdx.x * 4, end, OPT_THREADS * 4, n, hyp[t], b1, b2, eps, hyp[n_t + t], *step,
-                  grad_mult ? *grad_mult : 1.0f);
+                  grad_mult ? *grad_mult : 1.0f, shadow ? reinterpret_cast<void*>(shadow[t]) : nullptr,
+                  shadow ? (int)shadow[(int64_t)n_t + t] : SMOE_F16);
 }
 
 __global__ void amp_update_kernel(float* scale, float* growth_tracker, const float* found_inf, float growth, float backoff,
@@ -239,16 +257,16 @@ extern "C" int smoe_grad_sumsq_multi(const int64_t* tab, int n_tensors, const in
 
 extern "C" int smoe_adamw_step_multi(const int64_t* tab, const float* hyp, int n_tensors, const int32_t* blk, int64_t n_blocks,
                                      int g_dtype, float beta1, float beta2, float eps, const float* step, const float* grad_mult,
-                                     const float* found_inf, void* stream) {
+                                     const float* found_inf, const int64_t* shadow, void* stream) {
   SMOE_REQUIRE(n_tensors >= 0 && n_blocks >= 0 && n_blocks < (1ll << 31) && smoe_dtype_ok(g_dtype), "smoe_adamw_step_multi: bad arguments");
   if (n_blocks == 0) return 0;
   SMOE_REQUIRE(tab && hyp && blk && step, "smoe_adamw_step_multi: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)n_blocks), block(OPT_THREADS);
   switch (g_dtype) {
-    case SMOE_F32: hipLaunchKernelGGL(adamw_multi_kernel<float>, grid, block, 0, s, tab, hyp, n_tensors, blk, n_blocks, beta1, beta2, eps, step, grad_mult, found_inf); break;
-    case SMOE_F16: hipLaunchKernelGGL(adamw_multi_kernel<f16>, grid, block, 0, s, tab, hyp, n_tensors, blk, n_blocks, beta1, beta2, eps, step, grad_mult, found_inf); break;
-    default: hipLaunchKernelGGL(adamw_multi_kernel<bf16_bits>, grid, block, 0, s, tab, hyp, n_tensors, blk, n_blocks, beta1, beta2, eps, step, grad_mult, found_inf); break;
+    case SMOE_F32: hipLaunchKernelGGL(adamw_multi_kernel<float>, grid, block, 0, s, tab, hyp, n_tensors, blk, n_blocks, beta1, beta2, eps, step, grad_mult, found_inf, shadow); break;
+    case SMOE_F16: hipLaunchKernelGGL(adamw_multi_kernel<f16>, grid, block, 0, s, tab, hyp, n_tensors, blk, n_blocks, beta1, beta2, eps, step, grad_mult, found_inf, shadow); break;
+    default: hipLaunchKernelGGL(adamw_multi_kernel<bf16_bits>, grid, block, 0, s, tab, hyp, n_tensors, blk, n_blocks, beta1, beta2, eps, step, grad_mult, found_inf, shadow); break;
   }
   SMOE_CHECK_LAUNCH("smoe_adamw_step_multi");
   return 0;

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._cache import StreamCache, param_version
+from ._cache import StreamCache, param_version, register_shadow
 
 _COMPUTE_DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
 
@@ -54,14 +54,21 @@ class FMoELinear(nn.Module):
         w = self.weight
         if w.dtype == dtype:
             return w.detach()
-        return self._shadow.get((dtype, w.device), param_version(w), lambda: ops.cast(w.detach().contiguous(), dtype))
+        key = (dtype, w.device)
+        if w.dtype == torch.float32 and w.is_contiguous():
+            register_shadow(w, self._shadow, key)      # optim.AdamW refreshes this image in its own pass
+        return self._shadow.get(key, param_version(w), lambda: ops.cast(w.detach().contiguous(), dtype))
 
     def weight_t_as(self, dtype: torch.dtype) -> torch.Tensor:
         """``weight.transpose(1, 2)`` as a contiguous [E, in, out] tensor in ``dtype`` -- the operand of the dgrad GEMM
         (it contracts over ``out``); cached like ``weight_as``, made from the master weight in one HIP pass."""
         w = self.weight
         if w.is_cuda and w.shape[1] % 64 == 0 and w.shape[2] % 64 == 0:
-            make = lambda: ops.transpose_cast(w.detach().contiguous(), dtype)
+            # from the 16-bit image when it is current (the optimizer keeps it so in training: half the bytes to read; the same
+            # values -- rounding commutes with the transpose), else from the master weight
+            def make():
+                src = self._shadow.peek((dtype, w.device), param_version(w)) if w.dtype != dtype else None
+                return ops.transpose_cast(src if src is not None else w.detach().contiguous(), dtype)
         else:
             make = lambda: w.detach().transpose(1, 2).to(dtype).contiguous()
         return self._shadow.get(("t", dtype, w.device), param_version(w), make)

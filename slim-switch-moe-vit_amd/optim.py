@@ -22,7 +22,13 @@ from typing import Iterable, Optional
 
 import torch
 
+import os
+
 from . import _lib, ops
+from ._cache import param_version, shadow_of
+
+# the fused step also writes the 16-bit operand images of the weights it updates (A/B: SLIMMOE_ADAMW_SHADOW=0)
+SHADOW_STEP = os.environ.get("SLIMMOE_ADAMW_SHADOW", "1") != "0"
 
 
 def _hip_ok(p: torch.Tensor) -> bool:
@@ -119,6 +125,7 @@ class AdamW(torch.optim.Optimizer):
                 loss = closure()
         lib = None
         advanced = set()
+        refreshed = []   # [(parameter, (cache, key, image))]: 16-bit images the fused step wrote
         batches = {}   # (device, grad dtype, betas, eps) -> [(p, g, exp_avg, exp_avg_sq, lr, wd)]: one launch each
         for group in self.param_groups:
             lr, (b1, b2), eps, wd = group["lr"], group["betas"], group["eps"], group["weight_decay"]
@@ -165,14 +172,25 @@ class AdamW(torch.optim.Optimizer):
                                   [it[2].data_ptr() for it in items], [it[3].data_ptr() for it in items],
                                   [it[0].numel() for it in items]], dev)
             hyp = torch.tensor([[it[4] for it in items], [it[5] for it in items]], dtype=torch.float32, device=dev)
+            # 16-bit operand images of the parameters that are current NOW (the modules' weight shadows): written in the same pass,
+            # so the next forward finds them current (no f32 -> 16-bit cast pass over every weight per step)
+            shadows = [shadow_of(it[0]) if SHADOW_STEP else None for it in items]
+            sh_tab = None
+            if any(sh is not None for sh in shadows):
+                sh_tab = _pointer_table([[sh[2].data_ptr() if sh is not None else 0 for sh in shadows],
+                                         [ops.dtype_code(sh[2].dtype) if sh is not None else 0 for sh in shadows]], dev)
             rc = lib.smoe_adamw_step_multi(tab.data_ptr(), hyp.data_ptr(), len(items), blk.data_ptr(), sum(nb), ops.dtype_code(gdt),
-                                           b1, b2, eps, step_t.data_ptr(), ops._ptr(grad_mult), ops._ptr(found_inf), stream)
+                                           b1, b2, eps, step_t.data_ptr(), ops._ptr(grad_mult), ops._ptr(found_inf), ops._ptr(sh_tab),
+                                           stream)
             _lib.check(rc, "smoe_adamw_step_multi")
+            refreshed.extend((it[0], sh) for it, sh in zip(items, shadows) if sh is not None)
         # The kernels wrote the parameters through raw pointers: autograd's version counters did not move, and every derived
         # tensor keyed on them (the 16-bit weight shadows of the expert GEMMs and of the dense projections, the zero-row
         # constants) would go on serving the OLD weights.  Bump the versions, as an in-place torch op would have.
         for items in batches.values():
             _bump_versions([it[0] for it in items])
+        for p, (cache, key, img) in refreshed:        # the images written above belong to the NEW version of their parameter
+            cache.refresh(key, img, param_version(p))
         return loss
 
 

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ._cache import StreamCache, param_version
+from ._cache import StreamCache, param_version, register_shadow
 
 _MODEL_REGISTRY: Dict[str, Callable] = {}
 _LN_DIMS = (192, 384, 768, 1024)
@@ -130,6 +130,8 @@ class _HalfCache(StreamCache):
                 from . import ops
                 return ops.cast(q, torch.float16)
             return q.half()
+        if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous():
+            register_shadow(p, self, id(p))            # optim.AdamW refreshes this image in its own pass
         return super().get(id(p), param_version(p), make)
 
     def get_padded(self, p: torch.Tensor, rows: int, dtype) -> torch.Tensor:
@@ -147,8 +149,13 @@ class _HalfCache(StreamCache):
         over N), made in one HIP pass from the f32 master (N, K multiples of 64)."""
         from . import ops
         N = p.shape[0]
-        return super().get(("t", id(p)), param_version(p),
-                            lambda: ops.transpose_cast(p.detach().float().reshape(1, N, -1).contiguous(), torch.float16))
+
+        def make():   # from the current fp16 image when there is one (half the bytes; same values), else from the master
+            src = self.peek(id(p), param_version(p))
+            if src is None:
+                src = p.detach().float()
+            return ops.transpose_cast(src.reshape(1, N, -1).contiguous(), torch.float16)
+        return super().get(("t", id(p)), param_version(p), make)
 
     def get_t_padded(self, p: torch.Tensor, rows: int) -> torch.Tensor:
         """``get_t`` of ``p [N, K]`` with zero rows appended up to ``rows`` (a multiple of 64): ``[1, K, rows]`` fp16 -- the

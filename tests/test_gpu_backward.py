@@ -506,3 +506,53 @@ def test_zero_group_fold_equals_the_index_add_composition(E, Z, adt):
     assert torch.allclose(db2, ref_b2, rtol=1e-6, atol=1e-6) and torch.allclose(db1, ref_b1, rtol=1e-6, atol=1e-6)
     only2, none1 = ops.zero_group_fold(cs2, None, A, offsets, gmap, E, dW2.clone(), want_b1=False)
     assert none1 is None and torch.equal(only2, db2)
+
+
+def test_fused_adamw_step_keeps_the_16_bit_weight_images_current():
+    """optim.AdamW writes the 16-bit operand image of every weight it updates in the same pass (smoe_adamw_step_multi's `shadow`
+    table): after the step the modules' caches serve the SAME tensors, already equal to the rounded new weights -- no cast pass --
+    and the transposed images are re-made from them.  A step skipped by found_inf leaves weights and images untouched."""
+    from slim_switch_moe_vit_amd import optim as smo
+    from slim_switch_moe_vit_amd._cache import param_version
+    torch.manual_seed(0)
+    mod = sm.FMoETransformerMLP(4, 64, 128, torch.nn.GELU(), top_k=1).to(DEV).train()
+    lin = torch.nn.Linear(64, 64).to(DEV)
+    from slim_switch_moe_vit_amd import vit
+    hc = vit._HalfCache()
+    opt = smo.AdamW(list(mod.parameters()) + list(lin.parameters()), lr=1e-2, weight_decay=0.05)
+    x = torch.randn(300, 64, generator=_gen(1)).to(DEV)
+
+    def backward():
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = mod(x.requires_grad_(True))
+        (y.float().square().mean() + (lin(x) ** 2).mean()).backward()
+    backward()
+    ex = mod.experts
+    w1, w2 = ex.htoh4.weight, ex.h4toh.weight
+    img1, img2, imgl = ex.htoh4.weight_as(torch.float16), ex.h4toh.weight_as(torch.float16), hc.get(lin.weight)
+    t1 = ex.htoh4.weight_t_as(torch.float16)
+    before = w1.detach().clone()
+    opt.step()
+    assert not torch.equal(w1, before)
+    for w, img, cache, key in ((w1, img1, ex.htoh4._shadow, (torch.float16, w1.device)),
+                               (w2, img2, ex.h4toh._shadow, (torch.float16, w2.device)), (lin.weight, imgl, hc, id(lin.weight))):
+        assert cache.peek(key, param_version(w)) is img, "the image is current for the new version, and the same tensor"
+        assert torch.equal(img, w.detach().half()), "... holding the rounded NEW weights"
+    assert ex.htoh4.weight_as(torch.float16) is img1 and hc.get(lin.weight) is imgl
+    t1_new = ex.htoh4.weight_t_as(torch.float16)
+    assert t1_new is not t1 and torch.equal(t1_new, w1.detach().half().transpose(1, 2).contiguous())
+    # a skipped step (non-finite gradients): nothing moves, the images stay what the weights are
+    backward()
+    snap = w1.detach().clone()
+    opt.step(found_inf=torch.ones(1, device=DEV))
+    assert torch.equal(w1, snap) and torch.equal(ex.htoh4.weight_as(torch.float16), snap.half())
+    # switched off: the images go stale with the step and are re-cast on their next use (same values)
+    smo.SHADOW_STEP = False
+    try:
+        backward()
+        opt.step()
+        assert ex.htoh4._shadow.peek((torch.float16, w1.device), param_version(w1)) is None
+        assert torch.equal(ex.htoh4.weight_as(torch.float16), w1.detach().half())
+    finally:
+        smo.SHADOW_STEP = True

@@ -241,24 +241,41 @@ def test_gate_module_cpu_composition_against_the_reference_gate_fixture(golden_d
         with torch.no_grad():
             gate.head[1].weight.copy_(torch.from_numpy(g["w"])); gate.head[1].bias.copy_(torch.from_numpy(g["b"]))
         return gate
+    # Rows engineered onto the threshold decide by the last bit of the f32 sigmoid, and that bit belongs to the CPU's vector exp
+    # (the fixture was written on the build container's CPU; another host may round a row the other way): a decision may differ
+    # from the fixture only where the float64 sigmoid is within 2 ulp of the threshold.
+    p64 = torch.sigmoid(x.double() @ torch.from_numpy(g["w"]).double().t() + torch.from_numpy(g["b"]).double()).squeeze(-1).numpy()
+
+    def same_decisions(mask, ref_mask, thr):
+        on_the_line = np.abs(p64 - float(thr)) <= 2.4e-7
+        differ = (np.rint(mask) != np.rint(ref_mask)).any(-1)
+        assert not (differ & ~on_the_line).any(), "a decision differs from the reference's away from the threshold"
+        return int(differ.sum())
     gate = make().eval()
     with torch.no_grad():
         m = gate(x)
-    assert np.array_equal(m.numpy(), np.rint(g["eval_mask"])) and np.abs(m.numpy() - g["eval_mask"]).max() <= 1.2e-7
-    assert gate._total_tokens == int(g["eval_total"]) and gate._skipped_tokens == float(np.rint(g["eval_mask"])[..., 0].sum())
+    flips = same_decisions(m.numpy(), g["eval_mask"], g["thr_eval"])
+    keep = (np.rint(m.numpy()) == np.rint(g["eval_mask"])).all(-1)
+    assert np.abs(m.numpy() - g["eval_mask"])[keep].max() <= 1.2e-7
+    assert gate._total_tokens == int(g["eval_total"])
+    assert abs(gate._skipped_tokens - float(np.rint(g["eval_mask"])[..., 0].sum())) <= flips
     for mode, hard in (("train_hard", True), ("train_soft", False)):
         gate = make(hard).train()
         xg = x.clone().requires_grad_(True)
         m = gate(xg)
         m.backward(dret)
-        assert np.abs(m.detach().numpy() - g[f"{mode}_mask"]).max() <= 1.2e-7, mode
+        flips = 0
         if hard:
-            assert np.array_equal(m.detach().numpy(), np.rint(g[f"{mode}_mask"]))
+            flips = same_decisions(m.detach().numpy(), g[f"{mode}_mask"], g["thr_train"])
+            keep = (np.rint(m.detach().numpy()) == np.rint(g[f"{mode}_mask"])).all(-1)
+        else:
+            keep = np.ones(p64.shape, dtype=bool)
+        assert np.abs(m.detach().numpy() - g[f"{mode}_mask"])[keep].max() <= 1.2e-7, mode
         for got, key in ((xg.grad, "dx"), (gate.head[1].weight.grad, "dw"), (gate.head[1].bias.grad, "db")):
             ref = torch.from_numpy(g[f"{mode}_{key}"])
             assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6 * max(1.0, float(ref.abs().max()))), (mode, key)
         assert gate._total_tokens == int(g[f"{mode}_total"])
-        assert abs(gate._skipped_tokens - float(g[f"{mode}_skipped"])) <= 1e-3 * max(1.0, float(g[f"{mode}_skipped"]))
+        assert abs(gate._skipped_tokens - float(g[f"{mode}_skipped"])) <= 1e-3 * max(1.0, float(g[f"{mode}_skipped"])) + flips
     gate = make()
     gate.disable = True
     assert np.array_equal(gate(x).detach().numpy(), g["disabled_mask"])
