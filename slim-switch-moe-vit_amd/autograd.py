@@ -173,6 +173,12 @@ class _GroupFFN(torch.autograd.Function):
         G = offsets.numel() - 1
         n = rows.shape[0]
         dY = dY.contiguous()
+        # column sums (bias gradients) right behind the kernel that produced their operand, while it still sits in the 256-MB
+        # Infinity Cache: dY's here (the combine's adjoint just wrote it), dH's directly after the GEMM below -- not behind the two
+        # weight-gradient GEMMs, which stream 600 MB through the cache first
+        need_cs2 = ctx.has_b2 or bool(ctx.zero_groups)
+        need_cs1 = ctx.has_b1
+        cs2 = ops.group_colsum(dY, offsets) if need_cs2 else None                        # [G, d]
         w2t = ex.h4toh.weight_t_as(cd)                                                   # [E, h, d]  (N = h, K = d)
         # dH = (dY W2) * gelu'(H) [* dropout mask]: gelu' rides in the dgrad GEMM's epilogue; the (elementwise, commuting)
         # dropout mask of the rare drop > 0 training configuration is one multiply behind it
@@ -180,6 +186,12 @@ class _GroupFFN(torch.autograd.Function):
                               group_expert=gexp, residual=Hp)
         if ctx.has_drop:
             dH = dH * drop_mask
+        cs1 = ops.group_colsum(dH, offsets) if need_cs1 else None                        # [G, h]
+        drows = None
+        if ctx.needs_input_grad[0]:                                                      # (dH's other reader, same reason)
+            w1t = ex.htoh4.weight_t_as(cd)                                               # [E, d, h]  (N = d, K = h)
+            drows = ops.grouped_gemm(dH, w1t, None, offsets, ops.EPI_NONE, cd, variant=mod.gemm_variant,
+                                     group_expert=gexp)
         # dW2[e] = dY_e^T A_e, dW1[e] = dH_e^T R_e straight from the token-major tensors (transposing LDS reads;
         # smoe_transpose_pad + smoe_grouped_wgrad is the older two-step form, kept in ops for A/B tests)
         Z = ctx.zero_groups
@@ -191,27 +203,19 @@ class _GroupFFN(torch.autograd.Function):
             # colsum(dY_g) (x) A_row; the bias gradients are column sums as for every group.  The GEMMs run over the first E groups only.
             E = G - Z
             offs_e = offsets[: E + 1]
-            dW2 = ops.grouped_wgrad_rows(dY, A, offs_e)
             dW1 = ops.grouped_wgrad_rows(dH, rows, offs_e)
-            cs2 = ops.group_colsum(dY, offsets)                       # [G, d]
-            cs1 = ops.group_colsum(dH, offsets) if ctx.has_b1 else None   # [G, h]
+            dW2 = ops.grouped_wgrad_rows(dY, A, offs_e)
             # rank-1 terms into dW2 (in place) and the experts' bias gradients, one launch (smoe_zero_group_fold)
             db2, db1 = ops.zero_group_fold(cs2, cs1, A, offsets, gmap, E, dW2, want_b2=ctx.has_b2, want_b1=ctx.has_b1)
             G = E
         else:
-            dW2 = ops.grouped_wgrad_rows(dY, A, offsets)
             dW1 = ops.grouped_wgrad_rows(dH, rows, offsets)
-            db2 = ops.group_colsum(dY, offsets) if ctx.has_b2 else None
-            db1 = ops.group_colsum(dH, offsets) if ctx.has_b1 else None
+            dW2 = ops.grouped_wgrad_rows(dY, A, offsets)
+            db2, db1 = (cs2 if ctx.has_b2 else None), cs1
         if G != E_local:  # rank-major groups (source rank, local expert): fold the source ranks
             dW2, dW1 = dW2.view(-1, E_local, *dW2.shape[1:]).sum(0), dW1.view(-1, E_local, *dW1.shape[1:]).sum(0)
             db2 = db2.view(-1, E_local, db2.shape[1]).sum(0) if db2 is not None else None
             db1 = db1.view(-1, E_local, db1.shape[1]).sum(0) if db1 is not None else None
-        drows = None
-        if ctx.needs_input_grad[0]:
-            w1t = ex.htoh4.weight_t_as(cd)                                               # [E, d, h]  (N = d, K = h)
-            drows = ops.grouped_gemm(dH, w1t, None, offsets, ops.EPI_NONE, cd, variant=mod.gemm_variant,
-                                     group_expert=gexp)
         return drows, dW1, db1, dW2, db2, None, None, None, None, None
 
 
