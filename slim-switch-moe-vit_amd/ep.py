@@ -107,6 +107,22 @@ class _PinnedPool:
 
 _pinned = _PinnedPool()
 
+_offs_pool = {}     # (device, length) -> [ring of int32 buffers whose element 0 is 0, next index]
+_OFFS_RING = 64     # more than the layers x micro-batches x chunks whose GEMMs can still be queued behind one another
+
+
+def _offsets_buffer(length: int, device) -> torch.Tensor:
+    """An int32 [length] buffer with element 0 == 0 for a received-groups offset table (cumsum fills [1:]).  Taken round-robin from
+    a ring per (device, length): the consumer (the grouped GEMM) runs on the stream that filled it, and a buffer comes around again
+    only after 63 later tables were built on that stream."""
+    key = (str(device), int(length))
+    ent = _offs_pool.get(key)
+    if ent is None:
+        ent = _offs_pool[key] = [[torch.zeros(length, dtype=torch.int32, device=device) for _ in range(_OFFS_RING)], 0]
+    buf = ent[0][ent[1]]
+    ent[1] = (ent[1] + 1) % _OFFS_RING
+    return buf
+
 
 class PendingCounts:
     """Count matrices on their way to the host.  ``finish()`` is the layer's only host sync; between
@@ -120,7 +136,7 @@ class PendingCounts:
         """int32 [W*E_local + 1] row offsets of chunk c's received groups ([w][e] order), built on the device
         from the received counts (no host -> device copy on the critical path)."""
         n = self.dev[1][:, c, :].reshape(-1)
-        offs = torch.zeros(n.numel() + 1, dtype=torch.int32, device=n.device)
+        offs = _offsets_buffer(n.numel() + 1, n.device)          # element 0 is zero and stays zero: no clearing launch per layer
         torch.cumsum(n, 0, dtype=torch.int32, out=offs[1:])
         return offs
 
