@@ -23,7 +23,6 @@ namespace {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int AB_D = 64;
-constexpr int AB_THREADS = 256;
 constexpr int DS_ROW = 512;                 // bytes per query row of the dS image (up to 256 keys x 2 B)
 constexpr int DS_BYTES = 32 * DS_ROW;
 
@@ -66,14 +65,16 @@ __device__ __forceinline__ u32x4 tr_pair(const char* img, int r_lo, int r_hi, in
   return __builtin_bit_cast(u32x4, v);
 }
 
-template <typename HT, int NKT>
-__global__ __launch_bounds__(AB_THREADS, 1) void attn_bwd_kernel(const HT* __restrict__ qkv, const HT* __restrict__ o,
+template <typename HT, int NKT, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void attn_bwd_kernel(const HT* __restrict__ qkv, const HT* __restrict__ o,
                                                                  const HT* __restrict__ dout, const float* __restrict__ lse,
                                                                  HT* __restrict__ dqkv, int N, int H, float scale, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NKT + (NKT & 1);      // key tiles rounded to whole 32-key steps
   constexpr int NR = NT * 16;              // rows of every image
-  constexpr int KS = (NKT + 3) / 4;        // key tiles a wave may own
+  constexpr int KS = (NKT + NW - 1) / NW;  // key tiles a wave may own
+  constexpr int AB_THREADS = 64 * NW;      // NW = 4: one wave per SIMD; NW = 8: two (the same LDS images, half the tiles per wave)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   char* Qs = smem;
   char* Ks = Qs + NR * 128;
   char* Vs = Ks + NR * 128;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(AB_THREADS, 1) void attn_bwd_kernel(const HT* __res
   // ---- stage Q, K, V, dO (LDS DMA, 8 rows per wave-instruction, swizzle on the source address) ------------------------------
   {
     const int l_row = lane >> 3, l_pos = lane & 7;
-    for (int pc = wave; pc < NR / 8; pc += AB_THREADS / 64) {
+    for (int pc = wave; pc < NR / 8; pc += NW) {
       const int row = pc * 8 + l_row;
       const int srow = row < N ? row : N - 1;
       const int kc = l_pos ^ ((row >> 1) & 7);
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(AB_THREADS, 1) void attn_bwd_kernel(const HT* __res
     }
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
-      const int kt = wave + 4 * i;
+      const int kt = wave + NW * i;
       if (kt < NKT) {        // wave-uniform
         u32x4 kf[2], vf[2];
 #pragma unroll
@@ -210,26 +211,31 @@ __global__ __launch_bounds__(AB_THREADS, 1) void attn_bwd_kernel(const HT* __res
     }
     __syncthreads();
     // ---------------------------------------------------------------- phase B: dQ^T rows 16 w .. 16 w + 15, all keys
+    // (NW = 8: wave w takes head-dim block w & 3 for the 16 queries of sub-tile w >> 2 only)
     {
-      f32x4 dQ[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      constexpr int TB = NW == 4 ? 2 : 1;                 // query sub-tiles per wave
+      const int db = wave & 3, t0 = NW == 4 ? 0 : (wave >> 2);
+      f32x4 dQ[TB];
+#pragma unroll
+      for (int t = 0; t < TB; ++t) dQ[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < NT / 2; ++ks) {
-        const u32x4 ka = tr_pair(Ks, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, wave, tq, tp);
+        const u32x4 ka = tr_pair(Ks, 32 * ks + 8 * g, 32 * ks + 8 * g + 4, db, tq, tp);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int row = 16 * t + li;
+        for (int t = 0; t < TB; ++t) {
+          const int row = 16 * (t0 + t) + li;
           const u32x4 sv = *reinterpret_cast<const u32x4*>(Si + row * DS_ROW + (((4 * ks + g) ^ (row & 15)) << 4));
           dQ[t] = mma<HT>(ka, sv, dQ[t]);
         }
       }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int q = q0 + 16 * t + li;
+      for (int t = 0; t < TB; ++t) {
+        const int q = q0 + 16 * (t0 + t) + li;
         if (q < N) {
           u32x2 pk;
           pk[0] = (uint32_t)to16<HT>(dQ[t][0]) | ((uint32_t)to16<HT>(dQ[t][1]) << 16);
           pk[1] = (uint32_t)to16<HT>(dQ[t][2]) | ((uint32_t)to16<HT>(dQ[t][3]) << 16);
-          *reinterpret_cast<u32x2*>(gbase + (int64_t)q * ts3 + 16 * wave + 4 * g) = pk;
+          *reinterpret_cast<u32x2*>(gbase + (int64_t)q * ts3 + 16 * db + 4 * g) = pk;
         }
       }
     }
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(AB_THREADS, 1) void attn_bwd_kernel(const HT* __res
   // ---- dK, dV of the owned key tiles: lane (g, key li) holds head-dim elements 16 dt + 4 g + r -----------------------------
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
-    const int kt = wave + 4 * i;
+    const int kt = wave + NW * i;
     const int key = kt * 16 + li;
     if (kt < NKT && key < N) {
 #pragma unroll
@@ -256,26 +262,36 @@ __global__ __launch_bounds__(AB_THREADS, 1) void attn_bwd_kernel(const HT* __res
   }
 }
 
-template <typename HT, int NKT>
+template <typename HT, int NKT, int NW>
 int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int B, int N, int H, float scale,
                hipStream_t s) {
   constexpr int NT = NKT + (NKT & 1);
   const size_t smem = 4 * (size_t)NT * 16 * 128 + DS_BYTES + 2 * (size_t)NT * 16 * sizeof(float);
-  SMOE_ENSURE_SMEM(attn_bwd_kernel<HT, NKT>);
-  hipLaunchKernelGGL((attn_bwd_kernel<HT, NKT>), dim3(B * H), dim3(AB_THREADS), smem, s, (const HT*)qkv, (const HT*)o,
+  SMOE_ENSURE_SMEM((attn_bwd_kernel<HT, NKT, NW>));
+  hipLaunchKernelGGL((attn_bwd_kernel<HT, NKT, NW>), dim3(B * H), dim3(64 * NW), smem, s, (const HT*)qkv, (const HT*)o,
                      (const HT*)dout, lse, (HT*)dqkv, N, H, scale, scale * 1.4426950408889634f);
   SMOE_CHECK_LAUNCH("smoe_attention_bwd");
   return 0;
+}
+
+// waves per workgroup: the images fill the LDS (one workgroup per CU), so 8 waves = two per SIMD is what hides the latencies between
+// a step's dependent phases (LDS reads -> MFMA -> exp / pack -> MFMA); SMOE_ATTN_BWD_WAVES=4 keeps one per SIMD (A/B)
+inline int bwd_waves() {
+  static const int w = [] { const char* e = getenv("SMOE_ATTN_BWD_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+  return w;
 }
 
 template <typename HT>
 int bwd_dispatch(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int B, int N, int H, float scale,
                  hipStream_t s) {
   const int nkt = (N + 15) / 16;
-  if (nkt <= 4) return launch_bwd<HT, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
-  if (nkt <= 8) return launch_bwd<HT, 8>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
-  if (nkt <= 13) return launch_bwd<HT, 13>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);   // N = 197 / 198
-  return launch_bwd<HT, 16>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+  if (nkt <= 4) return launch_bwd<HT, 4, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+  if (nkt <= 8) return bwd_waves() == 8 ? launch_bwd<HT, 8, 8>(qkv, o, dout, lse, dqkv, B, N, H, scale, s)
+                                        : launch_bwd<HT, 8, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+  if (nkt <= 13) return bwd_waves() == 8 ? launch_bwd<HT, 13, 8>(qkv, o, dout, lse, dqkv, B, N, H, scale, s)   // N = 197 / 198
+                                         : launch_bwd<HT, 13, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
+  return bwd_waves() == 8 ? launch_bwd<HT, 16, 8>(qkv, o, dout, lse, dqkv, B, N, H, scale, s)
+                          : launch_bwd<HT, 16, 4>(qkv, o, dout, lse, dqkv, B, N, H, scale, s);
 }
 
 }  // namespace
