@@ -71,6 +71,8 @@ print(d['ms_per_step'], {k: v['avg_ms'] for k, v in d['kernels'].items() if 'gem
   profile)
     TAG=$1; O=gpurun_out/prof_$TAG; mkdir -p $O
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 bench.py --no-cpu-baseline --clock-seconds 0 --steps 20 --warmup 5 > $O/bench.log 2>&1
+    python3 tools/train_bench.py model 128 10 > $O/train_unprofiled.log 2>&1
+    python3 tools/train_bench.py model 128 10 resmoe_base_patch16_224_expert8_top1 > $O/train_resmoe_unprofiled.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o train -- python3 tools/train_bench.py model 128 6 > $O/train.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_resmoe -o train -- python3 tools/train_bench.py model 128 6 resmoe_base_patch16_224_expert8_top1 > $O/train_resmoe.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/dispatch -o dispatch -- python3 tools/dispatch_prof.py 20 > $O/dispatch.log 2>&1
@@ -92,9 +94,11 @@ print(d['ms_per_step'], {k: v['avg_ms'] for k, v in d['kernels'].items() if 'gem
     find $O -name "*.csv" | wc -l ;;
   train-profile)   # the two training steps only (kernel tables): tools/diag.sh train-profile TAG
     TAG=$1; O=gpurun_out/prof_$TAG; mkdir -p $O
+    python3 tools/train_bench.py model 128 10 > $O/train_unprofiled.log 2>&1        # the step's wall time WITHOUT the profiler
+    python3 tools/train_bench.py model 128 10 resmoe_base_patch16_224_expert8_top1 > $O/train_resmoe_unprofiled.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o train -- python3 tools/train_bench.py model 128 6 > $O/train.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_resmoe -o train -- python3 tools/train_bench.py model 128 6 resmoe_base_patch16_224_expert8_top1 > $O/train_resmoe.log 2>&1
-    tail -n 1 $O/train.log; tail -n 1 $O/train_resmoe.log ;;
+    grep "train step" $O/train_unprofiled.log $O/train_resmoe_unprofiled.log ;;
   *)
     sed -n 2,22p "$0"; exit 1 ;;
 esac

@@ -71,7 +71,13 @@ for what, title in (("train", "moe_base_patch16_224_expert8_top1 (SwitchGate, ca
     mine = sum(float(r["TotalDurationNs"]) for r in rows if own(r["Name"]))
     log = open(os.path.join(src, what + ".log")).read().strip().splitlines()
     line = next((l for l in log if "train step" in l), "")
-    out += [f"## {title}", "", f"`{line}`", "", f"GPU time of the 9 steps {tot / 1e6:.1f} ms; on kernels of libslimmoe_hip.so **{100 * mine / tot:.1f} %**", "",
+    plain = os.path.join(src, what + "_unprofiled.log")
+    plain_line = next((l for l in open(plain).read().splitlines() if "train step" in l), "") if os.path.exists(plain) else ""
+    out += [f"## {title}", ""]
+    if plain_line:
+        out += [f"without the profiler, same box: `{plain_line}`", ""]
+    out += [f"under rocprofv3 (host-side tracing slows the launches: wall time is NOT the step's): `{line}`", "",
+            f"GPU time of the 9 profiled steps {tot / 1e6:.1f} ms = {tot / 9e6:.2f} ms per step; on kernels of libslimmoe_hip.so **{100 * mine / tot:.1f} %**", "",
             "| ms (9 steps) | calls | own | kernel |", "|---|---|---|---|"]
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:28]:
         out.append(f"| {float(r['TotalDurationNs']) / 1e6:.2f} | {r['Calls']} | {'yes' if own(r['Name']) else 'torch'} | `{r['Name'][:120]}` |")
