@@ -316,3 +316,40 @@ def test_config_fallbacks_are_loud():
             model(images).float().sum().backward()
     msgs = [str(w.message) for w in rec if issubclass(w.category, vit.SlimMoEFallbackWarning)]
     assert any("dropout" in m for m in msgs), msgs
+
+
+@pytest.mark.parametrize("name,kw", [("resmoe_tiny_patch16_224_expert8", dict(starting_threshold=0.55, target_threshold=0.5)),
+                                     ("moe_tiny_patch16_224_expert4_top1", dict(gate="switch", capacity_factor=1.25))])
+def test_short_training_run_falls_and_the_optimizers_weight_images_change_nothing(name, kw):
+    """Fourteen optimizer steps on one fixed batch with the reference's default flags (drop-path 0.1; tools/train_soak.py is the long form):
+    the loss falls, and the run repeated with the fused AdamW NOT writing the 16-bit weight images (they are re-cast from the master
+    weights instead) gives the SAME losses bit for bit -- the images hold the same rounded weights either way."""
+    from slim_switch_moe_vit_amd import optim as smo
+
+    def run(shadow):
+        smo.SHADOW_STEP = shadow
+        torch.manual_seed(0)
+        model = sm.create_model(name, num_classes=100, drop_path_rate=0.1, depth=4, **kw).to(DEV).train()
+        opt = smo.AdamW(model.parameters(), lr=3e-4, weight_decay=0.05)
+        scaler = smo.NativeScaler()
+        x = torch.randn(8, 3, 224, 224, generator=_gen(1)).to(DEV)
+        y = torch.randint(0, 100, (8,), generator=_gen(2)).to(DEV)
+        moes = [m for m in model.modules() if isinstance(m, sm.FMoETransformerMLP)]
+        losses = []
+        for i in range(14):
+            torch.manual_seed(1000 + i)
+            with torch.autocast("cuda", dtype=torch.float16):
+                loss = torch.nn.functional.cross_entropy(model(x), y)
+                aux = [a for a in (m.gate.get_loss() for m in moes) if a is not None]
+                if aux:
+                    loss = loss + 0.01 * torch.stack([a.reshape(()) for a in aux]).sum()
+            opt.zero_grad()
+            scaler(loss, opt, clip_grad=1.0, parameters=model.parameters())
+            losses.append(float(loss.detach()))
+        return losses
+    try:
+        on, off = run(True), run(False)
+    finally:
+        smo.SHADOW_STEP = True
+    assert all(v == v for v in on) and on[-1] < on[0] - 0.2, on
+    assert on == off, (on, off)
