@@ -135,6 +135,10 @@ int smoe_gate_ln_bwd(const float* x, const void* g_f, int g_f_dtype, const float
                      float eps, const float* gate_w, const float* gate_b, const float* mask, int gate_on, int64_t T, int d, float* dx,
                      float* dz, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* smoe_depth_scale_rows: stochastic depth's per-sample factor (timm DropPath as models/vision_transformer.py:308 uses it: x / keep * mask)
+ * expanded to the sample's rows, the form the fused stores take it in (the GEMM's per-row combine scale): mask f32 [B] (0 / 1 draws)
+ * -> factor f32 [B] = mask / keep (IEEE division), rows f32 [B * N] = factor[row / N].                                                 */
+int smoe_depth_scale_rows(const float* mask, float keep, int64_t B, int N, float* factor, float* rows, void* stream);
 /* ---- the embedding stage and the last LayerNorm of the ViT forward (models/vision_transformer.py:818-830) ----
  * smoe_patchify_cast:  images f32 [B, C, H, W] -> patch rows [B * (H/ph) * (W/pw), C * ph * pw] (f16 / bf16), row (b, gy, gx) =
  *                      images[b, :, gy*ph:(gy+1)*ph, gx*pw:(gx+1)*pw] flattened (c, py, px) -- the operand of the per-patch projection

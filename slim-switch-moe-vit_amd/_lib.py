@@ -43,6 +43,7 @@ SIGNATURES = {
     "smoe_gate_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "smoe_gate_ln_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_int,
                                  c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "smoe_depth_scale_rows": (c_int, [c_void_p, ctypes.c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "smoe_zero_group_fold": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_switch_aux_workspace_bytes": (c_size_t, [c_int64, c_int]),

@@ -143,7 +143,30 @@ int rows_grid16(int64_t T) {
   return (int)(need < 1 ? 1 : (need > (1 << 20) ? (1 << 20) : need));
 }
 
+// stochastic depth's per-sample factor, expanded to the rows of the sample (timm DropPath: x / keep * mask, models/vision_transformer.py:308):
+// factor[b] = mask[b] / keep (an IEEE division, as torch's div_), rows[b * N + n] = factor[b].  One launch for both.
+__global__ __launch_bounds__(256) void depth_scale_rows_kernel(const float* __restrict__ mask, float keep, int64_t B, int N,
+                                                               float* __restrict__ factor, float* __restrict__ rows) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * N) return;
+  const int64_t b = i / N;
+  const float f = __fdiv_rn(mask[b], keep);
+  rows[i] = f;
+  if (i - b * N == 0) factor[b] = f;
+}
+
 }  // namespace
+
+// mask f32 [B] (0 / 1 draws) -> factor f32 [B] = mask / keep and rows f32 [B * N] = factor of the row's sample
+extern "C" int smoe_depth_scale_rows(const float* mask, float keep, int64_t B, int N, float* factor, float* rows, void* stream) {
+  SMOE_REQUIRE(B >= 0 && N >= 1 && B * (int64_t)N < (1ll << 40) && keep > 0.f, "smoe_depth_scale_rows: bad sizes B=%lld N=%d keep=%g", (long long)B, N, (double)keep);
+  if (B == 0) return 0;
+  SMOE_REQUIRE(mask && factor && rows, "smoe_depth_scale_rows: null pointer");
+  const int64_t blocks = (B * N + 255) / 256;
+  hipLaunchKernelGGL(depth_scale_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, keep, B, N, factor, rows);
+  SMOE_CHECK_LAUNCH("smoe_depth_scale_rows");
+  return 0;
+}
 
 extern "C" int smoe_patchify_cast(const float* images, int64_t B, int C, int H, int W, int ph, int pw, void* out, int out_dtype,
                                   void* stream) {

@@ -185,6 +185,18 @@ def layernorm_bwd(x: torch.Tensor, dy: torch.Tensor, weight: Optional[torch.Tens
     return dx, gb[:d], gb[d:]
 
 
+def depth_scale_rows(mask: torch.Tensor, keep: float, N: int):
+    """(factor f32 [B] = mask / keep, rows f32 [B * N] = the sample's factor on each of its N rows): stochastic depth's division and
+    expansion in one launch (smoe_depth_scale_rows)."""
+    _chk(mask, "mask", torch.float32, 1, align=4)
+    B = mask.shape[0]
+    factor = torch.empty(B, dtype=torch.float32, device=mask.device)
+    rows = torch.empty(B * int(N), dtype=torch.float32, device=mask.device)
+    rc = _lib.load().smoe_depth_scale_rows(_ptr(mask), float(keep), B, int(N), _ptr(factor), _ptr(rows), _stream(mask))
+    _lib.check(rc, "smoe_depth_scale_rows")
+    return factor, rows
+
+
 def patchify_cast(images: torch.Tensor, ph: int, pw: int, out_dtype: torch.dtype = torch.float16) -> torch.Tensor:
     """images f32 [B, C, H, W] -> patch rows [B * gh * gw, C * ph * pw] in 16 bit (smoe_patchify_cast)."""
     _chk(images, "images", torch.float32, 4)

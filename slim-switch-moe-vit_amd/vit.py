@@ -418,7 +418,11 @@ class Block(nn.Module):
         if self.stochastic_depth_inactive() or not isinstance(dp, DropPath):
             return None, None
         keep = 1.0 - dp.drop_prob
-        f = torch.empty(x.shape[0], dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
+        mask = torch.empty(x.shape[0], dtype=torch.float32, device=x.device).bernoulli_(keep)
+        if x.is_cuda:      # the division and the expansion to rows in one launch (the same IEEE division as div_)
+            from . import ops
+            return ops.depth_scale_rows(mask, keep, x.shape[1])
+        f = mask.div_(keep)
         return f, f.repeat_interleave(x.shape[1])
 
     def forward_steps(self, x, xn1=None, next_norm=None):

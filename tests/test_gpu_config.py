@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import slim_switch_moe_vit_amd as sm  # noqa: E402
-from slim_switch_moe_vit_amd import dense, vit  # noqa: E402
+from slim_switch_moe_vit_amd import dense, ops, vit  # noqa: E402
 from slim_switch_moe_vit_amd.vit import _HalfCache  # noqa: E402
 
 DEV = "cuda:0"
@@ -353,3 +353,11 @@ def test_short_training_run_falls_and_the_optimizers_weight_images_change_nothin
         smo.SHADOW_STEP = True
     assert all(v == v for v in on) and on[-1] < on[0] - 0.2, on
     assert on == off, (on, off)
+
+
+def test_depth_scale_rows_is_div_and_repeat_interleave():
+    m = (torch.rand(37, generator=_gen(3)) < 0.7).float().to(DEV)
+    for keep in (0.9, 0.5, 1.0 - 0.1 * 7 / 11):
+        f, rows = ops.depth_scale_rows(m, keep, 197)
+        ref = m.clone().div_(keep)
+        assert torch.equal(f, ref) and torch.equal(rows, ref.repeat_interleave(197))
