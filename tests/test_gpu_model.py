@@ -364,6 +364,14 @@ def _two_rank_worker(rank, world, port, q):
                 part.ep_micro_batches = n
                 assert part._ep_pipeline_depth(images) == n
                 res[n] = float((part(images).float() - base).abs().max())
+            # (3) token chunks inside a layer (chunk c + 1's exchange under chunk c's expert GEMMs, the next block's LayerNorm on
+            # every chunk's combine): every row's arithmetic is its own -- bit for bit the un-chunked forward, on every rank
+            part.ep_micro_batches = 1
+            for blk in part.blocks:
+                blk.mlp.ep_chunks = 2
+            res["chunks_bitwise"] = bool(torch.equal(part(images).float(), base))
+            for blk in part.blocks:
+                blk.mlp.ep_chunks = 1
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -395,6 +403,7 @@ def test_expert_parallel_ranks_on_one_gpu_match_single_rank_model(world):
         assert res["route_equal"], rank
         assert res["blocks"] <= 5e-3, (rank, res)
         assert res[2] <= 1e-3 and res[3] <= 1e-3, (rank, res)
+        assert res["chunks_bitwise"], (rank, res)
         assert res["attribution"]["clean_images"] >= 2, (rank, res)
 
 
