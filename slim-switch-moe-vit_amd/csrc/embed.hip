@@ -34,10 +34,11 @@ __global__ __launch_bounds__(256) void patchify_cast_kernel(const float* __restr
 
 // 16 lanes per token row (the router's layout): row (b, n) of the stream is tokens[b * P + n - 1] (n >= 1) or the class token
 // (n == 0), plus pos[n]; LayerNorm over it with the arithmetic of layernorm16_kernel / router16_kernel<LN>.
-// (launch bounds: 2 waves per SIMD = 256 VGPRs -- every load of a row is issued before the first use; at 4 waves per SIMD the
-//  d = 768 instantiation spilled 52 registers and ran at 2.2 TB/s)
+// (launch bounds: 3 waves per SIMD -- every load of a row is issued before the first use; gamma / beta are loaded behind the statistics
+//  (158 VGPRs at d = 768; with them hoisted the kernel needed 182 = 2 waves per SIMD, 96-100 us; now 89-92 us; 4 waves per SIMD = 128
+//  VGPRs, 5 spills: the same 90 us))
 template <typename TT, typename NT, int NJ>
-__global__ __launch_bounds__(R16_THREADS, 2) void embed_ln_kernel(const TT* __restrict__ tok, const float* __restrict__ cls,
+__global__ __launch_bounds__(R16_THREADS, 3) void embed_ln_kernel(const TT* __restrict__ tok, const float* __restrict__ cls,
                                                                   const float* __restrict__ pos, const float* __restrict__ g,
                                                                   const float* __restrict__ be, float eps, int64_t B, int P,
                                                                   float* __restrict__ x32, NT* __restrict__ xn) {
@@ -82,11 +83,15 @@ __global__ __launch_bounds__(R16_THREADS, 2) void embed_ln_kernel(const TT* __re
         for (int i = 0; i < 4; ++i) { const float dv = xv[j][i] - mean; s2 = fmaf(dv, dv, s2); }
       const float rstd = rsqrtf(row16_sum(s2) / (float)d + eps);
       if (live) {
+        // gamma / beta behind a per-row opaque zero: otherwise the loop-invariant loads are hoisted in front of the row's own loads
+        // and held across the token loop (96 registers at d = 768: the difference between two and three waves per SIMD)
+        int lz = 0;
+        asm volatile("" : "+v"(lz));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int c = u * 4 + 64 * j;
-          const f32x4 gg = g ? *reinterpret_cast<const f32x4*>(g + c) : f32x4{1.f, 1.f, 1.f, 1.f};
-          const f32x4 bb = be ? *reinterpret_cast<const f32x4*>(be + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+          const f32x4 gg = g ? *reinterpret_cast<const f32x4*>(g + lz + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+          const f32x4 bb = be ? *reinterpret_cast<const f32x4*>(be + lz + c) : f32x4{0.f, 0.f, 0.f, 0.f};
           f32x4 o;
 #pragma unroll
           for (int i = 0; i < 4; ++i) o[i] = fmaf((xv[j][i] - mean) * rstd, gg[i], bb[i]);
