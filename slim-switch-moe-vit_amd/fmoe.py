@@ -23,6 +23,21 @@ from ._cache import StreamCache, param_version, register_shadow
 _COMPUTE_DTYPES = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
 
 
+# How the single-rank inference path ends a MoE half that is followed by another block (models/vision_transformer.py:319-322):
+#   "epilogue": GEMM-2's row-mapped f32 epilogue adds score * y into the residual stream, the next block's norm1 is its own pass;
+#   "ln":       GEMM-2 stores contiguous 16-bit rows (direct-store epilogue), then combine + residual + the next norm1 in ONE pass
+#               (smoe_gather_combine_ln).  Same HBM bytes per layer; the f32 traffic moves off the CU store path.
+# A/B: SLIMMOE_TAIL, or flip the module variable between forwards (tools/tail_ab.py alternates in one process).
+TAIL_MODE = os.environ.get("SLIMMOE_TAIL", "epilogue")
+
+
+def _tail_ln_ok(next_norm, x2: torch.Tensor, cd: torch.dtype, k: int) -> bool:
+    d = x2.shape[1]
+    return (isinstance(next_norm, nn.LayerNorm) and next_norm.elementwise_affine and next_norm.bias is not None
+            and x2.dtype == torch.float32 and cd in (torch.float16, torch.bfloat16) and k <= 4 and d % 8 == 0 and d <= 1024
+            and next_norm.weight.dtype == torch.float32)
+
+
 def default_compute_dtype() -> torch.dtype:
     """dtype of the MFMA operands of the expert GEMMs (accumulation is always f32)."""
     return _COMPUTE_DTYPES[os.environ.get("SLIMMOE_COMPUTE_DTYPE", "f16")]
@@ -338,6 +353,16 @@ class FMoETransformerMLP(nn.Module):
         w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
         b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
         b2 = ex.h4toh.bias.detach().float() if ex.h4toh.bias is not None else None
+        if next_norm is not None and TAIL_MODE == "ln" and _tail_ln_ok(next_norm, x2, cd, k):
+            # GEMM-2 stores plain 16-bit rows straight from its accumulators (the direct-store epilogue: no row map, no f32 residual
+            # traffic on the CU's store path, which nothing overlaps with MFMAs), and ONE pass at the HBM roof then does the combine,
+            # the residual add and the NEXT block's norm1 (smoe_gather_combine_ln) -- the expert-parallel path's return side, taken
+            # on a single rank too.  One more 2^-11 rounding of y than the f32 epilogue; same routing, same float bar.
+            h = ops.grouped_gemm(xn16, w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant, a_gather=pos, a_div=k)
+            y = ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, cd, variant=self.gemm_variant)
+            out, xn_next = ops.gather_combine_ln(y, inv_pos, score, T, k, x2, next_norm.weight.detach().float(),
+                                                 next_norm.bias.detach().float(), next_norm.eps, torch.float16)
+            return out.reshape(shape), xn_next.reshape(shape)
         if k == 1:
             out = x2.clone() if cap >= 0 else torch.empty_like(x2)
             # both expert GEMMs (scatter folded into GEMM-1's operand fetch, combine + residual into GEMM-2's store) as ONE persistent

@@ -606,7 +606,7 @@ class VisionTransformer(nn.Module):
                 and x.shape[0] >= 2):
             return self._forward_features_two_streams(x)
         x, xn1 = self._embed(x, want_xn1=True)
-        if x.is_cuda and not torch.is_grad_enabled() and (self._ep_blocks() or xn1 is not None):
+        if x.is_cuda and not torch.is_grad_enabled():   # (generator form: every block is handed the next block's norm1)
             from .ep import drain
             x = drain(self._blocks_steps(x, xn1))
         else:
