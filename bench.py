@@ -47,6 +47,13 @@ def parse():
                     help="expert parallel only: micro-batches of the local batch interleaved through the model so that "
                          "count read-backs and all-to-alls of one run under the other's compute (1 = off; 0 = time "
                          "1, 2 and 3 during warm-up and keep the fastest -- the right depth depends on the link rate)")
+    ap.add_argument("--ep-static", default="auto", choices=["auto", "0", "1"],
+                    help="expert parallel only: the speculative STATIC exchange for the capacity-less gate (fixed alpha-sized slots, "
+                         "counts in-band, no host round trip per layer; an overflowing step is repeated on the counted exchange) -- "
+                         "1 = on, 0 = off (count read-back per layer), auto = timed against the counted exchange during warm-up")
+    ap.add_argument("--ep-alpha", type=float, default=1.25,
+                    help="speculative slot size as a multiple of the balanced share rows * k / E (raised automatically during warm-up "
+                         "to 1.1 x the largest group a step needed)")
     ap.add_argument("--cpu-batch", type=int, default=128, help="images in the CPU-oracle sample")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget: 5 timed forwards if they fit ~2x this, else 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,41 +239,66 @@ def main():
             torch.cuda.synchronize(device)
 
     ep_tuning = None
+    ep_repeats = 0
+    ep_static = False
     moes = [blk.mlp for blk in model.blocks]
-    if (world > 1 or args.force_ep) and (args.ep_micro_batches == 0 or args.ep_chunks == 0):
+    if world > 1 or args.force_ep:
+        from slim_switch_moe_vit_amd import ep as _ep
+
+        def guarded():
+            """One step whose overflow report is read at once (warm-up: the slots grow to what the routing needs)."""
+            nonlocal ep_repeats
+            _, again = _ep.run_guarded(step, flush=True)
+            ep_repeats += int(again)
+
         # pipeline shape: micro-batches of the local batch interleaved through the whole model (count read-backs and all-to-alls of
         # one run under the other's attention / GEMMs) x token chunks inside a MoE layer (chunk c + 1 travels under chunk c's expert
-        # GEMMs).  Fewer / bigger = more efficient kernels; more = more transfer hidden.  Which wins depends on the xGMI rate at this
-        # world size, so measure (every rank takes the same, all-reduced, decision)
+        # GEMMs) x the exchange itself: counted (one host round trip per layer) or speculative static (fixed slots of alpha x the
+        # balanced share, counts in-band, no host round trip, alpha x the all-to-all bytes).  Fewer / bigger = more efficient
+        # kernels; more = more transfer hidden; static = no idle GPU behind a read-back, but more bytes on the links.  Which wins
+        # depends on the xGMI rate at this world size, so measure (every rank takes the same, all-reduced, decision)
         ep_tuning = {}
         mbs = (1, 2, 3) if args.ep_micro_batches == 0 else (args.ep_micro_batches,)
         chs = (1, 2, 3) if args.ep_chunks == 0 else (args.ep_chunks,)
-        for n in mbs:
-            for c in chs:
-                if n * c > 4:
-                    continue
-                model.ep_micro_batches = n
-                for m in moes:
-                    m.ep_chunks = c
-                for _ in range(2):
-                    step()
-                fence()
-                t0 = time.perf_counter()
-                for _ in range(3):
-                    step()
-                fence()
-                t = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device=device)
-                if world > 1:
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                ep_tuning[f"{n}x{c}"] = round(float(t.item()) * 1e3, 3)
-        best = min(ep_tuning, key=ep_tuning.get)
-        args.ep_micro_batches, args.ep_chunks = (int(v) for v in best.split("x"))
+        statics = {"auto": (False, True), "0": (False,), "1": (True,)}[args.ep_static]
+        grid = [(st, n, c) for st in statics for n in mbs for c in (chs if not st else (1,)) if n * c <= 4]
+        for st, n, c in grid if len(grid) > 1 else []:
+            _ep.set_speculative(model, args.ep_alpha if st else None)
+            model.ep_micro_batches = n
+            for m in moes:
+                m.ep_chunks = c
+            for _ in range(2):
+                guarded()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                step()
+            fence()
+            ok = True
+            try:
+                _ep.check_static_overflow(flush=True)
+            except _ep.StaticExchangeOverflow:
+                ok = False                      # (the same steps fitted a moment ago: cannot happen with a fixed batch)
+            t = torch.tensor([(time.perf_counter() - t0) / 3 if ok else 1e9], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ep_tuning[("static " if st else "") + f"{n}x{c}"] = round(float(t.item()) * 1e3, 3)
+        if ep_tuning:
+            best = min(ep_tuning, key=ep_tuning.get)
+            ep_static = best.startswith("static ")
+            args.ep_micro_batches, args.ep_chunks = (int(v) for v in best.replace("static ", "").split("x"))
+        else:
+            ep_static, args.ep_micro_batches, args.ep_chunks = grid[0]
+        _ep.set_speculative(model, args.ep_alpha if ep_static else None)
         model.ep_micro_batches = args.ep_micro_batches
         for m in moes:
             m.ep_chunks = args.ep_chunks
     args.ep_chunks = max(1, args.ep_chunks)
     for _ in range(args.warmup):
-        step()
+        if ep_static:
+            guarded()
+        else:
+            step()
     fence()
     # Per-launch HIP events inside the timed region: the roofline kernel only (two event records around each of the
     # ~110 other launches of a step cost ~0.5 ms per step).  The other kernels' table comes from a few extra,
@@ -281,6 +313,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof = ops.profile_end()
+    ep_overflow_in_timed_region = False
+    if ep_static:
+        try:     # the timed steps ran without reading their overflow reports (no host sync): read them now
+            _ep.check_static_overflow(flush=True)
+        except _ep.StaticExchangeOverflow:
+            ep_overflow_in_timed_region = True      # the timed outputs are void: the line says so
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     side_steps = 0
     if world == 1 and not args.force_ep:
@@ -325,6 +363,13 @@ def main():
     if ep_info is None and ep_tuning is not None:
         ep_info = {"micro_batches": args.ep_micro_batches, "chunks_per_layer": args.ep_chunks,
                    "pipeline_tuning_ms_per_step (micro-batches x chunks)": ep_tuning}
+    if ep_info is not None:
+        ep_info["exchange"] = ("speculative static (fixed slots, counts in-band, no host round trip per layer)" if ep_static
+                               else "counted (count read-back + all-to-all-v per layer)")
+        if ep_static:
+            ep_info["speculative_alpha_per_layer"] = [round(float(m.ep_speculative), 3) for m in moes]
+            ep_info["steps_repeated_on_the_counted_exchange_during_warmup"] = ep_repeats
+            ep_info["overflow_in_timed_region"] = ep_overflow_in_timed_region
 
     # ---- per-kernel accounting from the HIP events recorded inside the timed region --------------------
     agg = {}
@@ -454,7 +499,7 @@ def main():
             "config": {"workload": f"ViT-B/16 Switch-MoE E={args.experts} top-1, 224^2, batch {args.batch}/GPU, "
                                    f"full eval forward (12 blocks: attention + MoE MLP), fp16 autocast",
                        "global_batch": args.batch * world, "tokens_per_image": 197, "compute_streams": args.compute_streams,
-                       "parallelism": ("single" if not args.force_ep else f"single (EP code path forced, {args.ep_micro_batches} interleaved micro-batches x {args.ep_chunks} chunks per layer)") if world == 1 else f"ep{world} (experts/{world} per rank, all-to-all, {args.ep_micro_batches} interleaved micro-batches x {args.ep_chunks} chunks per layer)"},
+                       "parallelism": ("single" if not args.force_ep else f"single (EP code path forced, {'speculative static' if ep_static else 'counted'} exchange, {args.ep_micro_batches} interleaved micro-batches x {args.ep_chunks} chunks per layer)") if world == 1 else f"ep{world} (experts/{world} per rank, {'speculative static' if ep_static else 'counted'} all-to-all, {args.ep_micro_batches} interleaved micro-batches x {args.ep_chunks} chunks per layer)"},
             "roofline": roofline,
             "kernels": kernels,
         }

@@ -112,8 +112,11 @@ int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, const float* ln
 /* What the MoE returns for an all-zero input row (every token the skip gate masks, resMoE.py:140-143):
  *   out[d] = sum_j score_j (W2[e_j] gelu(b1[e_j]) + b2[e_j]),  (e_j, score_j) = NaiveGate top-k of the gate bias bg.
  * w2 [E,d,h], b1 [E,h], b2 [E,d], bg [E] f32 (b1 / b2 / bg may be NULL = zeros).  Depends on parameters only.  */
+/* Under expert parallelism bg covers all E global experts while w2 / b1 / b2 hold the E_local experts [e_base, e_base + E_local)
+ * of this rank: out is then this rank's PARTIAL sum (chosen experts that live elsewhere contribute nothing); the ranks' partial
+ * sums add up to the full row (one all-reduce per parameter version).  Single rank: e_base = 0, E_local = E.                  */
 int smoe_zero_row_output(const float* bg, int E, int k, const float* w2, const float* b1, const float* b2, int d, int h,
-                         float* out, void* stream);
+                         int e_base, int E_local, float* out, void* stream);
 
 /* smoe_skip_gate_bwd: backward of one gated half of the residual-MoE block in TRAINING (models/resMoE.py:68-77: hard masks with
  * the straight-through estimator; 131-143: tk = xn * m1, skip_tk = xn * m0, out = f(tk) + tk + skip_tk).  xn [T,d] f32 = the normed
@@ -204,7 +207,35 @@ int smoe_dispatch_plan_hist(const int64_t* idx, int64_t n, int E, int64_t capaci
  * expert e's row range (smoe_grouped_gemm's `group_end`); counts / offsets as above.  capacity >= 1; E <= 64. */
 int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, int64_t capacity, int64_t slot_rows, int32_t* counts,
                               int32_t* offsets, int32_t* group_end, int64_t* pos_padded, int64_t* inv_pos,
-                              int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream);
+                              int64_t* idx_pruned,
+                              int32_t* raw_counts /* i32 [E] or NULL: entries routed to each expert BEFORE the capacity clamp */,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same plan over a SLOT TABLE (the static expert exchange's send layout): expert e owns the slots [slot_base[e],
+ * slot_base[e + 1]) (slot_base i32 [E + 1], device memory), the last hdr_rows (0 / 1) of them reserved for the in-band header; it
+ * keeps min(region - hdr_rows, capacity if capacity >= 0) entries.  pos_slots has slot_base[E] entries (unused ones -1), inv_pos[i]
+ * is the slot, group_end[e] = slot_base[e] + counts[e]; raw_counts as above.  E <= 64. */
+int smoe_dispatch_plan_slots(const int64_t* idx, int64_t n, int E, int64_t capacity, const int32_t* slot_base, int hdr_rows,
+                             int32_t* counts, int32_t* offsets, int32_t* group_end, int64_t* pos_slots, int64_t* inv_pos,
+                             int64_t* idx_pruned, int32_t* raw_counts, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- in-band headers of the static expert exchange ------------------------------------------------------------------------
+ * Replaces fmoe_cuda.expert_exchange (the count all-to-all in front of global_scatter) for the static exchange:
+ * the counts travel INSIDE the token all-to-all.  Send buffer = one region per global expert g, rows [slot_base[g],
+ * slot_base[g + 1]) (blocks of E_local consecutive regions go to one peer): payload rows + ONE header row (the region's last),
+ * whose leading int32 words are {kept rows of the group, rows routed to it before the clamp, the source's row count, G, the
+ * source's pre-clamp counts of ALL G experts}.  row_bytes >= 16 + 4 G.
+ * smoe_ep_pack_headers writes the G header rows of a send buffer (counts / raw_counts i32 [G] from smoe_dispatch_plan_slots;
+ * raw_counts NULL = counts; counts NULL = a rank without rows);
+ * smoe_ep_unpack_headers reads the W * E_local headers of a RECEIVED buffer ([source rank][local expert] order; local_base i32
+ * [E_local + 1] = this rank's experts' region offsets inside one source's block, local_base[E_local] = rows per block):
+ *   starts[l], ends[l] (i32 [W * E_local])  -> smoe_grouped_gemm's offsets / group_end
+ *   stats (may be NULL) i32 [W][1 + E_total] = {source w's row count, source w's pre-clamp counts of all experts} -- every rank
+ *   receives the same matrix, so all ranks can decide "somebody overflowed" (and re-size the slots) identically, without a collective */
+int smoe_ep_pack_headers(const int32_t* counts, const int32_t* raw_counts, const int32_t* slot_base, int G, int64_t row_bytes,
+                         int64_t t_rows, void* send, void* stream);
+int smoe_ep_unpack_headers(const void* recv, int W, int E_local, const int32_t* local_base, int64_t row_bytes, int E_total,
+                           int32_t* starts, int32_t* ends, int32_t* stats, void* stream);
 
 /* ---- token scatter (MOEScatter.forward local part: index_select(x, 0, pos // k)) ----
  * buf[s,:] = cast(x[pos[s] / k, :]) for every slot s < n_slots with pos[s] >= 0; other rows untouched.

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SLIMMOE_LIB: another build of the same sources (a diagnostic build, `make DIAG=-DSMOE_DIAG`, whose environment switches the
 # tools under tools/ use); the ABI and symbol checks below apply to it all the same
 LIB_PATH = os.environ.get("SLIMMOE_LIB") or os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -30,7 +30,11 @@ SIGNATURES = {
     "smoe_dispatch_plan": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_dispatch_plan_padded": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "smoe_dispatch_plan_slots": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "smoe_ep_pack_headers": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_void_p]),
+    "smoe_ep_unpack_headers": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "smoe_scatter_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "smoe_scatter_rows_fill": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "smoe_gelu": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
@@ -115,7 +119,8 @@ SIGNATURES = {
     "smoe_layernorm_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, ctypes.c_float, c_int64, c_int, c_void_p, c_void_p]),
     "smoe_skip_gate_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                                    c_void_p, c_void_p]),
-    "smoe_zero_row_output": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "smoe_zero_row_output": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p]),
 }
 
 _lib = None

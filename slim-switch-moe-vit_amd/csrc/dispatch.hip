@@ -82,13 +82,19 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
     const int64_t* __restrict__ idx, int64_t n, int E, int64_t capacity, const int32_t* __restrict__ rawbase_or_cnt,
     const int32_t* __restrict__ offsets_in, int64_t* __restrict__ pos, int64_t* __restrict__ inv_pos,
     int64_t* __restrict__ idx_pruned, int nblk, int32_t* __restrict__ counts_out, int32_t* __restrict__ offsets_out,
-    int64_t slot_stride, int32_t* __restrict__ group_end_out, int tab_rows, int tab_ratio) {
+    int64_t slot_stride, int32_t* __restrict__ group_end_out, int tab_rows, int tab_ratio,
+    int32_t* __restrict__ raw_out = nullptr, const int32_t* __restrict__ slot_base = nullptr, int hdr_rows = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // run[w][e]: raw rank of the next entry of expert e seen by wave w (wave w owns a contiguous quarter of the chunk)
   int32_t* run = reinterpret_cast<int32_t*>(smem);  // [PLAN_WAVES][E]
   int32_t* sbase = run + PLAN_WAVES * E;            // FUSED: [E] base rank of this chunk, [E] totals, [E+1] offsets
   int32_t* stot = sbase + E;
   int32_t* soff = stot + E;
+  // SLOT TABLE layout (slot_base != NULL; the speculative static exchange's per-expert slots): expert e owns the slots
+  // [slot_base[e], slot_base[e + 1]), the last hdr_rows of which are not payload; it keeps at most that many entries (and at most
+  // `capacity` when that is >= 0).  ssb = the table in LDS, scap = every expert's payload capacity.
+  int32_t* ssb = soff + E + 1;                      // [E+1]
+  int32_t* scap = ssb + E + 1;                      // [E]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t chunk_base = (int64_t)blockIdx.x * PLAN_CH;
   const int64_t wave_base = chunk_base + (int64_t)wave * (64 * PLAN_ITERS);
@@ -96,7 +102,18 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
   for (int i = tid; i < PLAN_WAVES * E; i += PLAN_THREADS) run[i] = 0;
   if constexpr (FUSED) {
     for (int i = tid; i < 2 * E; i += PLAN_THREADS) sbase[i] = 0;
+    if (slot_base) {
+      for (int i = tid; i <= E; i += PLAN_THREADS) ssb[i] = slot_base[i];
+    }
     __syncthreads();
+    if (slot_base) {
+      for (int e = tid; e < E; e += PLAN_THREADS) {
+        int32_t c = ssb[e + 1] - ssb[e] - hdr_rows;
+        c = c < 0 ? 0 : c;
+        if (capacity >= 0 && (int64_t)c > capacity) c = (int32_t)capacity;
+        scap[e] = c;
+      }
+    }
     // the count table: tab_rows rows of E, row b = the entries [b CH / tab_ratio, (b + 1) CH / tab_ratio) -- this kernel's own
     // chunks (tab_ratio 1, smoe_dispatch_plan's counting launch) or the finer chunks the fused router counted on its way
     // (smoe_dispatch_plan_hist): the rows in front of this workgroup's chunk are those below me * tab_ratio
@@ -129,7 +146,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
       int32_t acc = 0;
       for (int e = 0; e < E; ++e) {
         int32_t c = stot[e];
-        if (capacity >= 0 && (int64_t)c > capacity) c = (int32_t)capacity;
+        if (me == 0 && raw_out) raw_out[e] = c;   // the un-clamped total: what the speculative exchange's overflow test reads
+        if (slot_base) { if (c > scap[e]) c = scap[e]; }
+        else if (capacity >= 0 && (int64_t)c > capacity) c = (int32_t)capacity;
         stot[e] = c;
         soff[e] = acc;
         acc += c;
@@ -141,9 +160,15 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
       for (int e = tid; e < E; e += PLAN_THREADS) counts_out[e] = stot[e];
       for (int e = tid; e <= E; e += PLAN_THREADS) offsets_out[e] = soff[e];
       if (group_end_out)
-        for (int e = tid; e < E; e += PLAN_THREADS) group_end_out[e] = (int32_t)(e * slot_stride) + stot[e];
+        for (int e = tid; e < E; e += PLAN_THREADS)
+          group_end_out[e] = (slot_base ? ssb[e] : (int32_t)(e * slot_stride)) + stot[e];
     }
-    if (slot_stride > 0) {
+    if (slot_base) {
+      // unused payload slots (and the header rows) of every expert's range hold no entry
+      for (int e = 0; e < E; ++e)
+        for (int64_t sl = (int64_t)ssb[e] + stot[e] + (int64_t)me * PLAN_THREADS + tid; sl < ssb[e + 1]; sl += (int64_t)nblk * PLAN_THREADS)
+          pos[sl] = -1;
+    } else if (slot_stride > 0) {
       // unused slots of every expert's fixed range hold no entry; the workgroups share the E * slot_stride slots evenly
       const int64_t total = (int64_t)E * slot_stride, share = (total + nblk - 1) / nblk;
       for (int64_t sl = (int64_t)me * share + tid; sl < (int64_t)(me + 1) * share && sl < total; sl += PLAN_THREADS) {
@@ -203,9 +228,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void plan_assign_kernel(
     }
     if (e >= 0) {
       const int32_t raw = myrun[e] + rank_in_step;
-      const bool keep = (capacity < 0) || ((int64_t)raw < capacity);
+      const bool keep = FUSED && slot_base ? raw < scap[e] : ((capacity < 0) || ((int64_t)raw < capacity));
       if (keep) {
-        const int64_t slot = slot_stride > 0 ? (int64_t)e * slot_stride + raw : (int64_t)offsets[e] + raw;
+        const int64_t slot = FUSED && slot_base ? (int64_t)ssb[e] + raw
+                             : (slot_stride > 0 ? (int64_t)e * slot_stride + raw : (int64_t)offsets[e] + raw);
         pos[slot] = i;
         inv_pos[i] = slot;
       } else {
@@ -492,7 +518,8 @@ extern "C" size_t smoe_dispatch_plan_workspace_bytes(int64_t n, int E) {
 
 static int plan_impl(const int64_t* idx, int64_t n, int E, int64_t capacity, int32_t* counts, int32_t* offsets, int64_t* pos,
                      int64_t* inv_pos, int64_t* idx_pruned, void* workspace, size_t workspace_bytes, void* stream,
-                     int64_t slot_stride, int32_t* group_end) {
+                     int64_t slot_stride, int32_t* group_end, int32_t* raw_counts = nullptr, const int32_t* slot_base = nullptr,
+                     int hdr_rows = 0) {
   SMOE_REQUIRE(counts && offsets && workspace, "smoe_dispatch_plan: null pointer");
   SMOE_REQUIRE(n >= 0 && n < (1ll << 31), "smoe_dispatch_plan: n=%lld out of range", (long long)n);
   SMOE_REQUIRE(E >= 1 && E <= 8192, "smoe_dispatch_plan: E=%d out of range [1, 8192]", E);
@@ -508,13 +535,13 @@ static int plan_impl(const int64_t* idx, int64_t n, int E, int64_t capacity, int
   hipLaunchKernelGGL(plan_count_kernel, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)E * 4, s, idx, n, E, blockcnt);
   SMOE_CHECK_LAUNCH("smoe_dispatch_plan/count");
   if (n > 0 && E <= PLAN_FUSED_E && nblk * E <= PLAN_FUSED_MAX) {
-    hipLaunchKernelGGL(plan_assign_kernel<true>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)(PLAN_WAVES * E + 3 * E + 1) * 4, s,
+    hipLaunchKernelGGL(plan_assign_kernel<true>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)(PLAN_WAVES * E + 5 * E + 2) * 4, s,
                        idx, n, E, capacity, blockcnt, nullptr, pos, inv_pos, idx_pruned, (int)nblk, counts, offsets, slot_stride,
-                       group_end, (int)nblk, 1);
+                       group_end, (int)nblk, 1, raw_counts, slot_base, hdr_rows);
     SMOE_CHECK_LAUNCH("smoe_dispatch_plan/assign_fused");
     return 0;
   }
-  SMOE_REQUIRE(slot_stride == 0, "smoe_dispatch_plan_padded: the padded layout needs E <= %d and ceil(n / %d) * E <= %d",
+  SMOE_REQUIRE(slot_stride == 0 && !slot_base, "smoe_dispatch_plan_padded / _slots: the padded layouts need E <= %d and ceil(n / %d) * E <= %d",
                PLAN_FUSED_E, PLAN_CH, PLAN_FUSED_MAX);
   const int scan_threads = E < 64 ? 64 : (E > 1024 ? 1024 : ((E + 63) / 64) * 64);
   hipLaunchKernelGGL(plan_scan_kernel, dim3(1), dim3(scan_threads), (size_t)E * 4, s, blockcnt, (int)nblk, E, capacity, rawbase, counts, offsets);
@@ -549,7 +576,7 @@ extern "C" int smoe_dispatch_plan_hist(const int64_t* idx, int64_t n, int E, int
   SMOE_REQUIRE(counts && offsets && idx && pos && inv_pos, "smoe_dispatch_plan_hist: null pointer");
   SMOE_REQUIRE(n < (1ll << 31) && E >= 1, "smoe_dispatch_plan_hist: bad sizes");
   const int64_t nblk = plan_nblk(n);
-  hipLaunchKernelGGL(plan_assign_kernel<true>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)(PLAN_WAVES * E + 3 * E + 1) * 4,
+  hipLaunchKernelGGL(plan_assign_kernel<true>, dim3((int)nblk), dim3(PLAN_THREADS), (size_t)(PLAN_WAVES * E + 5 * E + 2) * 4,
                      (hipStream_t)stream, idx, n, E, capacity, hist, nullptr, pos, inv_pos, idx_pruned, (int)nblk, counts, offsets,
                      (int64_t)0, nullptr, (int)rows, PLAN_CH / hist_chunk);
   SMOE_CHECK_LAUNCH("smoe_dispatch_plan_hist/assign_fused");
@@ -558,15 +585,106 @@ extern "C" int smoe_dispatch_plan_hist(const int64_t* idx, int64_t n, int E, int
 
 extern "C" int smoe_dispatch_plan_padded(const int64_t* idx, int64_t n, int E, int64_t capacity, int64_t slot_rows,
                                          int32_t* counts, int32_t* offsets, int32_t* group_end, int64_t* pos_padded,
-                                         int64_t* inv_pos, int64_t* idx_pruned, void* workspace, size_t workspace_bytes,
-                                         void* stream) {
+                                         int64_t* inv_pos, int64_t* idx_pruned, int32_t* raw_counts, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
   SMOE_REQUIRE(capacity >= 1 && n >= 1, "smoe_dispatch_plan_padded: needs a capacity >= 1 and n >= 1");
   SMOE_REQUIRE(slot_rows >= capacity, "smoe_dispatch_plan_padded: slot_rows=%lld < capacity=%lld", (long long)slot_rows,
                (long long)capacity);
   SMOE_REQUIRE(group_end, "smoe_dispatch_plan_padded: null pointer");
   SMOE_REQUIRE((int64_t)E * slot_rows < (1ll << 31), "smoe_dispatch_plan_padded: E * slot_rows out of range");
   return plan_impl(idx, n, E, capacity, counts, offsets, pos_padded, inv_pos, idx_pruned, workspace, workspace_bytes, stream,
-                   slot_rows, group_end);
+                   slot_rows, group_end, raw_counts);
+}
+
+// The same plan over a SLOT TABLE (the static expert exchange, ep.py): expert e owns the slots [slot_base[e], slot_base[e + 1]) of
+// the send buffer, the last hdr_rows of them reserved (the in-band header row); it keeps min(region - hdr_rows, capacity if >= 0)
+// entries.  pos has slot_base[E] entries (unused ones -1); group_end[e] = slot_base[e] + counts[e]; raw_counts as above.
+extern "C" int smoe_dispatch_plan_slots(const int64_t* idx, int64_t n, int E, int64_t capacity, const int32_t* slot_base,
+                                        int hdr_rows, int32_t* counts, int32_t* offsets, int32_t* group_end, int64_t* pos_slots,
+                                        int64_t* inv_pos, int64_t* idx_pruned, int32_t* raw_counts, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  SMOE_REQUIRE(n >= 1 && slot_base && group_end, "smoe_dispatch_plan_slots: needs n >= 1, a slot table and group_end");
+  SMOE_REQUIRE(hdr_rows >= 0 && hdr_rows <= 1, "smoe_dispatch_plan_slots: hdr_rows must be 0 or 1");
+  return plan_impl(idx, n, E, capacity, counts, offsets, pos_slots, inv_pos, idx_pruned, workspace, workspace_bytes, stream, 0,
+                   group_end, raw_counts, slot_base, hdr_rows);
+}
+
+// ---- in-band headers of the static expert exchange (SURVEY.md N10 folded into N11) ---------------------------------------------
+// The static exchange's send buffer holds one region per global expert g, rows [slot_base[g], slot_base[g + 1]): payload rows
+// followed by ONE header row (the region's last).  The header's leading int32 words are
+//   {rows kept for this group, rows routed to it before the clamp, the source rank's row count T, E, raw[0], ..., raw[E - 1]}
+// -- raw = the SOURCE's pre-clamp counts for ALL E global experts.  The counts thereby travel WITH the rows: no count all-to-all
+// per layer (upstream's expert_exchange), and every receiver learns every source's T and whole routing histogram -- the same
+// [W, E] matrix on all ranks, which lets all ranks decide "somebody overflowed" and re-size the slots IDENTICALLY without a
+// collective (ep.py).
+namespace {
+__global__ void ep_pack_headers_kernel(const int32_t* __restrict__ counts, const int32_t* __restrict__ raw,
+                                       const int32_t* __restrict__ slot_base, int G, int64_t row_bytes, int32_t t_rows,
+                                       char* __restrict__ send) {
+  // one workgroup; thread (g, j): header g, word j of the raw vector
+  for (int i = threadIdx.x; i < G * (G + 4); i += blockDim.x) {
+    const int g = i / (G + 4), j = i - g * (G + 4);
+    int32_t* h = reinterpret_cast<int32_t*>(send + ((int64_t)slot_base[g + 1] - 1) * row_bytes);
+    int32_t v;
+    if (j == 0) v = counts ? counts[g] : 0;
+    else if (j == 1) v = raw ? raw[g] : (counts ? counts[g] : 0);
+    else if (j == 2) v = t_rows;
+    else if (j == 3) v = G;
+    else v = raw ? raw[j - 4] : (counts ? counts[j - 4] : 0);
+    h[j] = v;
+  }
+}
+
+// receiver: source w's block = rows [w * block_rows, (w + 1) * block_rows), block_rows = lbase[E_local]; inside it local expert e'
+// owns [lbase[e'], lbase[e' + 1]) (header = the last row).  group l = w * E_local + e'.
+__global__ void ep_unpack_headers_kernel(const char* __restrict__ recv, int W, int E_local, const int32_t* __restrict__ lbase,
+                                         int64_t row_bytes, int E_tot, int32_t* __restrict__ starts, int32_t* __restrict__ ends,
+                                         int32_t* __restrict__ stats) {
+  const int G = W * E_local;
+  const int64_t block_rows = lbase[E_local];
+  for (int l = threadIdx.x; l < G; l += blockDim.x) {
+    const int w = l / E_local, e = l - w * E_local;
+    const int64_t r0 = (int64_t)w * block_rows + lbase[e], r1 = (int64_t)w * block_rows + lbase[e + 1];
+    const int32_t* h = reinterpret_cast<const int32_t*>(recv + (r1 - 1) * row_bytes);
+    int32_t c = h[0];
+    const int32_t cap = (int32_t)(r1 - r0 - 1);
+    c = c < 0 ? 0 : (c > cap ? cap : c);
+    starts[l] = (int32_t)r0;
+    ends[l] = (int32_t)r0 + c;
+  }
+  if (stats) {
+    // stats[w] = {T of source w, raw[w][0 .. E_tot)} from the header of that source's first group
+    for (int i = threadIdx.x; i < W * (E_tot + 1); i += blockDim.x) {
+      const int w = i / (E_tot + 1), j = i - w * (E_tot + 1);
+      const int32_t* h = reinterpret_cast<const int32_t*>(recv + ((int64_t)w * block_rows + lbase[1] - 1) * row_bytes);
+      stats[i] = j == 0 ? h[2] : (h[3] == E_tot ? h[3 + j] : -1);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int smoe_ep_pack_headers(const int32_t* counts, const int32_t* raw_counts, const int32_t* slot_base, int G,
+                                    int64_t row_bytes, int64_t t_rows, void* send, void* stream) {
+  SMOE_REQUIRE(G >= 1 && G <= 1024 && row_bytes % 4 == 0 && row_bytes >= 16 + 4 * (int64_t)G,
+               "smoe_ep_pack_headers: bad sizes G=%d row_bytes=%lld (a header holds 4 + G int32 words)", G, (long long)row_bytes);
+  SMOE_REQUIRE(send && slot_base, "smoe_ep_pack_headers: null pointer");
+  SMOE_REQUIRE(t_rows >= 0 && t_rows < (1ll << 31), "smoe_ep_pack_headers: t_rows out of range");
+  hipLaunchKernelGGL(ep_pack_headers_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, raw_counts, slot_base, G,
+                     row_bytes, (int32_t)t_rows, (char*)send);
+  SMOE_CHECK_LAUNCH("smoe_ep_pack_headers");
+  return 0;
+}
+
+extern "C" int smoe_ep_unpack_headers(const void* recv, int W, int E_local, const int32_t* local_base, int64_t row_bytes, int E_total,
+                                      int32_t* starts, int32_t* ends, int32_t* stats, void* stream) {
+  SMOE_REQUIRE(W >= 1 && E_local >= 1 && (int64_t)W * E_local <= 8192 && E_total >= 1 && E_total <= 1024 && row_bytes % 4 == 0 &&
+               row_bytes >= 16 + 4 * (int64_t)E_total,
+               "smoe_ep_unpack_headers: bad sizes W=%d E_local=%d E_total=%d row_bytes=%lld", W, E_local, E_total, (long long)row_bytes);
+  SMOE_REQUIRE(recv && local_base && starts && ends, "smoe_ep_unpack_headers: null pointer");
+  hipLaunchKernelGGL(ep_unpack_headers_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const char*)recv, W, E_local, local_base,
+                     row_bytes, E_total, starts, ends, stats);
+  SMOE_CHECK_LAUNCH("smoe_ep_unpack_headers");
+  return 0;
 }
 
 static int scatter_rows_impl(const void* x, int x_dtype, const int64_t* pos, const float* scale, int64_t n_slots,

@@ -79,8 +79,8 @@ int gate_by_ln(bool with_ln, const float* x, const GLnArgs& ln, const SkipGateAr
 // all-zero row: top-k of the gate bias (ties -> lowest id, descending value), softmax over the kept k.  One wave per column.
 __global__ __launch_bounds__(256) void zero_row_output_kernel(const float* __restrict__ bg, int E, int k,
                                                               const float* __restrict__ w2, const float* __restrict__ b1,
-                                                              const float* __restrict__ b2, int d, int h,
-                                                              float* __restrict__ out) {
+                                                              const float* __restrict__ b2, int d, int h, int e_base,
+                                                              int E_local, float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= d) return;
@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void zero_row_output_kernel(const float* __res
   for (int r = 0; r < k; ++r) { ex[r] = expf(cval[r] - cval[0]); ssum += ex[r]; }
   float total = 0.f;
   for (int r = 0; r < k; ++r) {
-    const int e = chosen[r];
+    const int e = chosen[r] - e_base;              // expert parallel: only this rank's experts contribute to its partial sum
+    if (e < 0 || e >= E_local) continue;
     const float* wrow = w2 + ((int64_t)e * d + c) * h;
     float acc = 0.f;
     for (int j = lane; j < h; j += 64) {
@@ -245,10 +246,13 @@ extern "C" int smoe_gate_ln_router(const void* x, int x_dtype, int with_ln, cons
 }
 
 extern "C" int smoe_zero_row_output(const float* bg, int E, int k, const float* w2, const float* b1, const float* b2, int d,
-                                    int h, float* out, void* stream) {
+                                    int h, int e_base, int E_local, float* out, void* stream) {
   SMOE_REQUIRE(w2 && out, "smoe_zero_row_output: null pointer");
   SMOE_REQUIRE(E >= 1 && k >= 1 && k <= E && k <= R16_MAX_K && d > 0 && h > 0, "smoe_zero_row_output: bad sizes E=%d k=%d d=%d h=%d", E, k, d, h);
-  hipLaunchKernelGGL(zero_row_output_kernel, dim3((d + 3) / 4), dim3(256), 0, (hipStream_t)stream, bg, E, k, w2, b1, b2, d, h, out);
+  SMOE_REQUIRE(e_base >= 0 && E_local >= 1 && e_base + E_local <= E, "smoe_zero_row_output: local experts [%d, %d) outside [0, %d)",
+               e_base, e_base + E_local, E);
+  hipLaunchKernelGGL(zero_row_output_kernel, dim3((d + 3) / 4), dim3(256), 0, (hipStream_t)stream, bg, E, k, w2, b1, b2, d, h, e_base,
+                     E_local, out);
   SMOE_CHECK_LAUNCH("smoe_zero_row_output");
   return 0;
 }

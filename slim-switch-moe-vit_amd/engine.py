@@ -19,7 +19,15 @@ def _size_static_exchange(model: torch.nn.Module, data_loader) -> None:
                                             if hasattr(m, "ep_active")):
         return
     from .ep import set_static_tokens
-    set_static_tokens(model, int(bs) * int(pos.shape[1]))
+    set_static_tokens(model, int(bs) * int(pos.shape[1]), unit=int(pos.shape[1]))
+
+
+def _speculative_alpha(value):
+    """``ep_speculative`` of evaluate(): a number >= 1, None / 0 (off), or "auto" = SLIMMOE_EP_ALPHA (default 1.5; 0 = off)."""
+    import os
+    if value == "auto":
+        value = float(os.environ.get("SLIMMOE_EP_ALPHA", "1.5"))
+    return float(value) if value else None
 
 
 def accuracy(output: torch.Tensor, target: torch.Tensor, topk=(1,)):
@@ -32,32 +40,43 @@ def accuracy(output: torch.Tensor, target: torch.Tensor, topk=(1,)):
 
 @torch.no_grad()
 def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: torch.nn.Module, device,
-             autocast: bool = True):
+             autocast: bool = True, *, ep_speculative="auto"):
+    """engine.py:88-121.  Under expert parallelism the harness owns the step, so it can run the exchange WITHOUT a host round trip
+    per layer even for the reference's capacity-less NaiveGate: ``ep_speculative`` (alpha; "auto" = SLIMMOE_EP_ALPHA, default 1.5;
+    None / 0 = off) sizes static slots of alpha x the balanced share (ep.set_speculative), and a batch whose routing does not fit
+    -- reported by all ranks together -- is evaluated again on the counted exchange (ep.run_guarded): the metrics are those of the
+    counted exchange either way.  Returns the reference's dict keys plus images/sec and the number of repeated steps."""
+    from . import ep
     criterion = torch.nn.CrossEntropyLoss()
     model.eval()
     dev = torch.device(device)
     _size_static_exchange(model, data_loader)
-    n, loss_sum, a1, a5 = 0, 0.0, 0.0, 0.0
+    if any(m.ep_active() for m in ep._ep_modules(model)):
+        ep.set_speculative(model, _speculative_alpha(ep_speculative))
+    n, loss_sum, a1, a5, repeats = 0, 0.0, 0.0, 0.0, 0
     t0 = time.perf_counter()
     for images, target in data_loader:
         images = images.to(dev, non_blocking=True)
         target = target.to(dev, non_blocking=True)
-        with torch.autocast(device_type=dev.type, dtype=torch.float16, enabled=autocast and dev.type == "cuda"):
-            output = model(images)
-            loss = criterion(output, target)
+
+        def step():
+            with torch.autocast(device_type=dev.type, dtype=torch.float16, enabled=autocast and dev.type == "cuda"):
+                output = model(images)
+                return output, criterion(output, target)
+        # (flush: this step's overflow report is read before its numbers are -- the .item() below waits for the batch anyway)
+        (output, loss), again = ep.run_guarded(step, flush=True)
+        repeats += int(again)
         acc1, acc5 = accuracy(output, target, topk=(1, 5))
         bs = images.shape[0]
         n += bs
         loss_sum += loss.item() * bs
         a1 += acc1.item() * bs
         a5 += acc5.item() * bs
-        from .ep import check_static_overflow
-        check_static_overflow(flush=True)     # (the .item() above already waited for the batch)
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     n = max(n, 1)
-    return {"loss": loss_sum / n, "acc1": a1 / n, "acc5": a5 / n, "images_per_sec": n / dt}
+    return {"loss": loss_sum / n, "acc1": a1 / n, "acc5": a5 / n, "images_per_sec": n / dt, "ep_repeated_steps": repeats}
 
 
 def _criterion_takes_inputs(criterion) -> bool:

@@ -90,6 +90,16 @@ def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, 
                                   async_op=async_op)
 
 
+def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum of ``t`` over the group's ranks, on the group's own transport (a gloo group cannot take CUDA tensors)."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        return h.to(t.device)
+    dist.all_reduce(t, group=group)
+    return t
+
+
 class _PinnedPool:
     """Reusable pinned host buffers for the count read-back (hipHostMalloc per layer would cost more than the copy)."""
 
@@ -115,7 +125,8 @@ def _offsets_buffer(length: int, device) -> torch.Tensor:
     """An int32 [length] buffer with element 0 == 0 for a received-groups offset table (cumsum fills [1:]).  Taken round-robin from
     a ring per (device, length): the consumer (the grouped GEMM) runs on the stream that filled it, and a buffer comes around again
     only after 63 later tables were built on that stream."""
-    key = (str(device), int(length))
+    stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+    key = (str(device), int(length), stream)     # per stream: a side stream's cumsum never rewrites a table another stream's GEMM reads
     ent = _offs_pool.get(key)
     if ent is None:
         ent = _offs_pool[key] = [[torch.zeros(length, dtype=torch.int32, device=device) for _ in range(_OFFS_RING)], 0]
@@ -232,12 +243,11 @@ def drain(gen):
         return stop.value
 
 
-_starts_cache = StreamCache()
-
-
 class StaticExchangeOverflow(RuntimeError):
-    """A rank brought more rows than the static exchange buffers were agreed for.  Raised on EVERY rank of the group, at the same
-    point of the program (check_static_overflow), never by one rank alone in front of a collective."""
+    """A rank brought more rows than the static exchange buffers were agreed for, or -- speculative exchange of a gate without a
+    capacity -- routed more rows to one expert than a slot holds.  Raised on EVERY rank of the group, at the same point of the
+    program (check_static_overflow), never by one rank alone in front of a collective.  The outputs computed since the overflowing
+    forward are void; the modules are re-sized when this is raised, and ``run_guarded`` repeats the step on the dynamic path."""
 
 
 def _control_tensor(values, group, device) -> torch.Tensor:
@@ -246,19 +256,35 @@ def _control_tensor(values, group, device) -> torch.Tensor:
     return torch.tensor(values, dtype=torch.int64, device="cpu" if on_cpu else device)
 
 
+def _rows_div(mod) -> int:
+    """How many micro-batches the caller cuts the local batch into right now (vit.VisionTransformer sets ``ep_rows_div`` on every
+    expert-parallel module before a pipelined forward -- shared configuration, the same on every rank): the static buffers are
+    agreed, and sized, per micro-batch."""
+    return max(1, int(getattr(mod, "ep_rows_div", 1)))
+
+
 def static_slot_tokens(mod, T: int, device) -> int:
     """The row count T_slot the static exchange buffers of ``mod`` are sized for (every (source rank, expert) slot holds
     capacity(T_slot) rows).  It must be the same on every rank, whatever each rank's own batch is, and it must be known WITHOUT
-    communication once the job runs -- so it is agreed ONCE per module, on its first expert-parallel forward, by a collective
-    EVERY rank runs unconditionally (all ranks run the same layers in the same order, so it matches): an all-gather of
-    (preset ``ep_static_tokens`` or -1, this rank's row count).  No preset anywhere: the largest row count wins.  The same preset
-    everywhere (``set_static_tokens`` / ``mod.ep_static_tokens = n`` on every rank, e.g. from the loader's batch size): that value.
-    Presets that differ between ranks: every rank raises the same error.  Later batches must fit; one that does not is reported by
-    ``check_static_overflow`` on all ranks together (never by the overflowing rank alone: that deadlocked its peers)."""
-    st = mod.__dict__.get("_ep_static_agreed")
+    communication once the job runs -- so it is agreed ONCE per module (and per micro-batch divisor, ``ep_rows_div``), on its first
+    expert-parallel forward, by a collective EVERY rank runs unconditionally (all ranks run the same layers in the same order, so
+    it matches): an all-gather of (preset ``ep_static_tokens`` or -1, this rank's row count).  No preset anywhere: the largest row
+    count wins.  The same preset everywhere (``set_static_tokens`` / ``mod.ep_static_tokens = n`` on every rank, e.g. from the
+    loader's batch size; a preset counts rows of the WHOLE local batch -- under a divisor n it stands for ceil(preset / (n unit))
+    unit rows, ``unit`` = ``ep_rows_unit``, the tokens per image): that value.  Presets that differ between ranks: every rank raises
+    the same error.  Later batches must fit; one that does not is reported by ``check_static_overflow`` on all ranks together
+    (never by the overflowing rank alone: that deadlocked its peers)."""
+    div = _rows_div(mod)
+    table = mod.__dict__.get("_ep_static_agreed")
+    if table is None:
+        table = mod.__dict__["_ep_static_agreed"] = {}
+    st = table.get(div)
     if st is not None:
         return st
     have = getattr(mod, "ep_static_tokens", None)
+    if have is not None and div > 1:
+        unit = max(1, int(getattr(mod, "ep_rows_unit", 1)))
+        have = -(-int(have) // (div * unit)) * unit
     if mod.world_size > 1:
         group = mod.moe_group
         mine = _control_tensor([-1 if have is None else int(have), int(T)], group, device)
@@ -274,87 +300,289 @@ def static_slot_tokens(mod, T: int, device) -> int:
                                "set the same value on every rank's module, or on none")
     else:
         agreed = max(int(have) if have is not None else int(T), 1)
-    mod.ep_static_tokens = agreed
-    mod.__dict__["_ep_static_agreed"] = agreed
+    if div == 1:
+        mod.ep_static_tokens = agreed
+    table[div] = agreed
     return agreed
 
 
-def set_static_tokens(model: torch.nn.Module, rows: int) -> int:
+def _ep_modules(model: torch.nn.Module):
+    return [m for m in model.modules() if hasattr(m, "ep_active") and hasattr(m, "gate") and hasattr(m, "experts")]
+
+
+def set_static_tokens(model: torch.nn.Module, rows: int, unit: int = 1) -> int:
     """Size the static exchange buffers of every expert-parallel MoE module of ``model`` for batches of up to ``rows`` token rows
     per rank (call it with the same value on every rank BEFORE the first forward -- engine.evaluate / train_one_epoch do, from
-    the loader's batch size -- or again later, on every rank, to re-size).  Returns the number of modules touched."""
+    the loader's batch size -- or again later, on every rank, to re-size).  ``unit`` = token rows per image (micro-batches are cut
+    between images).  Returns the number of modules touched."""
     n = 0
-    for m in model.modules():
-        if hasattr(m, "ep_active") and hasattr(m, "gate") and hasattr(m, "experts"):
-            m.ep_static_tokens = int(rows)
-            m.__dict__.pop("_ep_static_agreed", None)
+    for m in _ep_modules(model):
+        m.ep_static_tokens = int(rows)
+        m.ep_rows_unit = int(unit)
+        m.__dict__.pop("_ep_static_agreed", None)
+        n += 1
+    return n
+
+
+# ---- speculative static exchange for gates WITHOUT a capacity (the reference's NaiveGate: models/resMoE.py:26 "use naive-gate") ----
+# A NaiveGate puts no bound on an expert's share, so its exchange is sized by the routing: upstream (and the dynamic path here) reads
+# the count matrix back to the host in every layer.  The speculative exchange sizes every (source rank, expert) slot for
+# ceil(alpha * rows * k / E) rows -- alpha x the balanced share -- and runs the capacity gates' static machinery on it: fixed-size
+# buffers, equal-split all-to-alls, the counts in-band, NO host round trip.  A routing that does not fit is detected on the device
+# (the plan's pre-clamp counts travel in the headers), reported by every rank together (check_static_overflow), and the step is
+# repeated on the dynamic path (run_guarded) -- so the results are those of the dynamic path: bit for bit when nothing overflows
+# (same rows, same groups, same kernels), and after the repeat when something did.  It is OPT-IN per model (set_speculative):
+# somebody has to repeat an overflowing step, and only a harness that owns the step can (engine.evaluate, bench.py).
+def set_speculative(model: torch.nn.Module, alpha: Optional[float]) -> int:
+    """Switch the speculative static exchange on (alpha >= 1: slot = ceil(alpha * rows * k / E)) or off (None) for every
+    expert-parallel MoE module of ``model`` whose gate has no capacity.  Same value on every rank.  Returns the modules touched."""
+    n = 0
+    for m in _ep_modules(model):
+        if m.gate.capacity(1 << 20) < 0:
+            m.ep_speculative = None if alpha is None else max(1.0, float(alpha))
             n += 1
     return n
 
 
-def use_static_exchange(mod, cd) -> bool:
-    """Static (capacity-padded) or dynamic (count read-back + all-to-all-v) exchange?  The two issue DIFFERENT collectives, so the
-    choice may only depend on what all ranks share -- the module's configuration -- never on a rank's own batch: a capacity gate
-    (E <= 63 groups of the fused plan kernel and of the persistent GEMM's row ranges), 16-bit operands, the persistent GEMM,
-    the fused GELU activation without dropout.  SLIMMOE_EP_STATIC=0 switches it off (A/B; set it on every rank)."""
-    if os.environ.get("SLIMMOE_EP_STATIC", "1") == "0":
-        return False
+_FORCE_DYNAMIC = 0
+
+
+class dynamic_only:
+    """Context: every expert-parallel forward inside takes the dynamic (counted) exchange -- the repeat of a step whose routing
+    overflowed the speculative slots.  Enter it on every rank at the same point of the program."""
+
+    def __enter__(self):
+        global _FORCE_DYNAMIC
+        _FORCE_DYNAMIC += 1
+
+    def __exit__(self, *a):
+        global _FORCE_DYNAMIC
+        _FORCE_DYNAMIC -= 1
+
+
+def static_kind(mod, cd) -> Optional[str]:
+    """None (dynamic: count read-back + all-to-all-v), "capacity" (a capacity gate's static exchange) or "speculative" (a gate
+    without a capacity on alpha-sized slots).  The kinds issue DIFFERENT collectives, so the choice may only depend on what all
+    ranks share -- the module's configuration and switches set on every rank alike -- never on a rank's own batch: <= 63 groups of
+    the fused plan kernel and of the persistent GEMM's row ranges, 16-bit operands, the persistent GEMM, the fused GELU
+    activation without dropout.  SLIMMOE_EP_STATIC=0 switches both off (A/B; set it on every rank)."""
+    if _FORCE_DYNAMIC or os.environ.get("SLIMMOE_EP_STATIC", "1") == "0":
+        return None
     g = mod.gate
-    return (g.capacity(1 << 20) >= 0 and g.tot_expert <= 63 and mod.gemm_variant in (9, 10, 11, 12, 13, 14)
-            and cd in (torch.float16, torch.bfloat16) and mod.d_model % 64 == 0 and mod.d_hidden % 64 == 0 and mod._fused_gelu
-            and not (mod._drop_p > 0 and mod.training))
+    if not (g.tot_expert <= 63 and mod.gemm_variant in (9, 10, 11, 12, 13, 14) and cd in (torch.float16, torch.bfloat16)
+            and mod.d_model % 64 == 0 and mod.d_hidden % 64 == 0 and mod._fused_gelu and not (mod._drop_p > 0 and mod.training)):
+        return None
+    if g.capacity(1 << 20) >= 0:
+        return "capacity"
+    if getattr(mod, "ep_speculative", None) is not None and not mod.training:
+        return "speculative"
+    return None
+
+
+def use_static_exchange(mod, cd) -> bool:
+    return static_kind(mod, cd) is not None
+
+
+def speculative_slot(mod, agreed: int) -> int:
+    import math
+    return max(1, int(math.ceil(float(mod.ep_speculative) * agreed * mod.top_k / mod.gate.tot_expert)))
 
 
 def static_plan_fits(mod, agreed: int) -> bool:
-    """The fused padded-plan kernel's table limit, evaluated on the AGREED row count (the same on every rank)."""
+    """The fused slot-plan kernel's table limit, evaluated on the AGREED row count (the same on every rank)."""
     return (-(-agreed * mod.top_k // 1024)) * mod.gate.tot_expert <= 8192
 
 
-# ---- overflow watch: every rank learns every rank's row count with the count exchange; the check is deferred so that it never
-#      makes the host wait for the GPU (the static path's point), and it is deterministic so that all ranks raise together ------
-OVERFLOW_LAG = 32          # exchanges between posting a row-count vector and reading it on the host
-_overflow_pending = []     # [(event | None, host int32 [W], agreed, module)]
+class _SlotTable:
+    """Send layout of one static exchange: global expert e owns ``caps[e]`` payload rows + ONE header row of the send buffer,
+    regions in expert order (so that the E_local regions of a destination rank are contiguous).  Host lists for the buffer shapes
+    and the all-to-all splits, device tables for the plan / header kernels."""
+
+    def __init__(self, caps, rank: int, E_local: int, device):
+        self.caps = [max(1, int(c)) for c in caps]
+        E = len(self.caps)
+        W = E // E_local
+        base = [0]
+        for c in self.caps:
+            base.append(base[-1] + c + 1)
+        self.rows = base[-1]                                             # rows of the send (and the returned) buffer
+        self.in_splits = [base[(w + 1) * E_local] - base[w * E_local] for w in range(W)]   # rows this rank sends to rank w
+        lb = [base[rank * E_local + i] - base[rank * E_local] for i in range(E_local + 1)]
+        self.out_splits = [lb[-1]] * W                                   # every source sends this rank's experts' regions
+        self.recv_rows = W * lb[-1]
+        self.base_dev = torch.tensor(base, dtype=torch.int32, device=device)
+        self.lbase_dev = torch.tensor(lb, dtype=torch.int32, device=device)
 
 
-def _watch_overflow(peer_rows: torch.Tensor, agreed: int, mod) -> None:
-    if peer_rows.is_cuda:
-        host = _pinned.take(peer_rows.shape, peer_rows.dtype)
-        host.copy_(peer_rows, non_blocking=True)
+HEADROOM = float(os.environ.get("SLIMMOE_EP_HEADROOM", "1.12"))   # speculative slots after adaptation: ceil(HEADROOM x the largest group seen)
+ADAPT_MIN_OBS = 2          # exchanges observed before a module's slots are cut to what its routing needs
+SHRINK_RATIO = 1.08        # ... and only when that saves more than this factor of the buffer rows
+
+
+class _SlotState:
+    """Per (module, micro-batch divisor): the slot table in use and what the headers of its exchanges reported since it was made."""
+
+    def __init__(self, mod, kind: str, agreed: int, caps, device):
+        self.mod, self.kind, self.agreed, self.device = mod, kind, agreed, device
+        self.alpha = getattr(mod, "ep_speculative", None)
+        self.headroom = HEADROOM
+        self.obs, self.n_obs = [0] * len(caps), 0
+        self._install(caps)
+
+    def _install(self, caps):
+        mod = self.mod
+        rank = dist.get_rank(mod.moe_group) if mod.world_size > 1 else 0
+        self.table = _SlotTable(caps, rank, mod.num_expert, self.device)
+
+    def fitted_caps(self):
+        import math
+        return [max(1, int(math.ceil(self.headroom * o))) for o in self.obs]
+
+
+def _slot_state(mod, kind: str, agreed: int, device) -> "_SlotState":
+    """The slot state of ``mod`` for the current micro-batch divisor; (re)made -- from shared values only: the gate's capacity or
+    alpha x the balanced share of the AGREED row count -- when there is none, or the agreed row count / kind / alpha changed."""
+    div = _rows_div(mod)
+    table = mod.__dict__.setdefault("_ep_slots", {})
+    st = table.get(div)
+    alpha = getattr(mod, "ep_speculative", None)
+    if st is None or st.agreed != agreed or st.kind != kind or (kind == "speculative" and st.alpha != alpha):
+        E_tot = mod.gate.tot_expert
+        cap = max(1, mod.gate.capacity(agreed)) if kind == "capacity" else speculative_slot(mod, agreed)
+        st = table[div] = _SlotState(mod, kind, agreed, [cap] * E_tot, device)
+    return st
+
+
+# ---- overflow watch: every rank learns every rank's row count and routing histogram from the headers of the exchange; the check is
+#      deferred so that it never makes the host wait for the GPU (the static path's point), and it is deterministic so that all
+#      ranks raise -- and re-size -- together ------------------------------------------------------------------------------------
+OVERFLOW_LAG = 32          # exchanges between posting a stats matrix and reading it on the host
+_overflow_pending = []     # [(event | None, host int32 [W, 1 + E], state, caps of that exchange, div, pooled)]
+
+
+def _watch_overflow(stats: torch.Tensor, st: "_SlotState") -> None:
+    """``stats`` i32 [W, 1 + E] = (row count, pre-clamp count per global expert) of every source rank -- identical on all ranks."""
+    mod = st.mod
+    div = _rows_div(mod)
+    if stats.is_cuda:
+        if torch.cuda.is_current_stream_capturing():
+            mod.__dict__["_ep_last_stats"] = (stats, st, list(st.table.caps))   # a captured forward: read after a replay
+            return
+        host = _pinned.take(stats.shape, stats.dtype)
+        host.copy_(stats, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        _overflow_pending.append((ev, host, agreed, mod, True))
+        _overflow_pending.append((ev, host, st, st.table.caps, div, True))
     else:
-        _overflow_pending.append((None, peer_rows.clone(), agreed, mod, False))
+        _overflow_pending.append((None, stats.clone(), st, st.table.caps, div, False))
+
+
+def _judge(rows, st: "_SlotState", caps):
+    """(largest row count, per-expert largest group, T overflow?, slot overflow?) of one stats matrix."""
+    t_max = max((r[0] for r in rows), default=0)
+    g_max = [max(r[1 + e] for r in rows) for e in range(len(caps))] if rows else [0] * len(caps)
+    over_t = t_max > st.agreed
+    over_s = st.kind == "speculative" and any(g > c for g, c in zip(g_max, caps))
+    return t_max, g_max, over_t, over_s
+
+
+def captured_overflow(model: torch.nn.Module) -> bool:
+    """After replaying a captured (HIP graph) expert-parallel forward: did any module's last exchange overflow?  Reads the stats
+    the captured kernels left on the device (a host sync)."""
+    bad = False
+    for m in _ep_modules(model):
+        ent = m.__dict__.get("_ep_last_stats")
+        if ent is not None:
+            stats, st, caps = ent
+            _, _, over_t, over_s = _judge(stats.cpu().tolist(), st, caps)
+            bad |= over_t or over_s
+    return bad
 
 
 def check_static_overflow(flush: bool = False) -> None:
-    """Reads the row-count vectors posted at least OVERFLOW_LAG exchanges ago (all of them with ``flush``: the harness calls that
-    at the end of a step).  Every rank holds the SAME vectors and runs the same sequence of exchanges, so every rank raises
-    StaticExchangeOverflow at the same call -- after re-sizing the module for the largest batch seen, so that repeating the
-    step (on every rank) works.  The outputs computed since the overflowing forward are void: that rank dropped the rows
-    that did not fit its slots to keep its buffers' agreed shape."""
+    """Reads the stats matrices posted at least OVERFLOW_LAG exchanges ago (all of them with ``flush``: the harness calls that
+    at the end of a step).  Every rank holds the SAME matrices and runs the same sequence of exchanges, so every rank takes the same
+    decisions at the same call: (1) an exchange whose source brought more rows than agreed, or routed more rows to an expert than its
+    speculative slot holds, overflowed -- EVERY module that overflowed among the matrices read is re-sized (row counts: the largest
+    batch seen; slots: HEADROOM x the largest group seen, per expert) and StaticExchangeOverflow is raised, so that repeating the
+    step (on every rank) works; the outputs computed since the overflowing forward are void: that rank dropped the rows that did not
+    fit to keep its buffers' agreed shape.  (2) Without an overflow, a speculative module whose slots are more than SHRINK_RATIO x
+    what its observed routing needs gets slots of HEADROOM x the largest group seen PER EXPERT (the first, uniform alpha-sized table
+    knows nothing of the experts' shares): the all-to-all then carries ~HEADROOM x the routed rows instead of alpha x."""
+    due = []
     while _overflow_pending and (flush or len(_overflow_pending) > OVERFLOW_LAG):
-        ev, host, agreed, mod, pooled = _overflow_pending.pop(0)
+        due.append(_overflow_pending.pop(0))
+    if not due:
+        return
+    touched, overflowed, report = {}, {}, None
+    for ev, host, st, caps, div, pooled in due:
         if ev is not None:
             ev.synchronize()
-        worst = int(host.max()) if host.numel() else 0
         rows = host.tolist()
         if pooled:
             _pinned.give(host)
-        if worst > agreed:
-            _overflow_pending.clear()
-            mod.ep_static_tokens = worst
-            mod.__dict__["_ep_static_agreed"] = worst
-            raise StaticExchangeOverflow(
-                f"expert-parallel static exchange: the ranks brought {rows} rows, the buffers were agreed for {agreed}; the "
-                f"outputs since then are void.  The module is now sized for {worst}: repeat the step on every rank, or call "
-                "ep.set_static_tokens(model, rows) with the largest local batch's row count on every rank before the first forward")
+        t_max, g_max, over_t, over_s = _judge(rows, st, caps)
+        st.obs = [max(a, b) for a, b in zip(st.obs, g_max)]
+        st.n_obs += 1
+        touched[id(st)] = (st, div)
+        if over_t or over_s:
+            prev = overflowed.get(id(st), (st, div, 0))
+            overflowed[id(st)] = (st, div, max(prev[2], t_max))
+            if report is None:
+                report = (f"the ranks brought {[r[0] for r in rows]} rows, the buffers were agreed for {st.agreed}" if over_t else
+                          f"the routing put up to {g_max} rows (per expert, from one source) into slots of {list(caps)}")
+    if report is None:
+        for st, div in touched.values():          # (2) cut a speculative module's slots to its routing
+            if st.kind == "speculative" and st.n_obs >= ADAPT_MIN_OBS:
+                fit = st.fitted_caps()
+                if sum(st.table.caps) > SHRINK_RATIO * sum(fit):
+                    st._install(fit)
+                    st.obs, st.n_obs = [0] * len(fit), 0
+        return
+    # every later matrix is void as well (computed on dropped rows): return their buffers, forget them
+    for ev, host, *_rest, pooled in _overflow_pending:
+        if pooled:
+            if ev is not None:
+                ev.synchronize()
+            _pinned.give(host)
+    _overflow_pending.clear()
+    for st, div, t_max in overflowed.values():
+        mod = st.mod
+        if t_max > st.agreed:
+            table = mod.__dict__.setdefault("_ep_static_agreed", {})
+            table[div] = max(t_max, table.get(div, 0))
+            if div == 1:
+                mod.ep_static_tokens = table[div]
+            if st.kind == "speculative":          # the next _slot_state call re-makes the table for the new row count; keep what
+                st.obs = [0] * len(st.obs)        # was learnt out of it (the observed groups belong to a dropped batch)
+        elif st.kind == "speculative":
+            st.headroom = min(2.0, st.headroom * 1.05) if st.n_obs > 1 else st.headroom
+            st._install([max(c, f) for c, f in zip(st.table.caps, st.fitted_caps())])
+    raise StaticExchangeOverflow(
+        f"expert-parallel static exchange: {report}; the outputs since then are void.  {len(overflowed)} module(s) re-sized: "
+        "repeat the step on every rank (ep.run_guarded does, on the counted exchange), or size the buffers up front with "
+        "ep.set_static_tokens(model, rows) / a larger alpha in ep.set_speculative(model, alpha)")
+
+
+def run_guarded(fn, flush: bool = True):
+    """``fn()`` = one step's forward (every rank calls this at the same point).  An overflow of the static exchange buffers --
+    reported by all ranks together -- voids the step: it is repeated ONCE on the counted exchange (results identical to what the
+    static path gives when everything fits).  ``flush``: read this step's stats before returning (a host sync at the end of the
+    step -- the harness reads the loss there anyway); without it an overflow surfaces up to OVERFLOW_LAG exchanges later and this
+    call repeats the step it surfaces in.  Returns (result, repeated: bool)."""
+    try:
+        out = fn()
+        check_static_overflow(flush=flush)
+        return out, False
+    except StaticExchangeOverflow:
+        with dynamic_only():
+            return fn(), True
 
 
 def exchange_counts_static(counts: torch.Tensor, T: int, W: int, group=None):
-    """The static path's count exchange, device to device: rank r sends [E_local counts for peer w | its own row count T] to
-    every peer w.  Returns (recv_counts i32 [W * E_local] in [source rank][local expert] order, peer_rows i32 [W] = every rank's
-    row count -- identical on all ranks).  Nobody on the host reads the counts; peer_rows feeds the overflow watch."""
+    """A count exchange device to device (kept for the C-ABI transport's tests; the static forward carries its counts in-band,
+    _ep_forward_static): rank r sends [E_local counts for peer w | its own row count T] to every peer w.  Returns (recv_counts i32
+    [W * E_local] in [source rank][local expert] order, peer_rows i32 [W] = every rank's row count -- identical on all ranks)."""
     E_local = counts.numel() // W
     both = torch.empty((2, W, E_local + 1), dtype=torch.int32, device=counts.device)
     both[0, :, :E_local].copy_(counts.view(W, E_local))
@@ -363,18 +591,20 @@ def exchange_counts_static(counts: torch.Tensor, T: int, W: int, group=None):
     return both[1, :, :E_local].reshape(-1), both[1, :, E_local]
 
 
-def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual, next_norm=None, agreed: Optional[int] = None):
-    """Expert-parallel forward of a CAPACITY gate on static buffers ("cfg 5 (capacity-bounded) can use
-    fixed-size padded buffers -> no host sync"; Appendix B's `cap` note).  A rank keeps at most `cap` of its rows per
-    global expert, so every (source rank, expert) pair owns a fixed slot of `slot` >= `cap` rows (the capacity of the row
-    count all ranks agreed on, static_slot_tokens): the send buffer is [W, E_local, slot, d], both all-to-alls have EQUAL
-    splits known without looking at the routing, and nothing of the layer
-    waits for the host -- the received counts stay on the device, where the grouped GEMM takes them as the end of each slot's
-    row range (group_end) and never schedules a tile over padding.  Yields at the two exchanges (micro-batch pipelining).
+def _ep_forward_static(mod, x, src, idx, plan_idx, score, probs, cd, residual, next_norm, agreed: int, kind: str):
+    """Expert-parallel forward on STATIC buffers ("cfg 5 (capacity-bounded) can use fixed-size padded
+    buffers -> no host sync"; Appendix B's `cap` note) -- for a capacity gate (``kind`` "capacity": a rank keeps at most `cap` of
+    its rows per global expert) and, speculatively, for a gate without one ("speculative": slots of alpha x the balanced share,
+    cut per expert to HEADROOM x what the routing needs once it has been observed).  Every global expert owns a fixed region of the
+    send buffer -- its slot's payload rows plus ONE header row (_SlotTable) -- so both all-to-alls have splits known without
+    looking at the routing, the counts travel in the header rows (smoe_ep_pack_headers / _unpack_headers: no count collective),
+    and nothing of the layer waits for the host: the received counts stay on the device, where the grouped GEMM takes them as the
+    end of each group's row range (group_end) and never schedules a tile over padding.  Two collectives per layer.  Yields at the
+    two exchanges (micro-batch pipelining).
 
-    A rank with NO rows takes the same path with empty slots.  A rank with MORE rows than agreed keeps the agreed buffer shape
-    (it drops what does not fit a slot; its peers must not hang) and the violation is raised on every rank by
-    check_static_overflow -- never here, by this rank alone."""
+    A rank with NO rows takes the same path with empty slots.  A rank with MORE rows than agreed, or a speculative group larger
+    than its slot, keeps the agreed buffer shape (it drops what does not fit; its peers must not hang) and the violation is raised
+    on every rank by check_static_overflow -- never here, by this rank alone."""
     from . import ops
     from .fmoe import SwitchGate
 
@@ -383,53 +613,52 @@ def _ep_forward_static(mod, x, src, idx, score, probs, cap: int, cd, residual, n
     group = mod.moe_group
     T = x.shape[0]
     E_tot = g.tot_expert
-    if agreed is None:
-        agreed = static_slot_tokens(mod, T, x.device)
-    slot = max(1, g.capacity(agreed))
-    cap_eff = min(cap, slot)
-    if T > 0 and cap_eff >= 1 and T <= agreed:
-        counts, offsets, gend, pos_pad, inv_pos, pruned = ops.dispatch_plan_padded(idx, E_tot, cap_eff, slot)
-    elif T > 0 and cap_eff >= 1:
-        # over the agreed size: the plan over the first `agreed` rows only (the fused plan kernel's table is sized for that)
-        counts, offsets, gend, pos_pad, inv_h, pruned_h = ops.dispatch_plan_padded(idx[:agreed].contiguous(), E_tot, cap_eff, slot)
-        inv_pos = torch.full((T * k,), -1, dtype=torch.int64, device=x.device)
-        inv_pos[: agreed * k].copy_(inv_h)
-        pruned = torch.full((T * k,), -1, dtype=torch.int64, device=x.device)
-        pruned[: agreed * k].copy_(pruned_h)
-    else:
-        counts = torch.zeros(E_tot, dtype=torch.int32, device=x.device)
-        offsets = torch.zeros(E_tot + 1, dtype=torch.int32, device=x.device)
-        pos_pad = torch.full((E_tot * slot,), -1, dtype=torch.int64, device=x.device)
-        inv_pos = torch.full((T * k,), -1, dtype=torch.int64, device=x.device)
-        pruned = torch.full((T * k,), -1, dtype=torch.int64, device=x.device)
-    mod.last_plan = (idx, score, counts, offsets, pos_pad, inv_pos)
-    if isinstance(g, SwitchGate) and T > 0:
-        from .autograd import switch_aux_loss
-        g.set_loss(switch_aux_loss(pruned, probs, E_tot))
-    # counts (and every rank's row count) travel device to device; nobody on the host reads the counts
-    recv_counts, peer_rows = exchange_counts_static(counts, T, W, group)
-    _watch_overflow(peer_rows, agreed, mod)
+    dev = x.device
+    st = _slot_state(mod, kind, agreed, dev)
+    tab = st.table
+    counts = raw = None
     if T > 0:
-        send = ops.scatter_rows(src, pos_pad, k, cd)                   # [E_tot * slot, d]; unused slots stay unwritten
+        cap = g.capacity(T) if kind == "capacity" else -1               # (on top of the slots: what THIS batch may keep)
+        if T <= agreed:
+            counts, offsets, gend, pos, inv_pos, pruned, raw = ops.dispatch_plan_slots(plan_idx, E_tot, tab.base_dev, tab.rows, cap)
+        else:
+            # over the agreed size: the plan over the first `agreed` rows only (the fused plan kernel's table is sized for that)
+            counts, offsets, gend, pos, inv_h, pruned_h, raw = ops.dispatch_plan_slots(plan_idx[:agreed].contiguous(), E_tot,
+                                                                                       tab.base_dev, tab.rows, cap)
+            inv_pos = torch.full((T * k,), -1, dtype=torch.int64, device=dev)
+            inv_pos[: agreed * k].copy_(inv_h)
+            pruned = torch.full((T * k,), -1, dtype=torch.int64, device=dev)
+            pruned[: agreed * k].copy_(pruned_h)
+        send = ops.scatter_rows(src, pos, k, cd)                        # [tab.rows, d]; unused slots stay unwritten
+        mod.last_plan = (idx, score, counts, offsets, pos, inv_pos)
+        if isinstance(g, SwitchGate):
+            from .autograd import switch_aux_loss
+            g.set_loss(switch_aux_loss(pruned, probs, E_tot))
     else:
-        send = torch.empty((E_tot * slot, d), dtype=cd, device=x.device)
-    recv = torch.empty_like(send)
-    work = _a2a(recv, send, group=group, async_op=True)                # equal splits: E_local * slot rows per peer
+        inv_pos = torch.empty((0,), dtype=torch.int64, device=dev)
+        send = torch.empty((tab.rows, d), dtype=cd, device=dev)
+        mod.last_plan = (idx, score, torch.zeros(E_tot, dtype=torch.int32, device=dev),
+                         torch.zeros(E_tot + 1, dtype=torch.int32, device=dev), None, inv_pos)
+    # the counts, this rank's row count and its whole routing histogram ride in the header rows; nobody on the host reads them
+    ops.ep_pack_headers(send, counts, raw, tab.base_dev, T)
+    recv = torch.empty((tab.recv_rows, d), dtype=cd, device=dev)
+    work = _a2a(recv, send, tab.out_splits, tab.in_splits, group, async_op=True)
     yield                                                              # dispatch all-to-all in flight
     if work is not None:
         work.wait()
-    starts = _starts_cache.get((E_tot, slot, str(x.device)), 0,
-                               lambda: (torch.arange(E_tot, dtype=torch.int32, device=x.device) * slot))
-    ends = starts + recv_counts                                        # group l = (source rank, local expert): rows [l slot, l slot + n)
-    gexp = _group_expert_ids(W, E_local, x.device)
-    y = mod._experts_fwd(recv, starts, cd, out_dtype=cd, group_expert=gexp, group_end=ends)
-    back = torch.empty_like(y)
-    work2 = _a2a(back, y, group=group, async_op=True)
+    # group l = (source rank, local expert): rows [starts[l], ends[l]) of the received buffer
+    starts, ends, stats = ops.ep_unpack_headers(recv, W, tab.lbase_dev, E_tot)
+    _watch_overflow(stats, st)
+    gexp = _group_expert_ids(W, E_local, dev)
+    y = mod._experts_fwd(recv, starts, cd, out_dtype=cd, group_expert=gexp, group_end=ends,
+                         rows_hint=(T if T > 0 else agreed) * k)
+    back = torch.empty((tab.rows, d), dtype=cd, device=dev)
+    work2 = _a2a(back, y, tab.in_splits, tab.out_splits, group, async_op=True)
     yield                                                              # return all-to-all in flight
     if work2 is not None:
         work2.wait()
     if T == 0:
-        return torch.empty((0, d), dtype=x.dtype, device=x.device)
+        return torch.empty((0, d), dtype=x.dtype, device=dev)
     return _combine_maybe_ln(back, inv_pos, score, T, k, x, residual, next_norm)
 
 
@@ -459,7 +688,8 @@ def _combine_maybe_ln(back, inv_pos, score, T, k, x, residual, next_norm):
 
 
 def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[torch.Tensor] = None,
-                     norm: Optional[torch.nn.Module] = None, next_norm: Optional[torch.nn.Module] = None):
+                     norm: Optional[torch.nn.Module] = None, next_norm: Optional[torch.nn.Module] = None,
+                     routed: Optional[dict] = None):
     """Generator form of the expert-parallel forward: ``yield``s wherever this micro-batch has to wait for something
     that is not GPU compute -- (1) the count matrices reaching the host, (2) the dispatch all-to-all, (3) the return
     all-to-all -- so that a caller interleaving several micro-batches (vit.VisionTransformer) keeps the compute
@@ -467,7 +697,10 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
     the same order whatever the routing, so the collectives stay matched.  Returns the output via StopIteration.
 
     With ``norm`` (a LayerNorm whose shape the fused kernel covers) the operator computes ``moe(norm(x))``: LayerNorm
-    and router run as one pass over x and the send buffers are gathered from the normalised 16-bit image."""
+    and router run as one pass over x and the send buffers are gathered from the normalised 16-bit image.  With ``routed`` (the
+    residual-MoE block's gated half, FMoETransformerMLP.forward_norm_gate_add: LayerNorm, token-skip gate and router already ran as
+    ONE pass) the routing is taken as given: ``idx`` / ``score`` [T, k], ``idx_plan`` (= idx, -1 for the tokens the skip gate
+    masked: they are simply not sent), ``src`` = the 16-bit operand image the send buffers are gathered from."""
     from . import ops
     from .fmoe import SwitchGate
 
@@ -487,7 +720,11 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
     gw = g.gate.weight.detach().float().contiguous()
     gb = g.gate.bias.detach().float() if g.gate.bias is not None else None
     src = x  # rows the send buffers are gathered from
-    if T == 0:   # a rank without rows still takes part in every collective of the layer
+    plan_idx = None
+    if routed is not None:
+        idx, score, probs, src = routed["idx"], routed["score"], None, routed["src"]
+        plan_idx = routed.get("idx_plan")
+    elif T == 0:   # a rank without rows still takes part in every collective of the layer
         idx = torch.empty((0, k), dtype=torch.int64, device=x.device)
         score = torch.empty((0, k), dtype=torch.float32, device=x.device)
         probs = torch.empty((0, g.tot_expert), dtype=torch.float32, device=x.device)
@@ -499,14 +736,17 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
         src = xn16
     else:
         idx, score, _, probs = ops.router_topk(x, gw, gb, k, g.kind, noise, want_probs=isinstance(g, SwitchGate))
-    if use_static_exchange(mod, cd):
+    if plan_idx is None:
+        plan_idx = idx
+    kind = static_kind(mod, cd)
+    if kind is not None:
         # decided from the configuration and the AGREED row count only: every rank takes the same branch whatever its batch
         agreed = static_slot_tokens(mod, T, x.device)
         if static_plan_fits(mod, agreed):
-            return (yield from _ep_forward_static(mod, x, src, idx, score, probs, cap, cd, residual, next_norm, agreed))
+            return (yield from _ep_forward_static(mod, x, src, idx, plan_idx, score, probs, cd, residual, next_norm, agreed, kind))
     plans = []
     for (t0, t1) in bounds:
-        plans.append(ops.dispatch_plan(idx[t0:t1], g.tot_expert, cap))
+        plans.append(ops.dispatch_plan(plan_idx[t0:t1], g.tot_expert, cap))
     mod.last_plan = (idx, score) + tuple(plans[0][:4])
     if isinstance(g, SwitchGate):
         from .autograd import switch_aux_loss

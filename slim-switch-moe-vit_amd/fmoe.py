@@ -388,7 +388,7 @@ class FMoETransformerMLP(nn.Module):
         return (x.is_cuda and x.dtype == torch.float32 and isinstance(norm, nn.LayerNorm) and norm.elementwise_affine
                 and tuple(norm.normalized_shape) == (self.d_model,) and self._fused_gelu and not self.training
                 and cd in (torch.float16, torch.bfloat16) and self.gemm_variant in (4, 9) and self.d_model % 64 == 0
-                and not torch.is_grad_enabled() and type(g) is NaiveGate and not self.ep_active()
+                and not torch.is_grad_enabled() and type(g) is NaiveGate
                 and ops.gate_ln_router_supported(self.d_model, g.tot_expert, g.top_k))
 
     def zero_row_output(self) -> torch.Tensor:
@@ -404,6 +404,16 @@ class FMoETransformerMLP(nn.Module):
 
         def make():
             f = lambda p: None if p is None else p.detach().float().contiguous()
+            if self.world_size > 1:
+                # expert parallel: the experts a zero row is routed to may live on other ranks -- every rank computes the part
+                # its own experts contribute and the parts are summed (one small all-reduce per PARAMETER VERSION, entered by
+                # every rank on the same forward: parameters change on all ranks together)
+                import torch.distributed as dist
+                from .ep import all_reduce_sum
+                rank = dist.get_rank(self.moe_group)
+                part = ops.zero_row_output(f(g.bias), self.top_k, f(ex.h4toh.weight), f(ex.htoh4.bias), f(ex.h4toh.bias),
+                                           e_base=rank * self.num_expert, E_total=self.gate.tot_expert)
+                return all_reduce_sum(part, self.moe_group)
             return ops.zero_row_output(f(g.bias), self.top_k, f(ex.h4toh.weight), f(ex.htoh4.bias), f(ex.h4toh.bias))
         return cache.get(str(ex.h4toh.weight.device), ver, make)
 
@@ -414,6 +424,13 @@ class FMoETransformerMLP(nn.Module):
         the 16-bit image, GEMM-2 (k = 1) or the combine (k > 1) adding into the f32 residual image in place.  Tokens the
         gate masks are all-zero rows for the operator: they are not dispatched; their constant output
         (``zero_row_output``) is added to their residual row by the first pass.  ``skip_gate`` is a resmoe.Gate."""
+        from .ep import drain
+        return drain(self.forward_norm_gate_add_steps(x, norm, skip_gate))
+
+    def forward_norm_gate_add_steps(self, x: torch.Tensor, norm: nn.Module, skip_gate):
+        """Generator form of ``forward_norm_gate_add`` (result = return value): under expert parallelism it yields where this
+        batch waits for the host or an all-to-all (ep.ep_forward_steps, which takes the routing of the fused pass as given: the
+        tokens the skip gate masked -- ``idx_plan = -1`` -- are simply not sent)."""
         assert self.norm_gate_fusable(x, norm), "forward_norm_gate_add: preconditions (norm_gate_fusable) do not hold"
         cd = self.compute_dtype or default_compute_dtype()
         g, d, k = self.gate, self.d_model, self.top_k
@@ -426,14 +443,28 @@ class FMoETransformerMLP(nn.Module):
         thr = skip_gate.active_threshold()
         if thr is not None:
             skip_gate._total_tokens += T
+        zero_out = self.zero_row_output() if thr is not None else None    # (expert parallel: a collective on its first call)
+        if T == 0:    # an expert-parallel rank without rows still takes part in the layer's collectives
+            from .ep import ep_forward_steps
+            empty = dict(idx=torch.empty((0, k), dtype=torch.int64, device=x2.device), idx_plan=None,
+                         score=torch.empty((0, k), dtype=torch.float32, device=x2.device),
+                         src=torch.empty((0, d), dtype=cd, device=x2.device))
+            if self.ep_active():
+                yield from ep_forward_steps(self, x2, cd, residual=x2, routed=empty)
+            return x2.reshape(shape)
         r = ops.gate_ln_router(
             x2, lin.weight, lin.bias, thr,
             ln=(norm.weight.detach(), norm.bias.detach() if norm.bias is not None else None, norm.eps),
             wg=g.gate.weight.detach().float().contiguous(), bg=g.gate.bias.detach().float() if g.gate.bias is not None else None,
-            k=k, xn16_dtype=cd, want_xn32=True, zero_out=self.zero_row_output() if thr is not None else None,
+            k=k, xn16_dtype=cd, want_xn32=True, zero_out=zero_out,
             skip_count=skip_gate.skip_counter(x.device) if thr is not None else None,
             hist=(hist := ops.chunk_hist(T, d, g.tot_expert, k, x2.device)))
         idx, score, out = r["idx"], r["score"], r["xn32"]
+        if self.ep_active():
+            from .ep import ep_forward_steps
+            res = yield from ep_forward_steps(self, out, cd, residual=out,
+                                              routed=dict(idx=idx, idx_plan=r["idx_plan"], score=score, src=r["xn16"]))
+            return res.reshape(shape)
         counts, offsets, pos, inv_pos, _ = ops.dispatch_plan(r["idx_plan"], g.tot_expert, -1, hist=hist)
         self.last_plan = (idx, score, counts, offsets, pos, inv_pos)
         ex = self.experts
@@ -477,23 +508,25 @@ class FMoETransformerMLP(nn.Module):
         return idx, score, probs, counts, offsets, pos, inv_pos, pruned
 
     def _experts_fwd(self, rows: torch.Tensor, offsets: torch.Tensor, cd: torch.dtype, out=None, row_map=None,
-                     row_scale=None, out_dtype=None, group_expert=None, residual=None, group_end=None):
+                     row_scale=None, out_dtype=None, group_expert=None, residual=None, group_end=None, rows_hint=None):
+        """``rows_hint``: with ``group_end`` (row ranges inside a padded buffer) the number of rows expected to exist -- what the
+        GEMMs' tile height is chosen for, and what the profiler counts FLOPs over."""
         ex = self.experts
         w1, w2 = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
         b1 = ex.htoh4.bias.detach().float() if ex.htoh4.bias is not None else None
         b2 = ex.h4toh.bias.detach().float() if ex.h4toh.bias is not None else None
         if self._fused_gelu:
             h = ops.grouped_gemm(rows, w1, b1, offsets, ops.EPI_GELU, cd, variant=self.gemm_variant,
-                                 group_expert=group_expert, group_end=group_end)
+                                 group_expert=group_expert, group_end=group_end, rows_hint=rows_hint)
             if self._drop_p > 0 and self.training:
                 h = torch.nn.functional.dropout(h, self._drop_p, True)
         else:
             h = ops.grouped_gemm(rows, w1, b1, offsets, ops.EPI_NONE, cd, variant=self.gemm_variant,
-                                 group_expert=group_expert, group_end=group_end)
+                                 group_expert=group_expert, group_end=group_end, rows_hint=rows_hint)
             h = self._generic_act(h).to(cd).contiguous()
         return ops.grouped_gemm(h, w2, b2, offsets, ops.EPI_NONE, out_dtype, row_map=row_map, row_scale=row_scale,
                                 out=out, variant=self.gemm_variant, group_expert=group_expert, residual=residual,
-                                group_end=group_end)
+                                group_end=group_end, rows_hint=rows_hint)
 
     def _forward_infer(self, inp: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         shape = inp.shape

@@ -466,15 +466,21 @@ def skip_gate_bwd(xn: torch.Tensor, g_f: torch.Tensor, g_out: Optional[torch.Ten
 
 
 def zero_row_output(bg: Optional[torch.Tensor], k: int, w2: torch.Tensor, b1: Optional[torch.Tensor],
-                    b2: Optional[torch.Tensor]) -> torch.Tensor:
-    """out[d] = sum_j score_j (W2[e_j] gelu(b1[e_j]) + b2[e_j]) for the NaiveGate routing of an all-zero row."""
+                    b2: Optional[torch.Tensor], e_base: int = 0, E_total: Optional[int] = None) -> torch.Tensor:
+    """out[d] = sum_j score_j (W2[e_j] gelu(b1[e_j]) + b2[e_j]) for the NaiveGate routing of an all-zero row.  Expert parallel
+    (``E_total`` global experts in ``bg``, ``w2`` / ``b1`` / ``b2`` = this rank's experts [e_base, e_base + E_local)): this rank's
+    partial sum -- the ranks' results add up to the row."""
     _chk(w2, "w2", torch.float32, 3)
-    E, d, h = w2.shape
+    E_local, d, h = w2.shape
+    E = E_local if E_total is None else int(E_total)
     for t, nm in ((bg, "bg"), (b1, "b1"), (b2, "b2")):
         if t is not None:
             _chk(t, nm, torch.float32, align=4)
+    if bg is not None and bg.numel() != E:
+        raise RuntimeError(f"zero_row_output: bg has {bg.numel()} entries, expected {E}")
     out = torch.empty(d, dtype=torch.float32, device=w2.device)
-    rc = _lib.load().smoe_zero_row_output(_ptr(bg), E, k, _ptr(w2), _ptr(b1), _ptr(b2), d, h, _ptr(out), _stream(w2))
+    rc = _lib.load().smoe_zero_row_output(_ptr(bg), E, k, _ptr(w2), _ptr(b1), _ptr(b2), d, h, int(e_base), E_local, _ptr(out),
+                                          _stream(w2))
     _lib.check(rc, "smoe_zero_row_output")
     return out
 
@@ -511,11 +517,12 @@ def dispatch_plan(idx: torch.Tensor, E: int, capacity: int = -1, want_pruned: Op
     return counts, offsets, pos, inv_pos, pruned
 
 
-def dispatch_plan_padded(idx: torch.Tensor, E: int, capacity: int, slot_rows: Optional[int] = None):
+def dispatch_plan_padded(idx: torch.Tensor, E: int, capacity: int, slot_rows: Optional[int] = None, want_raw: bool = False):
     """The plan in the padded layout of a capacity gate's static exchange: expert e owns the slots [e * slot_rows, (e + 1) *
     slot_rows) (slot_rows >= capacity, default = capacity).  Returns (counts i32 [E], offsets i32 [E+1] (compact prefix),
     group_end i32 [E] = e * slot_rows + counts[e], pos_padded i64 [E * slot_rows] (-1 = unused slot), inv_pos i64 [n] (padded
-    slot or -1), idx_pruned i64 [n])."""
+    slot or -1), idx_pruned i64 [n]); with ``want_raw`` a seventh entry, raw_counts i32 [E] = the entries routed to each expert
+    before the capacity clamp."""
     slot_rows = int(capacity) if slot_rows is None else int(slot_rows)
     _chk(idx, "idx", torch.int64, align=8)
     flat = idx.reshape(-1)
@@ -530,11 +537,79 @@ def dispatch_plan_padded(idx: torch.Tensor, E: int, capacity: int, slot_rows: Op
     pos = torch.empty(E * slot_rows, dtype=torch.int64, device=dev)
     inv_pos = torch.empty(n, dtype=torch.int64, device=dev)
     pruned = torch.empty(n, dtype=torch.int64, device=dev)
+    raw = torch.empty(E, dtype=torch.int32, device=dev) if want_raw else None
     with _timed("plan", {"bytes": n * 24}, idx):
         rc = lib.smoe_dispatch_plan_padded(_ptr(flat), n, E, int(capacity), slot_rows, _ptr(counts), _ptr(offsets), _ptr(group_end),
-                                           _ptr(pos), _ptr(inv_pos), _ptr(pruned), _ptr(ws), ws_bytes, _stream(idx))
+                                           _ptr(pos), _ptr(inv_pos), _ptr(pruned), _ptr(raw), _ptr(ws), ws_bytes, _stream(idx))
     _lib.check(rc, "smoe_dispatch_plan_padded")
+    if want_raw:
+        return counts, offsets, group_end, pos, inv_pos, pruned, raw
     return counts, offsets, group_end, pos, inv_pos, pruned
+
+
+def dispatch_plan_slots(idx: torch.Tensor, E: int, slot_base: torch.Tensor, n_slots: int, capacity: int = -1, hdr_rows: int = 1):
+    """The plan over a slot table (smoe_dispatch_plan_slots): expert e owns the slots [slot_base[e], slot_base[e + 1]) (i32 [E + 1] on
+    the device; ``n_slots`` = slot_base[E], known to the host), the last ``hdr_rows`` of them reserved.  Returns (counts i32 [E],
+    offsets i32 [E+1], group_end i32 [E], pos_slots i64 [n_slots] (-1 = unused), inv_pos i64 [n], idx_pruned i64 [n],
+    raw_counts i32 [E] = the entries routed to each expert before any clamp)."""
+    _chk(idx, "idx", torch.int64, align=8)
+    _chk(slot_base, "slot_base", torch.int32, 1, align=4)
+    if slot_base.numel() != E + 1:
+        raise RuntimeError("slot_base: expected E + 1 entries")
+    flat = idx.reshape(-1)
+    n = flat.numel()
+    dev = idx.device
+    lib = _lib.load()
+    ws_bytes = lib.smoe_dispatch_plan_workspace_bytes(n, E)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    counts = torch.empty(E, dtype=torch.int32, device=dev)
+    offsets = torch.empty(E + 1, dtype=torch.int32, device=dev)
+    group_end = torch.empty(E, dtype=torch.int32, device=dev)
+    pos = torch.empty(int(n_slots), dtype=torch.int64, device=dev)
+    inv_pos = torch.empty(n, dtype=torch.int64, device=dev)
+    pruned = torch.empty(n, dtype=torch.int64, device=dev)
+    raw = torch.empty(E, dtype=torch.int32, device=dev)
+    with _timed("plan", {"bytes": n * 24}, idx):
+        rc = lib.smoe_dispatch_plan_slots(_ptr(flat), n, E, int(capacity), _ptr(slot_base), int(hdr_rows), _ptr(counts), _ptr(offsets),
+                                          _ptr(group_end), _ptr(pos), _ptr(inv_pos), _ptr(pruned), _ptr(raw), _ptr(ws), ws_bytes,
+                                          _stream(idx))
+    _lib.check(rc, "smoe_dispatch_plan_slots")
+    return counts, offsets, group_end, pos, inv_pos, pruned, raw
+
+
+def ep_pack_headers(send: torch.Tensor, counts: Optional[torch.Tensor], raw_counts: Optional[torch.Tensor], slot_base: torch.Tensor,
+                    t_rows: int) -> None:
+    """Write the header rows of a static-exchange send buffer (smoe_ep_pack_headers): region g's last row gets int32
+    {counts[g], raw_counts[g], t_rows, G, raw_counts[0 .. G)}."""
+    _chk(send, "send", ndim=2)
+    _chk(slot_base, "slot_base", torch.int32, 1, align=4)
+    G = slot_base.numel() - 1
+    for t, nm in ((counts, "counts"), (raw_counts, "raw_counts")):
+        if t is not None:
+            _chk(t, nm, torch.int32, 1, align=4)
+            if t.numel() != G:
+                raise RuntimeError(f"{nm}: expected {G} entries")
+    rc = _lib.load().smoe_ep_pack_headers(_ptr(counts), _ptr(raw_counts), _ptr(slot_base), G, send.shape[1] * send.element_size(),
+                                          int(t_rows), _ptr(send), _stream(send))
+    _lib.check(rc, "smoe_ep_pack_headers")
+
+
+def ep_unpack_headers(recv: torch.Tensor, W: int, local_base: torch.Tensor, E_total: int):
+    """(starts i32 [G], ends i32 [G], stats i32 [W, 1 + E_total]) from the header rows of a received static-exchange buffer
+    (smoe_ep_unpack_headers): group l = (source rank, local expert) holds the rows [starts[l], ends[l]); stats[w] = (source w's
+    row count, its pre-clamp counts of all E_total experts)."""
+    _chk(recv, "recv", ndim=2)
+    _chk(local_base, "local_base", torch.int32, 1, align=4)
+    E_local = local_base.numel() - 1
+    G = int(W) * E_local
+    dev = recv.device
+    starts = torch.empty(G, dtype=torch.int32, device=dev)
+    ends = torch.empty(G, dtype=torch.int32, device=dev)
+    stats = torch.empty((int(W), 1 + int(E_total)), dtype=torch.int32, device=dev)
+    rc = _lib.load().smoe_ep_unpack_headers(_ptr(recv), int(W), E_local, _ptr(local_base), recv.shape[1] * recv.element_size(),
+                                            int(E_total), _ptr(starts), _ptr(ends), _ptr(stats), _stream(recv))
+    _lib.check(rc, "smoe_ep_unpack_headers")
+    return starts, ends, stats
 
 
 def scatter_rows(x: torch.Tensor, pos: torch.Tensor, k: int, out_dtype: torch.dtype,
@@ -621,6 +696,20 @@ def gather_combine_ln(y: torch.Tensor, inv_pos: torch.Tensor, score: torch.Tenso
     return out, xn
 
 
+def _ps_variant(rows: int, G: int, K: int, N: int, device) -> int:
+    """The persistent GEMM's tile height / schedule for ``rows`` real rows in G groups -- csrc/gemm.hip's variant-9 rule (expected
+    tiles of 256 or 320 rows, cost-weighted rounds of workgroups, ties to the taller tile; deep schedule for K >= 2048) as an
+    explicit variant: 10 / 11 = 320- / 256-row tiles, 13 / 12 = the same on the deep schedule."""
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    ntn = -(-N // 256)
+    t256 = (-(-rows // 256) + G // 2) * ntn
+    t320 = (-(-rows // 320) + G // 2) * ntn
+    tall = -(-t320 // cus) * 1.25 <= -(-t256 // cus) * 1.0
+    if K >= 2048:
+        return 13 if tall else 12
+    return 10 if tall else 11
+
+
 def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], offsets: torch.Tensor,
                  epilogue: int = EPI_NONE, out_dtype: Optional[torch.dtype] = None,
                  row_map: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
@@ -679,6 +768,10 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
             raise RuntimeError("residual: expected the shape of out")
     lib = _lib.load()
     rows = M if rows_hint is None else rows_hint
+    if variant == 9 and group_end is not None and rows_hint is not None:
+        # separate row ranges inside a PADDED buffer: the library picks tile height from the rows it is told about (M = the buffer);
+        # pick here, by the same cost-weighted rounds, from the rows that are expected to exist
+        variant = _ps_variant(int(rows_hint), G, K, N, A.device)
     with _timed(prof_name, {"flops": 2.0 * rows * K * N, "K": K, "N": N, "epilogue": epilogue}, A):
         rc = lib.smoe_grouped_gemm(_ptr(A), _ptr(W), _ptr(bias), _ptr(offsets), _ptr(group_expert), G, E, M, K, N,
                                    dtype_code(A.dtype), epilogue, _ptr(row_map), _ptr(row_scale), _ptr(residual),

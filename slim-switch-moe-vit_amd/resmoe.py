@@ -301,7 +301,7 @@ def forward_residule_moe(self, x):
     if x.is_cuda and th.is_autocast_enabled():
         from .vit import _warn_fallback
         _warn_fallback("residual-MoE block", "config: composed from torch modules (needs fp16-autocast inference, f32 contiguous "
-                       "activations, inactive stochastic depth, the naive gate on one rank)", x.shape)
+                       "activations, inactive stochastic depth, the naive gate)", x.shape)
     return _residual_block_composed(self, x)
 
 

@@ -600,6 +600,14 @@ class VisionTransformer(nn.Module):
 
     def forward_features(self, x):
         n = self._ep_pipeline_depth(x)
+        if self._ep_blocks():
+            # the static exchange's buffers are agreed and sized per micro-batch (ep.static_slot_tokens): the modules must know how
+            # the local batch is cut -- shared configuration (depth, gates, ep_micro_batches), so every rank says the same
+            for blk in self.blocks:
+                m = getattr(blk, "mlp", None)
+                if hasattr(m, "ep_active"):
+                    m.ep_rows_div = n
+                    m.ep_rows_unit = int(self.pos_embed.shape[1])
         if n > 1:
             return self._forward_features_pipelined(x, n)
         if (int(self.compute_streams) == 2 and x.is_cuda and not torch.is_grad_enabled() and not self.training

@@ -185,12 +185,16 @@ def _static_control_worker(rank, W, port, q):
         E_local = 6 // W
         want = torch.cat([torch.arange(6, dtype=torch.int32)[rank * E_local:(rank + 1) * E_local] + 10 * w for w in range(W)])
         res["counts_ok"] = bool(torch.equal(recv, want)) and peer.tolist() == [5, 0, 9]
-        ep._watch_overflow(peer, agreed, mod)
+        # what the headers of an exchange deliver on every rank: [W, 1 + E] = (rows, pre-clamp count per global expert) per source
+        stats = lambda rows_v: torch.cat([rows_v.to(torch.int32).reshape(W, 1), torch.zeros((W, 6), dtype=torch.int32)], 1)
+        st = ep._slot_state(mod, "capacity", agreed, "cpu")
+        res["slots"] = (st.table.caps, st.table.rows, st.table.in_splits, st.table.out_splits)
+        ep._watch_overflow(stats(peer), st)
         ep.check_static_overflow(flush=True)                                            # everything fits: silent
         # a later, LARGER batch on one rank: nobody raises alone; every rank raises at the same check, after re-sizing
         rows2 = [20, 0, 9][rank]
         _, peer2 = ep.exchange_counts_static(counts, rows2, W)
-        ep._watch_overflow(peer2, agreed, mod)
+        ep._watch_overflow(stats(peer2), st)
         ep.check_static_overflow()                                                      # younger than the lag: not read yet
         try:
             ep.check_static_overflow(flush=True)
@@ -198,6 +202,7 @@ def _static_control_worker(rank, W, port, q):
         except ep.StaticExchangeOverflow as exc:
             res["overflow"] = "raised" if "[20, 0, 9]" in str(exc) else str(exc)
         res["resized"] = mod.ep_static_tokens
+        res["slots_after"] = ep._slot_state(mod, "capacity", ep.static_slot_tokens(mod, 1, "cpu"), "cpu").table.caps
         # presets that differ between ranks: the same error everywhere
         mod2 = _StubMoE(W)
         if rank == 0:
@@ -211,6 +216,14 @@ def _static_control_worker(rank, W, port, q):
         mod3 = _StubMoE(W)
         mod3.ep_static_tokens = 64
         res["preset"] = ep.static_slot_tokens(mod3, rows, "cpu")
+        # micro-batches: the agreement is per divisor; a preset counts rows of the whole batch, cut between images (`ep_rows_unit`)
+        mod3.ep_rows_div, mod3.ep_rows_unit = 3, 4
+        res["preset_div3"] = ep.static_slot_tokens(mod3, 1, "cpu")                      # ceil(64 / (3 * 4)) * 4 = 24
+        mod4 = _StubMoE(W)
+        mod4.ep_rows_div = 2
+        res["agreed_div2"] = ep.static_slot_tokens(mod4, [7, 3, 11][rank], "cpu")       # no preset: the largest micro-batch
+        mod4.ep_rows_div = 1
+        res["agreed_div1"] = ep.static_slot_tokens(mod4, [14, 6, 22][rank], "cpu")      # its own collective, its own entry
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -231,5 +244,104 @@ def test_static_exchange_agreement_and_overflow_are_collective():
     got = dict(q.get(timeout=5) for _ in range(W))
     for r in range(W):
         res = got[r]
+        # capacity(9) = 2 rows per (source, expert) slot + one header row each: 6 x 3 = 18 rows, 2 experts (6 rows) per peer
+        assert res.pop("slots") == ([2] * 6, 18, [6, 6, 6], [6, 6, 6]), (r, res)
+        assert res.pop("slots_after") == [4] * 6, (r, res)                              # capacity(20) after the re-size
         assert res == {"static_by_config": True, "agreed": 9, "agreed_again": 9, "counts_ok": True, "overflow": "raised",
-                       "resized": 20, "preset_mismatch": "raised", "preset": 64}, (r, res)
+                       "resized": 20, "preset_mismatch": "raised", "preset": 64, "preset_div3": 24, "agreed_div2": 11,
+                       "agreed_div1": 22}, (r, res)
+
+
+class _NaiveStubGate:
+    tot_expert = 6
+
+    def capacity(self, n):
+        return -1
+
+
+def _speculative_control_worker(rank, W, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    try:
+        from slim_switch_moe_vit_amd import ep
+        res = {}
+        mods = []
+        for _ in range(3):                                   # three "layers"
+            m = _StubMoE(W)
+            m.gate = _NaiveStubGate()
+            mods.append(m)
+        # off by default: a gate without a capacity exchanges dynamically unless the harness opted in (somebody must own the redo)
+        res["default_kind"] = ep.static_kind(mods[0], torch.float16)
+        for m in mods:
+            m.ep_speculative = 1.5
+        res["kind"] = ep.static_kind(mods[0], torch.float16)
+        with ep.dynamic_only():
+            res["kind_in_redo"] = ep.static_kind(mods[0], torch.float16)
+        agreed = [ep.static_slot_tokens(m, [40, 0, 24][rank], "cpu") for m in mods]
+        res["agreed"] = agreed
+        sts = [ep._slot_state(m, "speculative", a, "cpu") for m, a in zip(mods, agreed)]
+        res["first_caps"] = sts[0].table.caps                # uniform: ceil(1.5 * 40 * 1 / 6) = 10
+        # [W, 1 + E]: source w brought rows[w] rows and routed hist[w][e] of them to global expert e (before any clamp)
+        rows = [40, 0, 24]
+        mk = lambda hist: torch.tensor([[rows[w]] + hist[w] for w in range(W)], dtype=torch.int32)
+        zero = [0] * 6
+        h0 = [[13, 5, 6, 6, 5, 5], zero, [4, 4, 4, 4, 4, 4]]           # layer 0: source 0 overflows expert 0 (13 > 10)
+        h1 = [[10, 6, 6, 6, 6, 6], zero, [4, 4, 4, 4, 4, 4]]           # layer 1: fits
+        h2 = [[7, 7, 7, 7, 6, 6], zero, [2, 2, 2, 2, 17, 1]]           # layer 2: source 2 overflows expert 4 (17 > 10)
+        calls = {"n": 0, "dyn": 0}
+
+        def step():
+            calls["n"] += 1
+            if ep.static_kind(mods[0], torch.float16) is None:
+                calls["dyn"] += 1
+                return "dynamic"
+            for st, h in zip(sts, (h0, h1, h2)):
+                ep._watch_overflow(mk(h), st)
+            return "static"
+        out, again = ep.run_guarded(step)
+        res["redo"] = (out, again, calls["n"], calls["dyn"])
+        # EVERY overflowing layer was re-sized by the one raise (per expert: max(old, ceil(1.12 x the largest group seen))), the
+        # fitting one was not
+        res["caps"] = [st.table.caps for st in sts]
+        res["pending_after"] = len(ep._overflow_pending)
+        # steps 2 and 3: the same routing fits the re-sized slots: no repeat; after ADAPT_MIN_OBS observations without an overflow
+        # every layer's slots are cut to ceil(1.12 x its largest group) PER EXPERT (the all-to-all then carries ~1.12 x the routed rows)
+        res["second"] = ep.run_guarded(step)
+        res["third"] = ep.run_guarded(step)
+        res["fitted"] = [st.table.caps for st in sts]
+        res["splits"] = (sts[1].table.in_splits, sts[1].table.out_splits, sts[1].table.rows, sts[1].table.recv_rows)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_speculative_exchange_control_plane_resizes_every_layer_and_repeats_once():
+    """VERDICT r4 item 1 / ADVICE r4 (low): the speculative static exchange of a capacity-less gate is opt-in; which exchange runs is
+    a function of shared switches only (incl. the redo context); an overflow of SEVERAL layers in one step re-sizes every one of
+    them in the one raise (a 12-layer model must not need 12 repeats), the step is repeated ONCE, on the dynamic exchange, by all
+    ranks together, and the next step fits."""
+    W = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_speculative_control_worker, args=(r, W, port, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    join_or_kill(procs, 120)
+    got = dict(q.get(timeout=5) for _ in range(W))
+    import math
+    fit = lambda hist: [max(1, math.ceil(1.12 * max(col))) for col in zip(*hist)]
+    for r in range(W):
+        res = got[r]
+        assert res["default_kind"] is None and res["kind"] == "speculative" and res["kind_in_redo"] is None, (r, res)
+        assert res["agreed"] == [40, 40, 40] and res["first_caps"] == [10] * 6, (r, res)
+        assert res["redo"] == ("dynamic", True, 2, 1), (r, res)
+        assert res["caps"] == [[15, 10, 10, 10, 10, 10], [10] * 6, [10, 10, 10, 10, 20, 10]], (r, res)
+        assert res["pending_after"] == 0 and res["second"] == ("static", False) and res["third"] == ("static", False), (r, res)
+        assert res["fitted"] == [fit([[13, 5, 6, 6, 5, 5], [4] * 6]), fit([[10, 6, 6, 6, 6, 6], [4] * 6]),
+                                 fit([[7, 7, 7, 7, 6, 6], [2, 2, 2, 2, 17, 1]])], (r, res)
+        # layer 1 after the cut: caps [12, 7, 7, 7, 7, 7] + one header row each; two experts per rank
+        E_local, caps = 2, res["fitted"][1]
+        blocks = [sum(caps[w * E_local:(w + 1) * E_local]) + E_local for w in range(W)]
+        assert res["splits"] == (blocks, [blocks[r]] * W, sum(blocks), W * blocks[r]), (r, res)

@@ -1,0 +1,325 @@
+"""The speculative STATIC expert exchange of a capacity-less gate (ep.set_speculative): fixed alpha-sized slots,
+counts in the header rows of the token all-to-all, no host round trip per layer -- and the same RESULTS as the counted exchange
+(FastMoE's expert_exchange + global_scatter / global_gather): bit for bit when the routing fits the slots,
+after one repeat on the counted exchange when it does not.  One-rank RCCL group and W = 2 / 4 processes on one GPU over gloo."""
+import os
+import socket
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from _mp import join_or_kill as _join_or_kill  # noqa: E402
+import slim_switch_moe_vit_amd as sm  # noqa: E402
+from test_gpu_model import _init  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _count_readbacks(ep):
+    """Patch the counted exchange's host sync so that the test can tell which exchange ran."""
+    calls = {"n": 0}
+    real = ep.PendingCounts.finish_rows
+
+    def counting(self):
+        calls["n"] += 1
+        return real(self)
+    ep.PendingCounts.finish_rows = counting
+    return calls, lambda: setattr(ep.PendingCounts, "finish_rows", real)
+
+
+def _one_rank_worker(q):
+    import torch.distributed as dist
+    from slim_switch_moe_vit_amd import ep, vit
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_port()}", rank=0, world_size=1, device_id=torch.device(DEV))
+    res = {}
+    try:
+        torch.manual_seed(0)
+        images = torch.randn(10, 3, 224, 224, generator=torch.Generator().manual_seed(8)).to(DEV)
+        calls, restore = _count_readbacks(ep)
+
+        def fwd(model):
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                return model(images).float()
+
+        for name in ("moe_tiny_patch16_224_expert4_top1", "moe_tiny_patch16_224_expert8"):      # top-1 and the reference's top-2
+            model = _init(sm.create_model(name, num_classes=100), 7).eval().to(DEV)
+            for blk in model.blocks:
+                blk.mlp.force_ep = True
+            model.ep_micro_batches = 1
+            ep.set_speculative(model, None)
+            calls["n"] = 0
+            dyn = fwd(model)
+            plans_dyn = [blk.mlp.last_plan[0].clone() for blk in model.blocks]
+            res[name + "/dynamic_readbacks"] = calls["n"]
+            # (1) roomy slots: nothing overflows -> the counted exchange's result, bit for bit, without one count read-back
+            ep.set_speculative(model, 3.0)
+            calls["n"] = 0
+            out, again = ep.run_guarded(lambda: fwd(model))
+            res[name + "/static"] = (bool(torch.equal(out, dyn)), again, calls["n"],
+                                     all(torch.equal(a, blk.mlp.last_plan[0]) for a, blk in zip(plans_dyn, model.blocks)))
+            # (2) slots of exactly the balanced share: some layer overflows -> every rank raises together, the step is repeated on
+            #     the counted exchange (same bits again), every overflowing layer was re-sized by the one raise ...
+            ep.set_speculative(model, 1.0)
+            calls["n"] = 0
+            out, again = ep.run_guarded(lambda: fwd(model))
+            res[name + "/overflow"] = (bool(torch.equal(out, dyn)), again, calls["n"] > 0)
+            # ... so the same batch fits now: no repeat, no read-back, same bits
+            calls["n"] = 0
+            out, again = ep.run_guarded(lambda: fwd(model))
+            res[name + "/after_resize"] = (bool(torch.equal(out, dyn)), again, calls["n"])
+            # (3) micro-batches (slots agreed per micro-batch): the pipelined static forward = the plain one to GEMM-schedule rounding
+            model.ep_micro_batches = 2
+            ep.set_speculative(model, 3.0)
+            calls["n"] = 0
+            with torch.no_grad():
+                assert model._ep_pipeline_depth(images) == 2
+            out, again = ep.run_guarded(lambda: fwd(model))
+            res[name + "/micro2"] = (float((out - dyn).abs().max()), calls["n"])
+            model.ep_micro_batches = 1
+        restore()
+        # (4) the reference's live block (forward_residule_moe with the token-skip gates) under expert parallelism: the fused path,
+        #     no fallback warning; skipped tokens are not sent; static == counted bit for bit; the single-rank fused block to fp16 rounding
+        torch.manual_seed(1)
+        rm = _init(sm.create_model("resmoe_tiny_patch16_224_expert8", num_classes=100, starting_threshold=0.5, target_threshold=0.5), 9)
+        with torch.no_grad():
+            for blk in rm.blocks:
+                for gt in (blk.dense_gate, blk.moe_gate):
+                    gt.head[1].weight.normal_(0, 0.5, generator=torch.Generator().manual_seed(3))
+        rm = rm.eval().to(DEV)
+        vit._fallbacks_seen.clear()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", vit.SlimMoEFallbackWarning)
+            single = fwd(rm)
+            skipped_single = float(sum(b.moe_gate._skipped_tokens for b in rm.blocks))
+            for blk in rm.blocks:
+                blk.mlp.force_ep = True
+            ep.set_speculative(rm, None)
+            dyn = fwd(rm)
+            ep.set_speculative(rm, 3.0)
+            out, again = ep.run_guarded(lambda: fwd(rm))
+        res["resmoe"] = (bool(torch.equal(out, dyn)), again, float((dyn - single).abs().max()), float(single.abs().max()),
+                         skipped_single > 0)
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_speculative_static_exchange_equals_the_counted_exchange_one_rank_group():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(q,))
+    p.start()
+    _join_or_kill([p], 400)
+    res = q.get(timeout=10)
+    print(res)
+    for name in ("moe_tiny_patch16_224_expert4_top1", "moe_tiny_patch16_224_expert8"):
+        assert res[name + "/dynamic_readbacks"] == 12
+        assert res[name + "/static"] == (True, False, 0, True), res
+        assert res[name + "/overflow"] == (True, True, True), res
+        assert res[name + "/after_resize"] == (True, False, 0), res
+        assert res[name + "/micro2"][0] <= 1e-3 and res[name + "/micro2"][1] == 0, res
+    same, again, err, scale, skipped = res["resmoe"]
+    assert same and not again and skipped, res
+    assert err <= 6e-3 * max(1.0, scale), res      # 16-bit exchange payload vs the single-rank f32 epilogue (one more 2^-11 rounding)
+
+
+def _graph_worker(q):
+    """with no host round trip left in it, the world-of-one static expert-parallel forward captures into ONE HIP
+    graph (RCCL's kernels included) and replays bit-exactly."""
+    import torch.distributed as dist
+    from slim_switch_moe_vit_amd import ep
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_port()}", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(0)
+        model = _init(sm.create_model("moe_base_patch16_224_expert8_top1", num_classes=100, depth=3), 23).eval().to(DEV)
+        for blk in model.blocks:
+            blk.mlp.force_ep = True
+        model.ep_micro_batches = 1
+        ep.set_speculative(model, 2.0)
+        images = torch.randn(16, 3, 224, 224, generator=torch.Generator().manual_seed(24)).to(DEV)
+
+        def step():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                return model(images)
+
+        eager = step().float().clone()
+        ep.check_static_overflow(flush=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ep.check_static_overflow(flush=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = step()
+        for _ in range(4):
+            g.replay()
+        torch.cuda.synchronize()
+        worst = float((out.float() - eager).abs().max())
+        images.copy_(torch.randn(16, 3, 224, 224, generator=torch.Generator().manual_seed(25)).to(DEV))
+        g.replay()
+        torch.cuda.synchronize()
+        overflow = ep.captured_overflow(model)
+        other = float((out.float() - step().float()).abs().max())
+        q.put({"replay_vs_eager": worst, "new_input_vs_eager": other, "overflow": overflow})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skip(reason="hipStreamEndCapture segfaults on a capture that holds an RCCL kernel on this stack (torch 2.10+rocm7.0, RCCL "
+                         "2.26.6): `python tools/ep_graph_debug.py a2a` reproduces it with a bare dist.all_to_all_single, and the "
+                         "library's own transport (SLIMMOE_EP_TRANSPORT=cabi) dies at the same call -- gpurun_out/r5_graphdbg_*.log. "
+                         "The forward itself has no host round trip left (test above: zero count read-backs); un-skip when the "
+                         "runtime captures RCCL")
+def test_static_expert_parallel_forward_captured_in_a_hip_graph_replays_bit_exact():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_graph_worker, args=(q,))
+    p.start()
+    _join_or_kill([p], 300)
+    res = q.get(timeout=10)
+    print("static EP graph replay:", res)
+    assert res["replay_vs_eager"] == 0.0 and res["new_input_vs_eager"] == 0.0 and not res["overflow"], res
+
+
+def _ranks_worker(rank, world, port, q):
+    """One rank of W sharing cuda:0 over gloo: the MoE operator (NaiveGate, top-2, E = 8) and the residual-MoE block."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from slim_switch_moe_vit_amd import ep, vit
+        d, h, E, k = 192, 768, 8, 2
+        E_local = E // world
+        g = torch.Generator().manual_seed(77)
+        wg = torch.randn(E, d, generator=g) * 0.3
+        bg = torch.randn(E, generator=g) * 0.1
+        w1 = torch.randn(E, h, d, generator=g) * 0.02; b1 = torch.randn(E, h, generator=g) * 0.02
+        w2 = torch.randn(E, d, h, generator=g) * 0.02; b2 = torch.randn(E, d, generator=g) * 0.02
+
+        def build(ws):
+            m = sm.FMoETransformerMLP(E // ws, d, h, torch.nn.GELU(), top_k=k, world_size=ws)
+            sl = slice(rank * E_local, (rank + 1) * E_local) if ws > 1 else slice(0, E)
+            with torch.no_grad():
+                m.gate.gate.weight.copy_(wg); m.gate.gate.bias.copy_(bg)
+                m.experts.htoh4.weight.copy_(w1[sl]); m.experts.htoh4.bias.copy_(b1[sl])
+                m.experts.h4toh.weight.copy_(w2[sl]); m.experts.h4toh.bias.copy_(b2[sl])
+            return m.to(DEV).eval()
+
+        full, part = build(1), build(world)
+        calls, restore = _count_readbacks(ep)
+        ln = torch.nn.LayerNorm(d, eps=1e-6).to(DEV)
+        holder = torch.nn.Module()
+        holder.mlp = part
+
+        def run(T):
+            x = torch.randn(T, d, generator=torch.Generator().manual_seed(500 + rank)).to(DEV)
+            with torch.no_grad():
+                return part.forward_norm_add(x, ln), x
+
+        T = 700
+        res = {}
+        ep.set_speculative(holder, None)
+        dyn, x = run(T + 13 * rank)                                    # ragged ranks, counted exchange
+        with torch.no_grad():
+            ref = full.forward_norm_add(x, ln)
+        res["dyn_vs_single"] = float((dyn - ref).abs().max())
+        ep.set_speculative(holder, 3.0)
+        calls["n"] = 0
+        (st, _), again = ep.run_guarded(lambda: run(T + 13 * rank))
+        res["static"] = (bool(torch.equal(st, dyn)), again, calls["n"])
+        # a rank WITHOUT rows takes part in every collective; the others' results do not change
+        T0 = 0 if rank == world - 1 else T + 13 * rank
+        (st0, _), again0 = ep.run_guarded(lambda: run(T0))
+        res["empty_rank"] = (st0.shape[0] == T0, again0, bool(T0 == 0 or torch.equal(st0, dyn)))
+        # slots of the balanced share: somebody overflows -> ALL ranks repeat (counted exchange), nobody hangs, same bits
+        ep.set_speculative(holder, 1.0)
+        calls["n"] = 0
+        (so, _), again = ep.run_guarded(lambda: run(T + 13 * rank))
+        caps = part.__dict__["_ep_slots"][1].table.caps
+        res["overflow"] = (bool(torch.equal(so, dyn)), again, calls["n"] > 0, max(caps) > min(caps))   # grown per expert
+        calls["n"] = 0
+        (sa, _), again = ep.run_guarded(lambda: run(T + 13 * rank))     # the re-sized slots hold the same routing
+        res["after_resize"] = (bool(torch.equal(sa, dyn)), again, calls["n"])
+        restore()
+        # the reference's live block (DeiT-Tiny, E = 8, top-2, skip gates) on W ranks: fused path, no fallback warning
+        # (the reference's factory hard-codes 8 experts PER RANK, FastMoE's convention; here the 8 are split over the ranks so that
+        # the single-rank model holding all of them is the same function)
+        from slim_switch_moe_vit_amd.resmoe import patch_blocks_with_moe
+        from slim_switch_moe_vit_amd.vit import deit_tiny_patch16_224
+        torch.manual_seed(0)
+        fullm = _init(patch_blocks_with_moe(deit_tiny_patch16_224(num_classes=50, depth=2), 8, 2, True, 0.5, 0.5), 11).eval()
+        torch.manual_seed(0)
+        partm = patch_blocks_with_moe(deit_tiny_patch16_224(num_classes=50, depth=2), 8 // world, 2, True, 0.5, 0.5,
+                                      world_size=world).eval()
+        with torch.no_grad():
+            for blk in fullm.blocks:
+                for gt in (blk.dense_gate, blk.moe_gate):
+                    gt.head[1].weight.normal_(0, 0.5, generator=torch.Generator().manual_seed(3))
+                blk.mlp.gate.gate.bias.copy_(torch.linspace(-0.3, 0.3, 8))    # zero rows route to experts 7 and 6: other ranks' too
+        sd = fullm.state_dict()
+        sl = slice(rank * E_local, (rank + 1) * E_local)
+        for key in list(sd):
+            if ".experts." in key:
+                sd[key] = sd[key][sl].clone()
+        partm.load_state_dict(sd)
+        fullm, partm = fullm.to(DEV), partm.to(DEV)
+        images = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(100 + rank)).to(DEV)
+        vit._fallbacks_seen.clear()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", vit.SlimMoEFallbackWarning)
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+                want = fullm(images).float()
+                ep.set_speculative(partm, None)
+                got_dyn = partm(images).float()
+                ep.set_speculative(partm, 3.0)
+                got_st, again = ep.run_guarded(lambda: partm(images).float())
+        res["resmoe"] = (float((got_dyn - want).abs().max()), float(want.abs().max()), bool(torch.equal(got_st, got_dyn)), again,
+                         float(sum(b.moe_gate._skipped_tokens for b in partm.blocks)) > 0)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_speculative_static_exchange_ranks_on_one_gpu(world):
+    """W = 2 / 4 processes on one GPU (gloo): ragged ranks, an empty rank, an overflow that every rank repeats together, the
+    re-sized slots, and a resmoe_* model under expert parallelism with no SlimMoEFallbackWarning (the zero-row constant of the
+    skipped tokens is summed over the ranks that own the experts a zero row routes to)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _port()
+    procs = [ctx.Process(target=_ranks_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    _join_or_kill(procs, 300)
+    got = dict(q.get(timeout=10) for _ in range(world))
+    for rank in range(world):
+        res = got[rank]
+        print(f"rank {rank}/{world}: {res}")
+        assert res["dyn_vs_single"] <= 2e-3, (rank, res)
+        assert res["static"] == (True, False, 0), (rank, res)
+        assert res["empty_rank"] == (True, False, True), (rank, res)
+        assert res["overflow"] == (True, True, True, True), (rank, res)
+        assert res["after_resize"] == (True, False, 0), (rank, res)
+        err, scale, same, again, skipped = res["resmoe"]
+        assert err <= 6e-3 * max(1.0, scale) and same and not again and skipped, (rank, res)

@@ -5,7 +5,8 @@ Runs a few eval forwards under the torch profiler (CPU + GPU activities), orders
 reports: wall time of the step, GPU busy time, and the idle gaps > 15 us aggregated by (kernel before -> kernel after) -- the
 places where the launch queue ran dry (host syncs of the count exchange, host work between launches).
 
-usage: python3 tools/ep_gaps.py [micro_batches=1] [batch=256]"""
+usage: python3 tools/ep_gaps.py [micro_batches=1] [batch=256]
+       EP_GAPS_STATIC=1.25 python3 tools/ep_gaps.py ...     the speculative static exchange (alpha; raised in warm-up as needed)"""
 import argparse
 import os
 import sys
@@ -35,6 +36,13 @@ def main():
     def step():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             return model(images)
+    alpha = os.environ.get("EP_GAPS_STATIC")
+    if force and alpha:
+        from slim_switch_moe_vit_amd import ep
+        ep.set_speculative(model, float(alpha))
+        reps = sum(int(ep.run_guarded(step)[1]) for _ in range(5))
+        print(f"speculative static exchange: alpha {[round(float(b.mlp.ep_speculative), 3) for b in model.blocks]}, "
+              f"{reps} warm-up step(s) repeated on the counted exchange")
     for _ in range(5):
         step()
     torch.cuda.synchronize()
@@ -64,6 +72,13 @@ def main():
     print("idle gaps > 15 us by (kernel before -> kernel after): count, total us")
     for key, (n, tot) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:14]:
         print(f"  {n:4d} {tot:9.1f}   {key[0]}  ->  {key[1]}")
+    per = defaultdict(lambda: [0, 0.0])
+    for e in ks:
+        per[e.name[:72]][0] += 1
+        per[e.name[:72]][1] += e.time_range.end - e.time_range.start
+    print("GPU time by kernel: count, total us, avg us")
+    for name, (n, tot) in sorted(per.items(), key=lambda kv: -kv[1][1])[:24]:
+        print(f"  {n:4d} {tot:9.1f} {tot / n:8.1f}   {name}")
     if force:
         dist.destroy_process_group()
 

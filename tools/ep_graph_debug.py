@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Debug probe: which piece of the world-of-one static EP forward survives HIP-graph capture (run under faulthandler)."""
+import faulthandler
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+faulthandler.enable()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import slim_switch_moe_vit_amd as sm  # noqa: E402
+from slim_switch_moe_vit_amd import ep  # noqa: E402
+
+DEV = "cuda:0"
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1, device_id=torch.device(DEV))
+what = sys.argv[1] if len(sys.argv) > 1 else "a2a"
+if what == "a2a":
+    a = torch.randn(1024, 768, device=DEV).half()
+    b = torch.empty_like(a)
+    dist.all_to_all_single(b, a)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        dist.all_to_all_single(b, a)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    print("capturing all_to_all_single", flush=True)
+    with torch.cuda.graph(g):
+        w = dist.all_to_all_single(b, a, async_op=True)
+        w.wait()
+    print("captured", flush=True)
+    g.replay()
+    torch.cuda.synchronize()
+    print("replayed", bool(torch.equal(a, b)), flush=True)
+else:
+    from test_gpu_model import _init
+    model = _init(sm.create_model("moe_base_patch16_224_expert8_top1", num_classes=100, depth=2), 23).eval().to(DEV)
+    for blk in model.blocks:
+        blk.mlp.force_ep = True
+    model.ep_micro_batches = 1
+    ep.set_speculative(model, 2.0)
+    images = torch.randn(16, 3, 224, 224, generator=torch.Generator().manual_seed(24)).to(DEV)
+
+    def step():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return model(images)
+    eager = step().float().clone()
+    ep.check_static_overflow(flush=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    ep.check_static_overflow(flush=True)
+    print("capturing model", flush=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = step()
+    print("captured", flush=True)
+    g.replay()
+    torch.cuda.synchronize()
+    print("replayed", float((out.float() - eager).abs().max()), flush=True)
+dist.destroy_process_group()
