@@ -77,6 +77,7 @@ class AdamW(torch.optim.Optimizer):
         self._step_restore = {}   # device -> count loaded from a checkpoint, applied when the counter is (re)created
 
     supports_device_scalars = True
+    _slimmoe_refreshes_images = True     # (_foreign_step_hook: this step bumps the versions / refreshes the 16-bit images itself)
 
     def _step_counter(self, device) -> torch.Tensor:
         t = self._step_dev.get(device)
@@ -208,6 +209,36 @@ def _bump_versions(tensors) -> None:
     except (TypeError, AttributeError):
         from ._cache import invalidate_all
         invalidate_all()
+
+
+def _foreign_step_hook(optimizer, args, kwargs) -> None:
+    """Global optimizer step post-hook (registered on import, below).  The modules keep 16-bit operand images of their f32
+    weights, keyed on ``(param._version, data_ptr, dtype)`` (_cache.param_version).  An optimizer that updates through
+    ``p.data`` -- every timm-native optimizer reachable from the reference's ``--opt`` (main.py:90-96, 729-731) does -- moves the
+    weights WITHOUT moving ``_version``, and the next forward would go on reading the old images: training on stale weights, no
+    error, no warning.  After ANY optimizer's step other than this module's AdamW (whose fused step refreshes the images itself)
+    the version counters of its parameters are therefore bumped here, as an in-place torch op would have: the images are re-cast
+    on their next use.  (A hand-written update outside a torch.optim.Optimizer -- ``p.data.add_(...)`` in a loop -- cannot be seen:
+    call ``slim_switch_moe_vit_amd.invalidate_weight_images()`` after it.)"""
+    if getattr(optimizer, "_slimmoe_refreshes_images", False):
+        return
+    params = [p for group in optimizer.param_groups for p in group["params"] if isinstance(p, torch.Tensor)]
+    if params:
+        _bump_versions(params)
+
+
+def invalidate_weight_images() -> None:
+    """Drop every derived tensor (16-bit weight images, transposed images, zero-row constants): call after changing parameters
+    behind autograd's back (``p.data`` writes outside an optimizer, raw-pointer writes)."""
+    from ._cache import invalidate_all
+    invalidate_all()
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
+    _FOREIGN_HOOK = _reg_post(_foreign_step_hook)
+except ImportError:      # (a torch without global optimizer hooks: the documented invalidate_weight_images() remains)
+    _FOREIGN_HOOK = None
 
 
 class NativeScaler:

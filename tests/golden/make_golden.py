@@ -18,6 +18,8 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# where the .npz files go: this directory, or -- tests/test_oracle.py::test_committed_fixtures_regenerate_bit_identically -- a scratch one
+OUT = os.environ.get("SLIMMOE_GOLDEN_OUT", HERE)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF_LAYERS = "/root/reference/models/layers.py"
@@ -47,7 +49,7 @@ def main():
     x = torch.randn(3, 37, 192, generator=g)
     with torch.no_grad():
         y = mlp(x)
-    np.savez_compressed(os.path.join(HERE, "ref_mlp_tiny.npz"), x=x.numpy(), fc1_w=mlp.fc1.weight.detach().numpy(),
+    np.savez_compressed(os.path.join(OUT, "ref_mlp_tiny.npz"), x=x.numpy(), fc1_w=mlp.fc1.weight.detach().numpy(),
                         fc1_b=mlp.fc1.bias.detach().numpy(), fc2_w=mlp.fc2.weight.detach().numpy(),
                         fc2_b=mlp.fc2.bias.detach().numpy(), y=y.numpy())
 
@@ -57,7 +59,7 @@ def main():
         ln.weight.copy_(1 + 0.1 * torch.randn(192, generator=g))
         ln.bias.copy_(0.1 * torch.randn(192, generator=g))
         yl = ln(x)
-    np.savez_compressed(os.path.join(HERE, "ref_layernorm_tiny.npz"), x=x.numpy(), w=ln.weight.detach().numpy(),
+    np.savez_compressed(os.path.join(OUT, "ref_layernorm_tiny.npz"), x=x.numpy(), w=ln.weight.detach().numpy(),
                         b=ln.bias.detach().numpy(), y=yl.numpy())
 
     # ---- 1c. reference Attention (models/layers.py:227-269; the same computation as models/vision_transformer.py:248-280)
@@ -74,7 +76,7 @@ def main():
     xb = torch.randn(1, 197, 192, generator=g)
     with torch.no_grad():
         ya, yb = att(xa), att(xb)
-    np.savez_compressed(os.path.join(HERE, "ref_attention_tiny.npz"), xa=xa.numpy(), xb=xb.numpy(), ya=ya.numpy(),
+    np.savez_compressed(os.path.join(OUT, "ref_attention_tiny.npz"), xa=xa.numpy(), xb=xb.numpy(), ya=ya.numpy(),
                         yb=yb.numpy(), qkv_w=att.qkv.weight.detach().numpy(), qkv_b=att.qkv.bias.detach().numpy(),
                         proj_w=att.proj.weight.detach().numpy(), proj_b=att.proj.bias.detach().numpy(),
                         num_heads=np.array(3))
@@ -100,7 +102,7 @@ def main():
                              idx_pruned=r.plan.idx_pruned).items():
             cases[f"{name}.{key}"] = val.numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
         cases[f"{name}.meta"] = np.array([T, k, gate, cap], dtype=np.int64)
-    np.savez_compressed(os.path.join(HERE, "oracle_moe_small.npz"), **cases)
+    np.savez_compressed(os.path.join(OUT, "oracle_moe_small.npz"), **cases)
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 

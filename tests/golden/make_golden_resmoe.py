@@ -23,6 +23,8 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+# where the .npz files go: this directory, or -- tests/test_oracle.py::test_committed_fixtures_regenerate_bit_identically -- a scratch one
+OUT = os.environ.get("SLIMMOE_GOLDEN_OUT", HERE)
 REF_RESMOE = "/root/reference/models/resMoE.py"
 REF_LAYERS = "/root/reference/models/layers.py"
 
@@ -185,10 +187,10 @@ def main():
     layers = load_ref_layers()
     gate = {}
     gate_fixture(ref, gate)
-    np.savez_compressed(os.path.join(HERE, "ref_gate_tiny.npz"), **gate)
+    np.savez_compressed(os.path.join(OUT, "ref_gate_tiny.npz"), **gate)
     blk = {}
     resblock_fixture(ref, layers, blk)
-    np.savez_compressed(os.path.join(HERE, "ref_resblock_tiny.npz"), **blk)
+    np.savez_compressed(os.path.join(OUT, "ref_resblock_tiny.npz"), **blk)
     print("gate: eval skipped", gate["eval_skipped"], "of", gate["eval_total"], "| train-hard skipped", gate["train_hard_skipped"])
     print("wrote ref_gate_tiny.npz, ref_resblock_tiny.npz")
 

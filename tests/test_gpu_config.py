@@ -10,6 +10,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from _mp import dtype_factor  # noqa: E402
+
 import slim_switch_moe_vit_amd as sm  # noqa: E402
 from slim_switch_moe_vit_amd import dense, ops, vit  # noqa: E402
 from slim_switch_moe_vit_amd.vit import _HalfCache  # noqa: E402
@@ -181,8 +183,10 @@ def test_resmoe_training_with_default_flags_on_own_kernels_matches_the_composed_
     # Bar: the own path is no further from the f32 gradients than torch's own fp16-autocast path (x 1.5), or within 3 %.  (Some
     # gradients of a model this small are dominated by cancellation -- the skip gates' dz = -<g_f, xn> p (1 - p) -- and BOTH fp16
     # computations are 5-20 % off the f32 value there; against the reference's f32 fixture the same kernels are within 0.1 %.)
+    print("resmoe training, all rows (own, torch-fp16, name):", [(f"{eo:.1e}", f"{et:.1e}", n) for eo, et, n in rows])
+    # measured (gpurun_out/r5_t5_prints.log): eo / et between 0.2 and 1.26 over all 60 tensors -- the own path tracks torch's fp16 path
     for eo, et, n in rows:
-        assert eo <= max(3e-2, 1.5 * et), (eo, et, n)
+        assert eo <= (1.5 * et + 1e-3) * dtype_factor(), (eo, et, n)
 
 
 def test_training_with_stochastic_depth_and_1000_classes_on_own_kernels():
@@ -219,7 +223,7 @@ def test_training_with_stochastic_depth_and_1000_classes_on_own_kernels():
     assert set(g_own) == set(g_ref)
     worst = max((_rel(g_own[n], g_ref[n]), n) for n in g_ref if float(g_ref[n].abs().max()) > 0)
     print(f"stochastic depth: loss {l_own:.5f} vs {l_ref:.5f}; worst relative L2 gradient difference {worst[0]:.2e} ({worst[1]})")
-    assert worst[0] <= 3e-2, worst
+    assert worst[0] <= 6e-3 * dtype_factor(), worst       # measured 1.99e-3 (blocks.1.attn.qkv.weight): 3 x
     assert a.head.weight.grad.shape == (1000, 768) and float(a.head.weight.grad.abs().max()) > 0
 
 

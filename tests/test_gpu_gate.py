@@ -9,6 +9,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from _mp import dtype_factor  # noqa: E402
+
 from oracle import moe_oracle as mo  # noqa: E402
 import slim_switch_moe_vit_amd as sm  # noqa: E402
 from slim_switch_moe_vit_amd import ops  # noqa: E402
@@ -163,8 +165,8 @@ def test_fused_moe_half_with_skip_gate(d, h, E, k):
     assert torch.equal(idx.cpu(), o.idx)
     ref = o.out + xn_c
     diff = fused.cpu() - ref
-    assert diff.abs().max().item() <= 1e-3 * max(1.0, float(o.out.abs().max())) + 1e-6
-    assert (diff.norm() / o.out.norm()).item() <= 1e-3
+    assert diff.abs().max().item() <= 1e-3 * dtype_factor() * max(1.0, float(o.out.abs().max())) + 1e-6
+    assert (diff.norm() / o.out.norm()).item() <= 1e-3 * dtype_factor()
 
 
 def _init_resmoe(model, seed):
@@ -344,9 +346,11 @@ def test_residual_block_against_the_reference_forward_residule_moe_fixture(mode)
         assert gt._skipped_tokens == float(np.rint(g[key])[..., 0].sum()), key
     diff = (y.float().cpu() - ref)
     scale = max(1.0, float(ref.abs().max()))
-    tol = 6e-3 if fused else 1e-4
+    # measured (gpurun_out/r5_t4_prints.log): fused fp16 autocast 1.356e-3 at scale 4.16 (3.3e-4 of it), rel L2 2.09e-4; composed f32
+    # 1.79e-6 (4.3e-7 of the scale), rel L2 2.7e-7 -- the bars are 3 x that
+    tol_abs, tol_l2 = (1e-3 * dtype_factor(), 6.3e-4 * dtype_factor()) if fused else (1.3e-6, 8.2e-7)
     print(f"{mode}: max |y - reference| = {float(diff.abs().max()):.3e} (scale {scale:.2f}), rel L2 {float(diff.norm() / ref.norm()):.2e}")
-    assert float(diff.abs().max()) <= tol * scale and float(diff.norm() / ref.norm()) <= tol
+    assert float(diff.abs().max()) <= tol_abs * scale and float(diff.norm() / ref.norm()) <= tol_l2
 
 
 # ---- training: the gate's backward kernel, the gated half's Function, the whole block against the reference's gradients ----------
@@ -411,11 +415,15 @@ def test_gate_ln_backward_in_one_pass_matches_float64_autograd_of_the_reference_
     dev = lambda t: t.to(DEV) if t is not None else None  # noqa: E731
     dx, dg, db_, dgw, dgb, dz = ops.gate_ln_bwd(dev(x), dev(g_f), dev(g_out), dev(gam), dev(bet), eps, dev(w), dev(b), dev(mask),
                                                 want_dz=True)
-    tol = 3e-5 if gdt == torch.float32 else 3e-5
+    worst = max(_rel(dx, xr.grad), _rel(dg, gr.grad), _rel(db_, btr.grad), _rel(dgw, wr.grad))
+    print(f"gate_ln_bwd[{gdt}, with_out={with_out}]: worst relative L2 vs float64 autograd {worst:.2e}")
+    tol = 8e-7       # measured <= 2.7e-7 for f32 and f16 upstream gradients alike (gpurun_out/r5_t5_prints.log): 3 x
     assert _rel(dx, xr.grad) <= tol, _rel(dx, xr.grad)
     assert _rel(dg, gr.grad) <= tol and _rel(db_, btr.grad) <= tol
-    assert _rel(dgw, wr.grad) <= tol and abs(float(dgb) - float(br.grad)) <= tol * max(1.0, abs(float(br.grad)))
-    assert abs(float(dz.sum()) - float(br.grad)) <= tol * max(1.0, abs(float(br.grad)))
+    e_b = abs(float(dgb) - float(br.grad)) / max(1.0, abs(float(br.grad)))
+    e_z = abs(float(dz.sum()) - float(br.grad)) / max(1.0, abs(float(br.grad)))
+    print(f"  gate bias gradient {e_b:.2e}, sum of dz {e_z:.2e} (relative to max(1, |db|))")
+    assert _rel(dgw, wr.grad) <= tol and e_b <= 1e-5 and e_z <= 1e-5     # (scalars: f32 sums over every row)
     again = ops.gate_ln_bwd(dev(x), dev(g_f), dev(g_out), dev(gam), dev(bet), eps, dev(w), dev(b), dev(mask))
     assert all(torch.equal(a, c) for a, c in zip(again[:5], (dx, dg, db_, dgw, dgb)))          # deterministic
     # the three-kernel composition it replaces (saved xn from the forward kernel's own LayerNorm)
@@ -462,7 +470,9 @@ def test_residual_block_training_against_the_reference_forward_residule_moe_grad
     for gt, key in ((blk.dense_gate, "train_dense_mask"), (blk.moe_gate, "train_moe_mask")):
         assert gt._total_tokens == T and gt._skipped_tokens == float(np.rint(g[key])[..., 0].sum()), key
     ref_y = torch.from_numpy(g["train_y"])
-    assert float((y.float().cpu() - ref_y).abs().max()) <= 6e-3 * max(1.0, float(ref_y.abs().max()))
+    err_y = float((y.detach().float().cpu() - ref_y).abs().max())
+    print(f"residual block, training: max |y - reference| = {err_y:.3e} (scale {float(ref_y.abs().max()):.2f})")
+    assert err_y <= 1e-3 * dtype_factor() * max(1.0, float(ref_y.abs().max()))     # measured 1.37e-3 at scale 4.16 (3.3e-4 of it): 3 x
     worst = [(_rel(x.grad, torch.from_numpy(g["train_dx"])), "x")]
     names = {"mlp.experts.htoh4.weight": "mlp.fc1.weight", "mlp.experts.htoh4.bias": "mlp.fc1.bias",
              "mlp.experts.h4toh.weight": "mlp.fc2.weight", "mlp.experts.h4toh.bias": "mlp.fc2.bias"}
@@ -474,7 +484,7 @@ def test_residual_block_training_against_the_reference_forward_residule_moe_grad
         worst.append((_rel(p.grad, ref), n))
     print("residual block, training, relative L2 gradient differences vs the reference:",
           {n: f"{e:.1e}" for e, n in sorted(worst, reverse=True)[:6]})
-    assert max(worst)[0] <= 3e-2, max(worst)
+    assert max(worst)[0] <= 3.3e-3 * dtype_factor(), max(worst)     # measured <= 1.1e-3 (dense_gate.head.1.weight): 3 x
 
 
 @pytest.mark.parametrize("E,k", [(8, 1), (8, 2), (4, 1)])

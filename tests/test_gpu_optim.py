@@ -235,3 +235,66 @@ def test_adamw_state_dict_round_trip_keeps_the_bias_correction_step():
     run(o4, resumed3, 4, start=5)
     for p, q in zip(resumed3, ref):
         assert (p.detach().cpu().double() - q.detach()).abs().max().item() <= 3e-6 * max(1.0, float(q.abs().max()))
+
+
+class _DataSGD(torch.optim.Optimizer):
+    """What timm's native optimizers do (main.py:90-96 --opt ...): the update goes through ``p.data``, which does NOT move
+    ``p._version``."""
+
+    def __init__(self, params, lr):
+        super().__init__(params, dict(lr=lr))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    p.data.add_(p.grad.data, alpha=-group["lr"])
+
+
+def test_foreign_optimizer_step_invalidates_the_16_bit_weight_images():
+    """the modules' 16-bit weight images are keyed on (param._version, data_ptr, dtype); an optimizer that
+    updates through ``p.data`` leaves ``_version`` alone, and the next forward kept reading the OLD images -- silently.  The global
+    optimizer step post-hook (optim._foreign_step_hook) bumps the versions after any foreign optimizer's step: one such SGD step
+    changes the next forward's output exactly as a fresh model loaded with the updated weights computes it."""
+    torch.manual_seed(0)
+    model = sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=10, depth=2).to(DEV)
+    with torch.no_grad():
+        for blk in model.blocks:
+            blk.mlp.experts.htoh4.weight.normal_(0, 0.02)
+            blk.mlp.experts.h4toh.weight.normal_(0, 0.02)
+        model.head.weight.normal_(0, 0.02)
+    images = torch.randn(4, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(DEV)
+    target = torch.tensor([1, 2, 3, 4], device=DEV)
+
+    def infer(m):
+        m.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            return m(images).float()
+
+    before = infer(model)                                    # builds every 16-bit image
+    opt = _DataSGD(model.parameters(), lr=0.5)
+    model.train()
+    with torch.autocast("cuda", dtype=torch.float16):
+        loss = torch.nn.functional.cross_entropy(model(images).float(), target)
+    loss.backward()
+    versions = [p._version for p in model.parameters()]
+    opt.step()
+    moved = [p._version != v for p, v in zip(model.parameters(), versions) if p.grad is not None]
+    assert all(moved), "the hook must have bumped the version of every parameter the optimizer stepped"
+    after = infer(model)
+
+    def fresh_copy():                                         # a new model loaded with the CURRENT weights: no cache of any kind
+        torch.manual_seed(0)
+        m = sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=10, depth=2)
+        m.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        return m.to(DEV)
+    want = infer(fresh_copy())
+    assert float((after - before).abs().max()) > 1e-3, "the step must have changed the output"
+    assert torch.equal(after, want), float((after - want).abs().max())
+    # the documented escape hatch for updates no optimizer hook can see
+    with torch.no_grad():
+        for p in model.parameters():
+            p.data.mul_(1.01)
+    sm.invalidate_weight_images()
+    assert torch.equal(infer(model), infer(fresh_copy()))

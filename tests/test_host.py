@@ -4,6 +4,7 @@ import ctypes
 import inspect
 import os
 import re
+import types
 
 import pytest
 import torch
@@ -386,3 +387,37 @@ def test_adamw_state_dict_carries_the_step_count_on_cpu():
     assert ob.state_dict()["state"][0]["step"] == 4
     run(ob, b, grads[4:])
     assert torch.allclose(b.detach(), ref.detach(), rtol=0, atol=1e-6)
+
+
+def test_foreign_optimizer_step_bumps_parameter_versions():
+    """optim._foreign_step_hook (a global optimizer step post-hook): an optimizer that writes through ``p.data`` leaves ``_version``
+    where it was -- the key of the 16-bit weight images -- so the hook moves it; the package's own AdamW is exempt (its fused step
+    refreshes the images itself)."""
+    import slim_switch_moe_vit_amd as sm
+    from slim_switch_moe_vit_amd import optim
+
+    class DataSGD(torch.optim.Optimizer):
+        def __init__(self, params):
+            super().__init__(params, dict(lr=0.1))
+
+        def step(self, closure=None):
+            for g in self.param_groups:
+                for p in g["params"]:
+                    p.data.add_(p.grad.data, alpha=-g["lr"])
+
+    p = torch.nn.Parameter(torch.ones(4))
+    p.grad = torch.ones(4)
+    v0 = p._version
+    DataSGD([p]).step()
+    assert p._version > v0 and torch.allclose(p.detach(), torch.full((4,), 0.9))
+    assert optim._FOREIGN_HOOK is not None and getattr(sm.AdamW, "_slimmoe_refreshes_images", False)
+    seen = []
+    real = optim._bump_versions
+    optim._bump_versions = lambda ts: seen.append(len(ts))
+    try:
+        optim._foreign_step_hook(types.SimpleNamespace(_slimmoe_refreshes_images=True, param_groups=[{"params": [p]}]), (), {})
+        assert seen == []
+        optim._foreign_step_hook(types.SimpleNamespace(param_groups=[{"params": [p]}]), (), {})
+        assert seen == [1]
+    finally:
+        optim._bump_versions = real

@@ -283,3 +283,26 @@ def test_forced_routing_is_the_identity_on_the_oracles_own_decisions_and_traces_
     logits = mo.router_logits(x, wg, bg)
     gap = (logits.max(1).values - logits.gather(1, forced).squeeze(1))[::50].max()
     assert abs(tr[0]["max_margin"] - float(gap)) < 1e-6
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree only exists in the build container")
+def test_committed_fixtures_regenerate_bit_identically(tmp_path):
+    """The .npz files under tests/golden/ that pin the oracle are OUTPUTS OF THE REFERENCE'S OWN CODE (models/layers.py Mlp / LayerNorm /
+    Attention; models/resMoE.py Gate / forward_residule_moe) as the committed scripts produce them: re-run both scripts into a scratch
+    directory and require every array of every committed fixture back bit for bit (same keys, dtypes, shapes, bytes).  A fixture edited
+    by hand, or a script that drifted from the data it is said to have made, fails here."""
+    import subprocess
+    import sys
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    env = dict(os.environ, SLIMMOE_GOLDEN_OUT=str(tmp_path))
+    for script in ("make_golden.py", "make_golden_resmoe.py"):
+        r = subprocess.run([sys.executable, os.path.join(golden, script)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (script, r.stderr[-800:])
+    made = sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
+    assert made == sorted(f for f in os.listdir(golden) if f.endswith(".npz")), made
+    for f in made:
+        new, old = np.load(os.path.join(tmp_path, f)), np.load(os.path.join(golden, f))
+        assert sorted(new.files) == sorted(old.files), f
+        for key in old.files:
+            a, b = old[key], new[key]
+            assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes(), (f, key)
