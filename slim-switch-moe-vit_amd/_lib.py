@@ -135,9 +135,10 @@ class SlimMoEError(RuntimeError):
     pass
 
 
-def source_build_id() -> str:
+def source_build_id(extra_flags: str = "") -> str:
     """sha256 (first 16 hex digits) over the library's sources as they lie in the tree -- what ``smoe_build_id()`` of a
-    binary built from them returns.  None if the sources are not there (a binary-only install)."""
+    binary built from them returns.  None if the sources are not there (a binary-only install).  ``extra_flags``: appended to the
+    flags line as the Makefile appends them for a derived build (" -DSMOE_CLOCK" = the clock-probe library's id)."""
     import hashlib
     import re
     h = hashlib.sha256()
@@ -151,7 +152,7 @@ def source_build_id() -> str:
         flags = re.search(r"^CXXFLAGS\s*=\s*(.*)$", mk, re.M).group(1)
         arch = re.search(r"^ARCH\s*\?=\s*(\S+)", mk, re.M).group(1)
         flags = flags.replace("$(ARCH)", arch).replace("$(DIAG)", "")
-        h.update((" ".join(flags.split()) + "\n").encode())
+        h.update((" ".join(flags.split()) + extra_flags + "\n").encode())
     except (OSError, AttributeError):
         return None
     return h.hexdigest()[:16]

@@ -30,6 +30,73 @@ def _speculative_alpha(value):
     return float(value) if value else None
 
 
+class GraphedForward:
+    """``model(images)`` under fp16 autocast / no_grad, replayed from ONE HIP graph per input shape.
+
+    The library's launch functions neither allocate nor synchronise (include/slimmoe.h), so the single-rank eval forward captures
+    whole (tests/test_gpu_model.py::test_eval_forward_captured_in_a_hip_graph_replays_bit_exact) and a replay computes the same
+    bits.  What it buys depends on the model: ViT-B/16 at batch 256 is not launch-bound (12.75 vs 12.80 ms), but the reference's
+    own DeiT-Tiny models (models/resMoE.py:151-209, batch 128) run ~150 kernels of 10-45 us per forward and the gaps between
+    them are a third of the step -- 3.40 -> 2.26 ms (resmoe_tiny_patch16_224_expert8), 2.75 -> 2.09 ms (moe_tiny_...),
+    profiles/r05_tiny_models.md.  One graph per (shape, dtype) of the input; the first call with a new shape runs two eager
+    forwards (they fill every cache: 16-bit weight images, constant tables) and captures the third.  Host-side bookkeeping the
+    captured kernels cannot do is replayed by hand: the token-skip gates' ``_total_tokens`` (the skipped-token counters live on
+    the device and are updated by the captured kernels themselves).  Not for expert-parallel models: hipStreamEndCapture dies on
+    RCCL kernels on this stack (tools/ep_graph_debug.py)."""
+
+    def __init__(self, model: torch.nn.Module, autocast: bool = True):
+        self.model, self.autocast, self.graphs = model, autocast, {}
+
+    @staticmethod
+    def supported(model: torch.nn.Module, device) -> bool:
+        dev = torch.device(device)
+        if dev.type != "cuda" or model.training:
+            return False
+        return not any(getattr(m, "ep_active", lambda: False)() for m in model.modules() if hasattr(m, "ep_active"))
+
+    def _run(self, images):
+        with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.float16, enabled=self.autocast):
+            return self.model(images)
+
+    def _gates(self):
+        return [m for m in self.model.modules() if hasattr(m, "_total_tokens") and hasattr(m, "skip_counter")]
+
+    def _capture(self, images):
+        static_in = images.clone()
+        side = torch.cuda.Stream(images.device)
+        side.wait_stream(torch.cuda.current_stream(images.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._run(static_in)
+        torch.cuda.current_stream(images.device).wait_stream(side)
+        torch.cuda.synchronize(images.device)
+        gates = self._gates()
+        before = [g._total_tokens for g in gates]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = self._run(static_in)
+        tokens = [(g, g._total_tokens - b) for g, b in zip(gates, before)]
+        for g, b in zip(gates, before):       # the capture itself computed nothing: its host-side counts are taken back
+            g._total_tokens = b
+        return static_in, graph, static_out, tokens
+
+    def __call__(self, images: torch.Tensor) -> torch.Tensor:
+        key = (tuple(images.shape), images.dtype, str(images.device))
+        ent = self.graphs.get(key)
+        if ent is None:
+            gates = self._gates()
+            before = [(g, g._total_tokens, g._skipped_tokens) for g in gates]   # the two warm-up forwards count for nothing
+            ent = self.graphs[key] = self._capture(images)
+            for g, t, s in before:
+                g._total_tokens, g._skipped_tokens = t, s
+        static_in, graph, static_out, tokens = ent
+        static_in.copy_(images)
+        graph.replay()
+        for g, n in tokens:
+            g._total_tokens += n
+        return static_out.clone()        # (the graph's own output buffer is overwritten by the next replay)
+
+
 def accuracy(output: torch.Tensor, target: torch.Tensor, topk=(1,)):
     """timm.utils.accuracy: top-k accuracy in percent."""
     maxk = min(max(topk), output.shape[1])
@@ -40,8 +107,10 @@ def accuracy(output: torch.Tensor, target: torch.Tensor, topk=(1,)):
 
 @torch.no_grad()
 def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: torch.nn.Module, device,
-             autocast: bool = True, *, ep_speculative="auto"):
-    """engine.py:88-121.  Under expert parallelism the harness owns the step, so it can run the exchange WITHOUT a host round trip
+             autocast: bool = True, *, ep_speculative="auto", hip_graph="auto"):
+    """engine.py:88-121.  ``hip_graph`` (True / False / "auto" = on for single-rank GPU models unless SLIMMOE_EVAL_GRAPH=0): every
+    batch shape's forward is captured once and replayed (GraphedForward: same bits, no launch gaps -- a third of the step of the
+    reference's DeiT-Tiny models).  Under expert parallelism the harness owns the step, so it can run the exchange WITHOUT a host round trip
     per layer even for the reference's capacity-less NaiveGate: ``ep_speculative`` (alpha; "auto" = SLIMMOE_EP_ALPHA, default 1.5;
     None / 0 = off) sizes static slots of alpha x the balanced share (ep.set_speculative), and a batch whose routing does not fit
     -- reported by all ranks together -- is evaluated again on the counted exchange (ep.run_guarded): the metrics are those of the
@@ -53,6 +122,10 @@ def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: to
     _size_static_exchange(model, data_loader)
     if any(m.ep_active() for m in ep._ep_modules(model)):
         ep.set_speculative(model, _speculative_alpha(ep_speculative))
+    import os
+    if hip_graph == "auto":
+        hip_graph = os.environ.get("SLIMMOE_EVAL_GRAPH", "1") != "0"
+    graphed = GraphedForward(model, autocast) if (hip_graph and GraphedForward.supported(model, dev)) else None
     n, loss_sum, a1, a5, repeats = 0, 0.0, 0.0, 0.0, 0
     t0 = time.perf_counter()
     for images, target in data_loader:
@@ -61,7 +134,7 @@ def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: to
 
         def step():
             with torch.autocast(device_type=dev.type, dtype=torch.float16, enabled=autocast and dev.type == "cuda"):
-                output = model(images)
+                output = graphed(images) if graphed is not None else model(images)
                 return output, criterion(output, target)
         # (flush: this step's overflow report is read before its numbers are -- the .item() below waits for the batch anyway)
         (output, loss), again = ep.run_guarded(step, flush=True)
@@ -76,7 +149,8 @@ def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: to
         torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     n = max(n, 1)
-    return {"loss": loss_sum / n, "acc1": a1 / n, "acc5": a5 / n, "images_per_sec": n / dt, "ep_repeated_steps": repeats}
+    return {"loss": loss_sum / n, "acc1": a1 / n, "acc5": a5 / n, "images_per_sec": n / dt, "ep_repeated_steps": repeats,
+            "hip_graph": graphed is not None}
 
 
 def _criterion_takes_inputs(criterion) -> bool:

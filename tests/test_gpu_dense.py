@@ -87,7 +87,10 @@ def test_linear_function_forward_and_backward_on_own_gemms(M, K, N, res):
         assert torch.equal(rg.grad, dy.to(DEV)), "the residual's gradient is the output's"
 
 
-@pytest.mark.parametrize("B,N,H", [(3, 197, 12), (2, 197, 3), (2, 50, 4), (1, 256, 2), (2, 16, 1), (1, 130, 3), (4, 198, 6)])
+# (N = 65 / 100 / 128: 5-8 key tiles -- the <HT, 8, 8> instantiation of the eight-wave kernel, which 197 / 256 (13 / 16 tiles) never
+#  select: ADVICE r4)
+@pytest.mark.parametrize("B,N,H", [(3, 197, 12), (2, 197, 3), (2, 50, 4), (1, 256, 2), (2, 16, 1), (1, 130, 3), (4, 198, 6),
+                                   (2, 65, 3), (2, 100, 2), (1, 128, 4)])
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_attention_backward_matches_float64_autograd(B, N, H, dt):
     """dq, dk, dv of softmax(q k^T scale) v (models/vision_transformer.py:263-275) on the fused [B, N, 3, H, 64] layout."""
@@ -113,6 +116,39 @@ def test_attention_backward_matches_float64_autograd(B, N, H, dt):
     qg = qkv.to(DEV).requires_grad_(True)
     dense.AttentionFn.apply(qg, B, N, H, 64, scale).backward(do.to(DEV))
     assert torch.equal(qg.grad, dqkv)
+
+
+def _attn_bwd_hash_worker(q, waves):
+    """dqkv of a fixed input under SMOE_ATTN_BWD_WAVES (read once per process: csrc/attention_bwd.hip) for several shapes."""
+    import hashlib
+    import os
+    os.environ["SMOE_ATTN_BWD_WAVES"] = str(waves)
+    from slim_switch_moe_vit_amd import ops as _ops
+    out = {}
+    for B, N, H in ((2, 197, 12), (2, 65, 3), (2, 100, 2), (1, 128, 4), (1, 256, 2), (2, 50, 4)):
+        g = torch.Generator().manual_seed(B * 1000 + N + H)
+        qkv = (torch.randn(B, N, 3, H, 64, generator=g) * 1.2).half().to(DEV)
+        do = (torch.randn(B, N, H * 64, generator=g) * 0.5).half().to(DEV)
+        o, lse = _ops.attention(qkv, B, N, H, 64, 0.125, want_lse=True)
+        dqkv = _ops.attention_bwd(qkv, o, do, lse, B, N, H, 64, 0.125)
+        out[(B, N, H)] = hashlib.sha256(dqkv.cpu().numpy().tobytes()).hexdigest()
+    q.put((waves, out))
+
+
+def test_attention_backward_eight_waves_equal_four_waves_bitwise():
+    """Round 4 moved attn_bwd_kernel to eight waves per workgroup on the claim that every output element keeps its accumulation
+    order; that was hashed at the training shape only.  Here: the four- and the eight-wave form (SMOE_ATTN_BWD_WAVES, read once per
+    process, hence two child processes) produce the same BITS at 2-16 key tiles, incl. the <HT, 8, 8> instantiation (N = 65-128)."""
+    import torch.multiprocessing as mp
+    from _mp import join_or_kill
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_attn_bwd_hash_worker, args=(q, w)) for w in (4, 8)]
+    for p in procs:
+        p.start()
+    join_or_kill(procs, 240)
+    got = dict(q.get(timeout=10) for _ in procs)
+    assert got[4] == got[8], {k: (got[4][k][:12], got[8][k][:12]) for k in got[4] if got[4][k] != got[8][k]}
 
 
 def _train_losses_and_grads(model, images, target, backend):

@@ -629,3 +629,39 @@ def test_static_capacity_padded_exchange_ranks_on_one_gpu(world):
         assert dropped == 1, "the test must exercise dropping"
         assert same_counts
         assert err <= 2e-3 and err_ln <= 2e-3, (rank, err, err_ln)
+
+
+def test_eval_harness_on_hip_graphs_reproduces_the_eager_harness():
+    """engine.evaluate(hip_graph=True): every batch shape's forward is captured once (GraphedForward) and replayed -- the same
+    logits BIT FOR BIT, hence the same loss / accuracy, and the same token-skip counters (host-side ``_total_tokens`` replayed by
+    hand, device-side skip counters by the captured kernels) as the eager harness, over two batches of one shape and a ragged last
+    one.  The reference's live model (resmoe_tiny_patch16_224_expert8, gates firing) and the stock-block one."""
+    for name, kw in (("resmoe_tiny_patch16_224_expert8", dict(starting_threshold=0.55, target_threshold=0.5)),
+                     ("moe_tiny_patch16_224_expert8", {})):
+        torch.manual_seed(0)
+        model = _init(sm.create_model(name, num_classes=100, depth=3, **kw), 51)
+        with torch.no_grad():
+            for blk in model.blocks:
+                for gt in (getattr(blk, "dense_gate", None), getattr(blk, "moe_gate", None)):
+                    if gt is not None:
+                        gt.head[1].weight.normal_(0, 0.3, generator=torch.Generator().manual_seed(5))
+        model = model.to(DEV)
+        g = torch.Generator().manual_seed(52)
+        batches = [(torch.randn(b, 3, 224, 224, generator=g), torch.randint(0, 100, (b,), generator=g)) for b in (6, 6, 3)]
+        gates = [m for m in model.modules() if isinstance(m, sm.Gate)]
+
+        def run(graph):
+            for gt in gates:
+                gt._total_tokens, gt._skipped_tokens = 0, 0.0
+            stats = sm.evaluate(batches, model, DEV, hip_graph=graph)
+            return stats, [(gt._total_tokens, gt._skipped_tokens) for gt in gates]
+
+        eager, c_eager = run(False)
+        graphed, c_graph = run(True)
+        again, c_again = run(True)            # graphs are per evaluate() call: captured afresh, same numbers
+        assert graphed["hip_graph"] and not eager["hip_graph"]
+        for key in ("loss", "acc1", "acc5"):
+            assert graphed[key] == eager[key] == again[key], (name, key, graphed[key], eager[key])
+        assert c_graph == c_eager == c_again, (name, c_graph, c_eager)
+        if gates:
+            assert sum(s for _, s in c_eager) > 0, "the gates must fire in this test"

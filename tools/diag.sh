@@ -13,6 +13,8 @@
 #   tools/diag.sh train-profile TAG                  rocprofv3 kernel stats of the two training steps only
 #   tools/diag.sh profile TAG                        rocprofv3 kernel stats of bench / train / dispatch + PMC sets of both GEMMs
 #                                                    -> gpurun_out/prof_TAG   (counters in passes of their own: --pmc alone)
+#   tools/diag.sh tiny-profile TAG                   the reference's own DeiT-Tiny MoE models: eval tables + rocprofv3 kernel stats
+#   tools/diag.sh cfg4-profile TAG                   BASELINE cfg 4's model (ViT-L/16 @384, E 32) at batch 64 + rocprofv3 kernel stats
 # `stamps`, `order-*` and `bench-order-ab` use a DIAGNOSTIC build of the library made in /tmp (the production .so stays untouched).
 set -e
 export TMPDIR=/tmp
@@ -99,6 +101,20 @@ print(d['ms_per_step'], {k: v['avg_ms'] for k, v in d['kernels'].items() if 'gem
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o train -- python3 tools/train_bench.py model 128 6 > $O/train.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_resmoe -o train -- python3 tools/train_bench.py model 128 6 resmoe_base_patch16_224_expert8_top1 > $O/train_resmoe.log 2>&1
     grep "train step" $O/train_unprofiled.log $O/train_resmoe_unprofiled.log ;;
+  tiny-profile)    # the reference's own models (DeiT-Tiny, E 8, top-2, batch 128): tools/diag.sh tiny-profile TAG
+    TAG=$1; O=gpurun_out/prof_$TAG; mkdir -p $O
+    for m in resmoe_tiny_patch16_224_expert8 moe_tiny_patch16_224_expert8; do
+      python3 tools/tiny_bench.py $m 128 20 > $O/tiny_$m.json 2> $O/tiny_$m.txt
+      rocprofv3 --kernel-trace --stats --output-format csv -d $O/tiny_$m -o tiny -- python3 tools/tiny_bench.py $m 128 20 > $O/tiny_${m}_prof.log 2>&1
+    done
+    python3 tools/train_bench.py model 128 10 resmoe_tiny_patch16_224_expert8 > $O/tiny_train_unprofiled.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/tiny_train -o train -- python3 tools/train_bench.py model 128 6 resmoe_tiny_patch16_224_expert8 > $O/tiny_train.log 2>&1
+    grep -h "images/s" $O/tiny_*.txt $O/tiny_train_unprofiled.log ;;
+  cfg4-profile)    # BASELINE cfg 4's model at its per-rank batch (512 / 8 = 64): tools/diag.sh cfg4-profile TAG
+    TAG=$1; O=gpurun_out/prof_$TAG; mkdir -p $O
+    python3 tools/cfg4_bench.py 64 > $O/cfg4_b64.txt 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg4 -o cfg4 -- python3 tools/cfg4_bench.py 64 > $O/cfg4_prof.log 2>&1
+    grep -v amdgpu $O/cfg4_b64.txt ;;
   *)
-    sed -n 2,22p "$0"; exit 1 ;;
+    sed -n 2,24p "$0"; exit 1 ;;
 esac

@@ -38,6 +38,10 @@ def main():
         sys.exit("gemm_clock.py needs the clock-probe build: SLIMMOE_LIB=.../libslimmoe_hip_clock.so (make clock)")
     rd.restype = ctypes.c_int
     rd.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    want, got = _lib.source_build_id(" -DSMOE_CLOCK"), _lib.binary_build_id()
+    if want is not None and got != want:     # a probe library left over from other sources would clock another kernel
+        sys.exit(f"gemm_clock.py: the clock-probe library reports build id {got}, these sources with -DSMOE_CLOCK hash to {want}: "
+                 "rebuild it (make -C slim-switch-moe-vit_amd/csrc clock)")
     idx = torch.randint(0, E, (T, 1), device=dev)
     counts, offsets, pos, inv_pos, _ = ops.dispatch_plan(idx, E)
     x16 = torch.randn(T, d, device=dev).half()                     # random operands: zeros would clock ~20 % higher

@@ -79,15 +79,43 @@ def main():
             r["tb_s"] = round(by / (t * 1e-3) / 1e12, 2)
             r["frac_of_6.3TBs"] = round(by / (t * 1e-3) / 1e12 / 6.3, 3)
         rows.append(r)
+    # the same forward replayed from ONE HIP graph: what the launch gaps between ~150 short kernels cost
+    graph_ms = None
+    try:
+        side_s = torch.cuda.Stream()
+        side_s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side_s):
+            step()
+        torch.cuda.current_stream().wait_stream(side_s)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            gout = step()
+        for _ in range(3):
+            gr.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            gr.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        graph_ms = e0.elapsed_time(e1) / steps
+        graph_same = bool(torch.equal(gout, step()))
+    except Exception as exc:      # a report, not the measurement
+        graph_ms, graph_same = None, f"{type(exc).__name__}: {exc}"
     gates = [m for m in model.modules() if isinstance(m, sm.Gate)]
     out = {"model": name, "batch": batch, "ms_per_step_median": round(med, 3), "min_max": [round(ms[0], 3), round(ms[-1], 3)],
            "images_per_s": round(batch / med * 1e3, 1),
+           "hip_graph_replay_ms_per_step": None if graph_ms is None else round(graph_ms, 3), "hip_graph_replay_equals_eager": graph_same,
            "timed_kernel_ms_per_step": round(sum(r["ms_per_step"] for r in rows), 3),
            "skipped_token_fraction": (round(sum(gt._skipped_tokens for gt in gates) / max(1, sum(gt._total_tokens for gt in gates)), 3)
                                       if gates else None),
            "kernels": rows}
     print(json.dumps(out))
-    print(f"\n{name}, batch {batch}: {med:.3f} ms per eval forward = {batch / med * 1e3:.0f} images/s", file=sys.stderr)
+    print(f"\n{name}, batch {batch}: {med:.3f} ms per eval forward = {batch / med * 1e3:.0f} images/s"
+          + (f"; replayed from one HIP graph {graph_ms:.3f} ms = {batch / graph_ms * 1e3:.0f} images/s (same bits: {graph_same})"
+             if graph_ms else f"; HIP graph: {graph_same}"), file=sys.stderr)
     for r in rows:
         print(f"  {r['kernel']:44s} x{r['launches_per_step']:5.1f}  {r['avg_us']:8.1f} us  {r['ms_per_step']:7.3f} ms/step  "
               + (f"{r['tflops']:7.1f} TF/s ({r['frac_of_2.5PF']:.3f})" if "tflops" in r else "")
