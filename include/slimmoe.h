@@ -302,7 +302,9 @@ int smoe_grouped_gemm(const void* A, const void* W, const float* bias, const int
                       const void* residual, const int64_t* a_gather, int a_div,
                       void* out, int64_t out_rows, int out_dtype, int variant, const int32_t* group_end, void* stream);
 
-/* smoe_expert_ffn: the whole expert FFN of one MoE layer with the top-1 combine -- fmoe_cuda.linear_forward x 2 with the activation
+/* OPTIONAL -- only in a library built with `make FFN=-DSMOE_FFN_FUSED` (it measured slower than the two smoe_grouped_gemm launches in
+ * every scheduler design, profiles/r04_fused_ffn.md, and left the default build in round 5; bit-identical to them).
+ * smoe_expert_ffn: the whole expert FFN of one MoE layer with the top-1 combine -- fmoe_cuda.linear_forward x 2 with the activation
  * between them, MOEGather and the combine (models/resMoE.py:143 -> FastMoE `_Expert.forward`) -- as ONE persistent
  * launch:   H[r]   = gelu(X[a_gather[r] / a_div] W1[e]^T + b1[e])                      (16-bit, [m_rows_max, d_hidden]; caller's buffer)
  *           out[row_map[r]] = residual[row_map[r]] + row_scale[row_map[r]] (H[r] W2[e]^T + b2[e])       (f32, [out_rows, d_out])

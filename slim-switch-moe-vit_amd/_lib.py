@@ -123,6 +123,9 @@ SIGNATURES = {
                                      c_void_p]),
 }
 
+# entry points that only an optional build holds (`make FFN=-DSMOE_FFN_FUSED`): bound when present, never required
+OPTIONAL = {"smoe_expert_ffn_workspace_bytes", "smoe_expert_ffn"}
+
 _lib = None
 
 # what csrc/Makefile hashes into smoe_build_id(): the same names, sorted as strings, relative to csrc/
@@ -133,6 +136,16 @@ _HASHED = ["api.hip", "router.hip", "router16.hip", "gate.hip", "dispatch.hip", 
 
 class SlimMoEError(RuntimeError):
     pass
+
+
+def has_symbol(name: str) -> bool:
+    """Whether the loaded library exports an OPTIONAL entry point."""
+    lib = load()
+    try:
+        getattr(lib, name)
+        return True
+    except AttributeError:
+        return False
 
 
 def source_build_id(extra_flags: str = "") -> str:
@@ -151,7 +164,7 @@ def source_build_id(extra_flags: str = "") -> str:
         mk = open(os.path.join(csrc, "Makefile")).read()
         flags = re.search(r"^CXXFLAGS\s*=\s*(.*)$", mk, re.M).group(1)
         arch = re.search(r"^ARCH\s*\?=\s*(\S+)", mk, re.M).group(1)
-        flags = flags.replace("$(ARCH)", arch).replace("$(DIAG)", "")
+        flags = flags.replace("$(ARCH)", arch).replace("$(DIAG)", "").replace("$(FFN)", "")
         h.update((" ".join(flags.split()) + extra_flags + "\n").encode())
     except (OSError, AttributeError):
         return None
@@ -177,6 +190,8 @@ def load():
         try:
             fn = getattr(lib, name)
         except AttributeError as exc:
+            if name in OPTIONAL:
+                continue
             raise SlimMoEError(f"{LIB_PATH} does not export {name}") from exc
         fn.restype = res
         fn.argtypes = args

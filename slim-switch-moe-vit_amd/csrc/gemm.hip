@@ -1427,6 +1427,7 @@ extern "C" int smoe_grouped_gemm(const void* A, const void* W, const float* bias
   return 1;
 }
 
+#ifdef SMOE_FFN_FUSED
 // The expert FFN of one MoE layer (top-1 combine fused) as ONE persistent launch: see expert_ffn_fused in gemm_persistent.h.
 // Returns -1 (no error set) for what that launch does not cover -- the caller then issues the two smoe_grouped_gemm launches.
 extern "C" size_t smoe_expert_ffn_workspace_bytes(int64_t m_rows_max, int G) {
@@ -1477,6 +1478,8 @@ extern "C" int smoe_expert_ffn(const void* X, const int64_t* a_gather, int a_div
   SMOE_CHECK_LAUNCH("smoe_expert_ffn");
   return 0;
 }
+
+#endif  // SMOE_FFN_FUSED
 
 // First expert linear of the TRAINING forward: pre_out = A W^T + bias (kept for gelu' in the backward) and out = gelu(pre_out),
 // both in the operand dtype, from one epilogue of the persistent kernel.  Returns -1 when the shape is outside that kernel's

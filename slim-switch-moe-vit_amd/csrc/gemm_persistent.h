@@ -996,6 +996,8 @@ __device__ __forceinline__ FusedPlan fused_plan(int cnt, int ntn1, int ntn2, int
   return p;
 }
 
+#ifdef SMOE_FFN_FUSED   // the fused GEMM-1 + GEMM-2 launch: measured slower than the two launches (profiles/r04_fused_ffn.md); not in the
+                        // default build since round 5 -- `make FFN=-DSMOE_FFN_FUSED` compiles it (and smoe_expert_ffn) back in
 template <typename AB>
 __global__ __launch_bounds__(512, 2) void expert_ffn_fused(
     const AB* __restrict__ X, const int64_t* __restrict__ a_gather, int a_div, int gather_len, const AB* __restrict__ W1,
@@ -1096,6 +1098,8 @@ __global__ __launch_bounds__(512, 2) void expert_ffn_fused(
       if (i != FUSED_WS_ERR) __hip_atomic_store(ws + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the error word stays)
   }
 }
+
+#endif  // SMOE_FFN_FUSED
 
 template <typename AB, typename OT, int AFR, bool DEEP, bool KEEP = false>
 int launch_ps(const void* A, const void* W, const float* bias, const int32_t* offsets, const int32_t* group_expert, int E,

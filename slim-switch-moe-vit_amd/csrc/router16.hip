@@ -69,8 +69,80 @@ __global__ __launch_bounds__(R16_THREADS, 4) void layernorm16_kernel(const XT* _
   }
 }
 
+// LayerNorm alone, ONE WAVE PER ROW (lane l holds the elements [8 l + 512 i, 8 l + 512 i + 8) of the row: whole 32-byte pieces,
+// two-pass statistics over the wave).  Same arithmetic order inside a lane's pieces as the 16-lanes-per-token kernel? No -- the
+// reduction tree differs, so the two kernels agree to f32 rounding, not bit for bit; a shape uses ONE of them, always (below).
+// At d = 1024 the 16-lane layout holds 64 row elements per lane and reaches 3.1 TB/s (cfg 4's model: 72.6 us for 227 MB,
+// profiles/r05_cfg4_kernel_stats.csv); a wave per row holds 16.
+template <typename XT, int NI, typename OT>
+__global__ __launch_bounds__(256) void layernorm_wave_kernel(const XT* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ b, float eps, int64_t T, int d,
+                                                             OT* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const float inv_d = 1.0f / (float)d;
+  for (int64_t t = wave_gid; t < T; t += nwaves) {
+    float v[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 8 + 512 * i;
+      if (c < d) load8(x + t * (int64_t)d + c, v[i]);
+      else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[i][q] = 0.f;
+      }
+    }
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s1 += v[i][q];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s1 += __shfl_xor(s1, m, 64);
+    const float mean = s1 * inv_d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (lane * 8 + 512 * i < d) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float dv = v[i][q] - mean; s2 = fmaf(dv, dv, s2); }
+      }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
+    const float rstd = rsqrtf(s2 * inv_d + eps);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 8 + 512 * i;
+      if (c < d) {
+        float gg[8], bb[8], o[8];
+        if (g) load8(g + c, gg);
+        if (b) load8(b + c, bb);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = fmaf((v[i][q] - mean) * rstd, g ? gg[q] : 1.f, b ? bb[q] : 0.f);
+        store8(out + t * (int64_t)d + c, o);
+      }
+    }
+  }
+}
+
+inline bool ln_wave_layout(int d) {
+  // which layout serves a width: measured on MI355X (tools/ln_ab.py, profiles/r05_cfg4.md); SMOE_LN_WAVE=0 / 1 forces one (A/B)
+  static const int forced = [] { const char* e = getenv("SMOE_LN_WAVE"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced != 0;
+  return d >= 768;    // in the model: d 768 48.5 -> 44.0 us, d 1024 74.8 -> 39.1 us; d 384 / 192 stay (38.4 vs 39.5 us, 12.9 vs 16.4)
+}
+
 template <typename XT, typename OT>
 int ln_dispatch_nj(const void* x, const float* g, const float* b, float eps, int64_t T, int d, void* out, hipStream_t s) {
+  if (ln_wave_layout(d) && d % 8 == 0 && d <= 1024) {
+    int64_t blocks = (T + 3) / 4;
+    const int wg = (int)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks));
+    if (d <= 512) hipLaunchKernelGGL((layernorm_wave_kernel<XT, 1, OT>), dim3(wg), dim3(256), 0, s, (const XT*)x, g, b, eps, T, d, (OT*)out);
+    else hipLaunchKernelGGL((layernorm_wave_kernel<XT, 2, OT>), dim3(wg), dim3(256), 0, s, (const XT*)x, g, b, eps, T, d, (OT*)out);
+    SMOE_CHECK_LAUNCH("smoe_layernorm/wave");
+    return 0;
+  }
   // one 16-token group per workgroup (no loop): the dispatcher back-fills CUs as groups retire, so there is no
   // 1-vs-2-iteration imbalance between resident workgroups
   int64_t need = (T + 15) / 16;

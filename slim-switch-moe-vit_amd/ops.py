@@ -785,7 +785,12 @@ def grouped_gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor],
 # and OFF by default: measured 0.530-0.545 ms against 0.50-0.51 ms for the two launches at ViT-B / 256 images -- what the shared
 # tile list saves in partly filled rounds (~30 us) goes into the switches between the two GEMM bodies, the write-through stores
 # of H and the waits on late m-tiles (profiles/r04_fused_ffn.md).
+# Since round 5 the launch is not in the default build: `make -C slim-switch-moe-vit_amd/csrc FFN=-DSMOE_FFN_FUSED` compiles it back in.
 FFN_FUSED = _os.environ.get("SLIMMOE_FFN_FUSED", "0") == "1"
+
+
+def ffn_fused_available() -> bool:
+    return _lib.has_symbol("smoe_expert_ffn")
 _ffn_ws = {}   # (device index, stream) -> the fused launch's kept-zero workspace
 
 
@@ -848,6 +853,9 @@ def expert_ffn(X: torch.Tensor, W1: torch.Tensor, b1: Optional[torch.Tensor], W2
             raise RuntimeError("residual: expected the shape of out")
     if X.dtype not in (torch.float16, torch.bfloat16) or M == 0:
         return None
+    if not ffn_fused_available():
+        raise _lib.SlimMoEError("smoe_expert_ffn is not in this build of libslimmoe_hip.so (it measured slower than the two launches and "
+                                "left the default build in round 5): make -C slim-switch-moe-vit_amd/csrc FFN=-DSMOE_FFN_FUSED")
     if H is None:
         H = torch.empty((M, h), dtype=X.dtype, device=X.device)
     else:

@@ -6,10 +6,13 @@ experts, one hot expert, fewer tiles than CUs, dropped tokens), repeated launche
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
-
 import slim_switch_moe_vit_amd as sm  # noqa: E402
 from slim_switch_moe_vit_amd import ops  # noqa: E402
+
+# the fused launch left the default build in round 5 (slower than the two launches in every design): these tests run against a
+# library made with `make -C slim-switch-moe-vit_amd/csrc FFN=-DSMOE_FFN_FUSED` (SLIMMOE_LIB may point at it)
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ops.ffn_fused_available(),
+                                                  reason="smoe_expert_ffn is not in this build (make FFN=-DSMOE_FFN_FUSED)")]
 
 DEV = "cuda:0"
 

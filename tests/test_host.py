@@ -27,6 +27,8 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 21
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for s in syms:
+        if s in _lib.OPTIONAL:      # (declared, but only an optional build holds them: `make FFN=-DSMOE_FFN_FUSED`)
+            continue
         assert hasattr(lib, s), f"libslimmoe_hip.so does not export {s}"
     assert set(syms) == set(_lib.SIGNATURES), "ctypes signature table out of sync with include/slimmoe.h"
 
