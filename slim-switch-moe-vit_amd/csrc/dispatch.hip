@@ -343,7 +343,6 @@ __global__ __launch_bounds__(256) void gather_combine_ln_kernel(const YT* __rest
   const int lane = threadIdx.x & 63;
   const int64_t wave_gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const float inv_d = 1.0f / (float)d;
   for (int64_t t = wave_gid; t < T; t += nwaves) {
     int64_t slot[KMAX];
     float sc[KMAX];
@@ -377,24 +376,8 @@ __global__ __launch_bounds__(256) void gather_combine_ln_kernel(const YT* __rest
         store8(out + t * (int64_t)d + c, acc[it]);
       }
     }
-    float s1 = 0.f;
-#pragma unroll
-    for (int it = 0; it < NJ; ++it)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) s1 += acc[it][q];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s1 += __shfl_xor(s1, m, 64);
-    const float mean = s1 * inv_d;
-    float s2 = 0.f;
-#pragma unroll
-    for (int it = 0; it < NJ; ++it)
-      if (lane * 8 + 512 * it < d) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { const float dv = acc[it][q] - mean; s2 = fmaf(dv, dv, s2); }
-      }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
-    const float rstd = rsqrtf(s2 * inv_d + eps);
+    float mean, rstd;      // (smoe_common.h: THE wave-per-row LayerNorm arithmetic -- the bits of smoe_layernorm at d >= 768)
+    wave_row_stats<NJ>(acc, d, lane, eps, mean, rstd);
 #pragma unroll
     for (int it = 0; it < NJ; ++it) {
       const int c = lane * 8 + 512 * it;
@@ -403,7 +386,7 @@ __global__ __launch_bounds__(256) void gather_combine_ln_kernel(const YT* __rest
         load8(gamma + c, g);
         load8(beta + c, b);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = fmaf((acc[it][q] - mean) * rstd, g[q], b[q]);
+        for (int q = 0; q < 8; ++q) o[q] = wave_row_affine(acc[it][q], mean, rstd, g[q], b[q]);
         store8(xn + t * (int64_t)d + c, o);
       }
     }

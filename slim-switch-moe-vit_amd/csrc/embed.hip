@@ -102,6 +102,91 @@ __global__ __launch_bounds__(R16_THREADS, 3) void embed_ln_kernel(const TT* __re
   }
 }
 
+// The same pass with ONE WAVE PER ROW (d >= 768, where smoe_layernorm runs that layout: smoe_common.h smoe_ln_wave_layout) -- lane l
+// holds the elements [8 l + 512 i, +8) of its row; the LayerNorm is wave_row_stats, operation for operation smoe_layernorm's.
+template <typename TT, typename NT, int NI>
+__global__ __launch_bounds__(256) void embed_ln_wave_kernel(const TT* __restrict__ tok, const float* __restrict__ cls,
+                                                            const float* __restrict__ pos, const float* __restrict__ g,
+                                                            const float* __restrict__ be, float eps, int64_t B, int P, int d,
+                                                            float* __restrict__ x32, NT* __restrict__ xn) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t T = B * (int64_t)(P + 1);
+  for (int64_t t = wave_gid; t < T; t += nwaves) {
+    const int64_t b = t / (P + 1);
+    const int n = (int)(t - b * (P + 1));
+    float v[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 8 + 512 * i;
+      if (c < d) {
+        float a[8], pe[8];
+        if (n == 0) load8(cls + c, a);
+        else load8(tok + (b * P + (n - 1)) * (int64_t)d + c, a);
+        load8(pos + (int64_t)n * d + c, pe);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[i][q] = a[q] + pe[q];
+        store8(x32 + t * (int64_t)d + c, v[i]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[i][q] = 0.f;
+      }
+    }
+    if (xn) {
+      float mean, rstd;
+      wave_row_stats<NI>(v, d, lane, eps, mean, rstd);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = lane * 8 + 512 * i;
+        if (c < d) {
+          float gg[8], bb[8], o[8];
+          if (g) load8(g + c, gg);
+          if (be) load8(be + c, bb);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = wave_row_affine(v[i][q], mean, rstd, g ? gg[q] : 1.f, be ? bb[q] : 0.f);
+          store8(xn + t * (int64_t)d + c, o);
+        }
+      }
+    }
+  }
+}
+
+template <int NI>
+__global__ __launch_bounds__(256) void layernorm_rows_wave_kernel(const float* __restrict__ x, int64_t row_stride,
+                                                                  const float* __restrict__ g, const float* __restrict__ be, float eps,
+                                                                  int64_t T, int d, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t t = wave_gid; t < T; t += nwaves) {
+    float v[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 8 + 512 * i;
+      if (c < d) load8(x + t * row_stride + c, v[i]);
+      else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[i][q] = 0.f;
+      }
+    }
+    float mean, rstd;
+    wave_row_stats<NI>(v, d, lane, eps, mean, rstd);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 8 + 512 * i;
+      if (c < d) {
+        float gg[8], bb[8], o[8];
+        if (g) load8(g + c, gg);
+        if (be) load8(be + c, bb);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = wave_row_affine(v[i][q], mean, rstd, g ? gg[q] : 1.f, be ? bb[q] : 0.f);
+        store8(out + t * (int64_t)d + c, o);
+      }
+    }
+  }
+}
+
 // LayerNorm of T rows that start row_stride elements apart (f32 in, f32 out, contiguous [T, d] out)
 template <int NJ>
 __global__ __launch_bounds__(R16_THREADS, 2) void layernorm_rows_kernel(const float* __restrict__ x, int64_t row_stride,
@@ -203,6 +288,17 @@ extern "C" int smoe_embed_ln(const void* tokens, int tok_dtype, const float* cls
   SMOE_REQUIRE(tok_dtype == SMOE_F16 || tok_dtype == SMOE_BF16, "smoe_embed_ln: tokens must be f16 or bf16");
   SMOE_REQUIRE(!xn || xn_dtype == SMOE_F16 || xn_dtype == SMOE_BF16, "smoe_embed_ln: xn must be f16 or bf16");
   hipStream_t s = (hipStream_t)stream;
+  if (smoe_ln_wave_layout(d) && d > 512 && d <= 1024 && d % 8 == 0) {   // the layout smoe_layernorm uses at this width: the same bits
+    const int64_t rows = B * (int64_t)(P + 1), blocks = (rows + 3) / 4;
+    const int wg = (int)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks));
+    const bool xb = xn && xn_dtype == SMOE_BF16;
+#define ELW(TT, NT) hipLaunchKernelGGL((embed_ln_wave_kernel<TT, NT, 2>), dim3(wg), dim3(256), 0, s, (const TT*)tokens, cls_token, pos_embed, ln_gamma, ln_beta, ln_eps, B, P, d, x32, (NT*)xn)
+    if (tok_dtype == SMOE_F16) { if (xb) ELW(f16, bf16_bits); else ELW(f16, f16); }
+    else { if (xb) ELW(bf16_bits, bf16_bits); else ELW(bf16_bits, f16); }
+#undef ELW
+    SMOE_CHECK_LAUNCH("smoe_embed_ln/wave");
+    return 0;
+  }
   const int grid = rows_grid16(B * (int64_t)(P + 1));
 #define EL(TT, NT, NJ) hipLaunchKernelGGL((embed_ln_kernel<TT, NT, NJ>), dim3(grid), dim3(R16_THREADS), 0, s, (const TT*)tokens, cls_token, pos_embed, ln_gamma, ln_beta, ln_eps, B, P, x32, (NT*)xn)
 #define EL_D(TT, NT)                                                  \
@@ -228,6 +324,13 @@ extern "C" int smoe_layernorm_rows(const float* x, int64_t row_stride, const flo
   if (T == 0) return 0;
   SMOE_REQUIRE(x && out, "smoe_layernorm_rows: null pointer");
   hipStream_t s = (hipStream_t)stream;
+  if (smoe_ln_wave_layout(d) && d > 512 && row_stride % 8 == 0) {
+    const int64_t blocks = (T + 3) / 4;
+    const int wg = (int)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks));
+    hipLaunchKernelGGL((layernorm_rows_wave_kernel<2>), dim3(wg), dim3(256), 0, s, x, row_stride, gamma, beta, eps, T, d, out);
+    SMOE_CHECK_LAUNCH("smoe_layernorm_rows/wave");
+    return 0;
+  }
   const int grid = rows_grid16(T);
 #define LR(NJ) hipLaunchKernelGGL((layernorm_rows_kernel<NJ>), dim3(grid), dim3(R16_THREADS), 0, s, x, row_stride, gamma, beta, eps, T, out)
   switch (d) {

@@ -81,7 +81,6 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(const XT* __restric
   const int lane = threadIdx.x & 63;
   const int64_t wave_gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  const float inv_d = 1.0f / (float)d;
   for (int64_t t = wave_gid; t < T; t += nwaves) {
     float v[NI][8];
 #pragma unroll
@@ -93,24 +92,8 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(const XT* __restric
         for (int q = 0; q < 8; ++q) v[i][q] = 0.f;
       }
     }
-    float s1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) s1 += v[i][q];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s1 += __shfl_xor(s1, m, 64);
-    const float mean = s1 * inv_d;
-    float s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-      if (lane * 8 + 512 * i < d) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { const float dv = v[i][q] - mean; s2 = fmaf(dv, dv, s2); }
-      }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
-    const float rstd = rsqrtf(s2 * inv_d + eps);
+    float mean, rstd;
+    wave_row_stats<NI>(v, d, lane, eps, mean, rstd);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = lane * 8 + 512 * i;
@@ -119,23 +102,16 @@ __global__ __launch_bounds__(256) void layernorm_wave_kernel(const XT* __restric
         if (g) load8(g + c, gg);
         if (b) load8(b + c, bb);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = fmaf((v[i][q] - mean) * rstd, g ? gg[q] : 1.f, b ? bb[q] : 0.f);
+        for (int q = 0; q < 8; ++q) o[q] = wave_row_affine(v[i][q], mean, rstd, g ? gg[q] : 1.f, b ? bb[q] : 0.f);
         store8(out + t * (int64_t)d + c, o);
       }
     }
   }
 }
 
-inline bool ln_wave_layout(int d) {
-  // which layout serves a width: measured on MI355X (tools/ln_ab.py, profiles/r05_cfg4.md); SMOE_LN_WAVE=0 / 1 forces one (A/B)
-  static const int forced = [] { const char* e = getenv("SMOE_LN_WAVE"); return e ? atoi(e) : -1; }();
-  if (forced >= 0) return forced != 0;
-  return d >= 768;    // in the model: d 768 48.5 -> 44.0 us, d 1024 74.8 -> 39.1 us; d 384 / 192 stay (38.4 vs 39.5 us, 12.9 vs 16.4)
-}
-
 template <typename XT, typename OT>
 int ln_dispatch_nj(const void* x, const float* g, const float* b, float eps, int64_t T, int d, void* out, hipStream_t s) {
-  if (ln_wave_layout(d) && d % 8 == 0 && d <= 1024) {
+  if (smoe_ln_wave_layout(d) && d % 8 == 0 && d <= 1024) {
     int64_t blocks = (T + 3) / 4;
     const int wg = (int)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks));
     if (d <= 512) hipLaunchKernelGGL((layernorm_wave_kernel<XT, 1, OT>), dim3(wg), dim3(256), 0, s, (const XT*)x, g, b, eps, T, d, (OT*)out);

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libslimmoe_hip.so (gfx950 only; wave = 64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -142,4 +143,49 @@ static inline bool smoe_dtype_ok(int code) { return code == SMOE_F32 || code == 
 __device__ __forceinline__ void list_push(int32_t* count, int32_t* list, int64_t cap, int64_t t) {
   const int32_t slot = atomicAdd(count, 1);
   if (slot >= 0 && (int64_t)slot < cap) list[slot] = (int32_t)t;
+}
+
+// ---- LayerNorm of one row held by ONE WAVE -----------------------------------------------------------------------------------
+// Lane l holds v[i][0..8) = the row's elements [8 l + 512 i, 8 l + 512 i + 8) (zeros past d).  THE arithmetic of every wave-per-row
+// LayerNorm of the library -- smoe_layernorm / smoe_embed_ln / smoe_layernorm_rows at d >= 768, smoe_gather_combine_ln at every d --
+// so that each of them produces the same bits for the same row (tests/test_gpu_dense.py).  Two passes in registers.
+template <int NI>
+__device__ __forceinline__ void wave_row_stats(const float (&v)[NI][8], int d, int lane, float eps, float& mean, float& rstd) {
+  const float inv_d = 1.0f / (float)d;
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s1 += v[i][q];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s1 += __shfl_xor(s1, m, 64);
+  mean = s1 * inv_d;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (lane * 8 + 512 * i < d) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const float dv = v[i][q] - mean; s2 = fmaf(dv, dv, s2); }
+    }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s2 += __shfl_xor(s2, m, 64);
+  rstd = rsqrtf(s2 * inv_d + eps);
+}
+
+// ... and the affine output of one element.  The f32 value is the result: the empty asm keeps the compiler from fusing the FMA with a
+// following f32 -> f16 conversion (v_fma_mixlo / mixhi_f16 round ONCE; a kernel whose store converts in an instruction of its own
+// rounds TWICE -- the two differ in ~1 of 2^13 elements, which is how smoe_gather_combine_ln and smoe_layernorm disagreed at first).
+__device__ __forceinline__ float wave_row_affine(float v, float mean, float rstd, float g, float b) {
+  float o = fmaf((v - mean) * rstd, g, b);
+  asm volatile("" : "+v"(o));
+  return o;
+}
+
+// which LayerNorm layout serves a width (one answer per width for EVERY kernel that promises smoe_layernorm's bits): a wave per row
+// from d = 768 up (in the model: d 768 48.5 -> 44.0 us, d 1024 74.8 -> 39.1 us per launch), 16 lanes per token below (d 384: 38.4
+// vs 39.5 us, d 192: 12.9 vs 16.4).  SMOE_LN_WAVE=0 / 1 forces one (A/B, tools/ln_ab.py).
+inline bool smoe_ln_wave_layout(int d) {
+  static const int forced = [] { const char* e = getenv("SMOE_LN_WAVE"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced != 0;
+  return d >= 768;
 }

@@ -247,3 +247,22 @@ def test_embedding_stage_kernels_equal_the_torch_composition(B, C, size, patch, 
     assert none is None and torch.equal(x_only, want)
     rows = ops.layernorm_rows(want, (P + 1) * d, B, d, w, b, 1e-6)
     assert torch.equal(rows, ops.layernorm(want[:, 0].contiguous(), w, b, 1e-6, torch.float32))
+
+
+@pytest.mark.parametrize("d", [768, 1024])
+def test_wave_per_row_layernorms_share_their_bits(d):
+    """From d = 768 up smoe_layernorm runs one wave per row (csrc/smoe_common.h wave_row_stats), the arithmetic smoe_gather_combine_ln
+    has always had: the combine's fused "next norm1" is now BIT FOR BIT the LayerNorm a separate launch computes of the same row (the
+    expert-parallel return path and the single-rank path hand attention the same bits), as are smoe_embed_ln's and
+    smoe_layernorm_rows' (test_embedding_stage_kernels_equal_the_torch_composition)."""
+    g = _gen(d)
+    T = 1000
+    x = torch.randn(T, d, generator=g).to(DEV)
+    y = torch.randn(T, d, generator=g).half().to(DEV)
+    w, b = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
+    inv = torch.randperm(T, generator=g).to(DEV)
+    score = torch.rand(T, generator=g).to(DEV)
+    out, xn = ops.gather_combine_ln(y, inv, score, T, 1, x, w, b, 1e-6, torch.float16)
+    want = ops.gather_combine(y, inv, score, T, 1, torch.float32, residual=x)
+    assert torch.equal(out, want)
+    assert torch.equal(xn, ops.layernorm(want, w, b, 1e-6, torch.float16))
