@@ -307,13 +307,21 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # per-step times (median reported)
     t0 = time.perf_counter()
     marks[0].record()
+    ep_overflow_in_timed_region = False
     for i in range(args.steps):
-        step()
+        if ep_static:
+            try:
+                step()
+            except _ep.StaticExchangeOverflow:      # raised by every rank at the same exchange (the deferred watch inside the forward):
+                ep_overflow_in_timed_region = True  # the step is repeated on the counted exchange INSIDE the timed region, and the
+                with _ep.dynamic_only():            # line says so (it cannot happen with one fixed batch whose routing fitted in warm-up)
+                    step()
+        else:
+            step()
         marks[i + 1].record()
     fence()
     elapsed = time.perf_counter() - t0
     prof = ops.profile_end()
-    ep_overflow_in_timed_region = False
     if ep_static:
         try:     # the timed steps ran without reading their overflow reports (no host sync): read them now
             _ep.check_static_overflow(flush=True)
@@ -367,7 +375,11 @@ def main():
         ep_info["exchange"] = ("speculative static (fixed slots, counts in-band, no host round trip per layer)" if ep_static
                                else "counted (count read-back + all-to-all-v per layer)")
         if ep_static:
-            ep_info["speculative_alpha_per_layer"] = [round(float(m.ep_speculative), 3) for m in moes]
+            ep_info["speculative_alpha_first_table"] = args.ep_alpha
+            div = max(1, int(model.ep_micro_batches))
+            rows_mb = -(-args.batch // div) * 197       # routed rows of one (micro-)batch: top-1
+            ep_info["send_buffer_rows_over_routed_rows_per_layer"] = [
+                round(m.__dict__["_ep_slots"][div].table.rows / rows_mb, 3) if div in m.__dict__.get("_ep_slots", {}) else None for m in moes]
             ep_info["steps_repeated_on_the_counted_exchange_during_warmup"] = ep_repeats
             ep_info["overflow_in_timed_region"] = ep_overflow_in_timed_region
 
