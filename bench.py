@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--ep-alpha", type=float, default=1.25,
                     help="speculative slot size as a multiple of the balanced share rows * k / E (raised automatically during warm-up "
                          "to 1.1 x the largest group a step needed)")
+    ap.add_argument("--ep-reserve-cus", type=int, default=-1,
+                    help="expert parallel only: CUs the persistent expert GEMM leaves free (ops.set_reserved_cus) so that RCCL's all-to-all "
+                         "of one micro-batch can run BESIDE the other micro-batch's GEMMs (the persistent kernel otherwise owns every CU "
+                         "for the whole launch); -1 = time 0 and 16 for every pipelined configuration during warm-up")
     ap.add_argument("--cpu-batch", type=int, default=128, help="images in the CPU-oracle sample")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget: 5 timed forwards if they fit ~2x this, else 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -261,9 +265,13 @@ def main():
         mbs = (1, 2, 3) if args.ep_micro_batches == 0 else (args.ep_micro_batches,)
         chs = (1, 2, 3) if args.ep_chunks == 0 else (args.ep_chunks,)
         statics = {"auto": (False, True), "0": (False,), "1": (True,)}[args.ep_static]
-        grid = [(st, n, c) for st in statics for n in mbs for c in (chs if not st else (1,)) if n * c <= 4]
-        for st, n, c in grid if len(grid) > 1 else []:
+        # ... x CUs the persistent GEMM leaves free: only where there is something to run beside it (a pipelined configuration)
+        reserves = (0, 16) if args.ep_reserve_cus < 0 else (args.ep_reserve_cus,)
+        grid = [(st, n, c, r) for st in statics for n in mbs for c in (chs if not st else (1,)) if n * c <= 4
+                for r in (reserves if n * c > 1 else reserves[:1] if args.ep_reserve_cus >= 0 else (0,))]
+        for st, n, c, r in grid if len(grid) > 1 else []:
             _ep.set_speculative(model, args.ep_alpha if st else None)
+            ops.set_reserved_cus(r)
             model.ep_micro_batches = n
             for m in moes:
                 m.ep_chunks = c
@@ -282,13 +290,19 @@ def main():
             t = torch.tensor([(time.perf_counter() - t0) / 3 if ok else 1e9], dtype=torch.float64, device=device)
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ep_tuning[("static " if st else "") + f"{n}x{c}"] = round(float(t.item()) * 1e3, 3)
+            ep_tuning[("static " if st else "") + f"{n}x{c}" + (f" reserve {r}" if r else "")] = round(float(t.item()) * 1e3, 3)
+        ep_reserve = 0
         if ep_tuning:
             best = min(ep_tuning, key=ep_tuning.get)
             ep_static = best.startswith("static ")
-            args.ep_micro_batches, args.ep_chunks = (int(v) for v in best.replace("static ", "").split("x"))
+            core = best.replace("static ", "")
+            if " reserve " in core:
+                core, rs = core.split(" reserve ")
+                ep_reserve = int(rs)
+            args.ep_micro_batches, args.ep_chunks = (int(v) for v in core.split("x"))
         else:
-            ep_static, args.ep_micro_batches, args.ep_chunks = grid[0]
+            ep_static, args.ep_micro_batches, args.ep_chunks, ep_reserve = grid[0]
+        ops.set_reserved_cus(ep_reserve)
         _ep.set_speculative(model, args.ep_alpha if ep_static else None)
         model.ep_micro_batches = args.ep_micro_batches
         for m in moes:
@@ -372,6 +386,7 @@ def main():
         ep_info = {"micro_batches": args.ep_micro_batches, "chunks_per_layer": args.ep_chunks,
                    "pipeline_tuning_ms_per_step (micro-batches x chunks)": ep_tuning}
     if ep_info is not None:
+        ep_info["cus_left_free_by_the_persistent_gemm"] = ep_reserve
         ep_info["exchange"] = ("speculative static (fixed slots, counts in-band, no host round trip per layer)" if ep_static
                                else "counted (count read-back + all-to-all-v per layer)")
         if ep_static:

@@ -36,6 +36,12 @@ enum { SMOE_F32 = 0, SMOE_F16 = 1, SMOE_BF16 = 2 };
 enum { SMOE_GATE_NAIVE = 0, SMOE_GATE_SWITCH = 1 };
 enum { SMOE_EPI_NONE = 0, SMOE_EPI_GELU = 1, SMOE_EPI_GELU_GRAD = 2 };
 
+/* smoe_set_reserved_cus(n): the persistent grouped GEMM (variants 9-14: one workgroup per CU for the whole launch, with all of the
+ * CU's LDS and registers) leaves n CUs free from now on (process-wide; 0 <= n <= 128; default 0).  A kernel on ANOTHER stream cannot
+ * share a CU with it, so RCCL's all-to-all under the expert-parallel micro-batch pipeline ("overlapped with the
+ * local GEMM on a second HIP stream") only overlaps the GEMMs if some CUs are left to it; results do not depend on n. */
+int smoe_set_reserved_cus(int n);
+
 /* library ABI version (bumped on any signature change) */
 int smoe_abi_version(void);
 /* first 16 hex digits of the sha256 over the sources this binary was built from (csrc/Makefile HASHED): lets the loader
@@ -344,6 +350,11 @@ int smoe_gelu(const void* src, void* dst, int dtype, int64_t n, void* stream);
 int smoe_rowdot(const void* dout, int dout_dtype, const void* y, int y_dtype, const int64_t* inv_pos,
                 int64_t n, int k, int d, float* dscore, void* stream);
 int smoe_pad_offsets(const int32_t* offsets, int E, int32_t* offsets_pad, void* stream);
+/* smoe_split_offsets: every row group [offsets[g], offsets[g + 1]) cut into S pseudo-groups of whole 64-row chunks (the last ones may be
+ * empty): out i32 [G * S + 1].  smoe_grouped_wgrad_rows' grid is groups x output tiles, so a weight gradient over few long groups
+ * (fmoe_cuda.linear_backward's grad_W at DeiT-Tiny's dims: 24 tiles) is computed as S partial products per expert, summed in piece
+ * order by the caller (deterministic). */
+int smoe_split_offsets(const int32_t* offsets, int G, int S, int32_t* out, void* stream);
 int smoe_transpose_pad(const void* src, int dtype, const int32_t* offsets, const int32_t* offsets_pad, int E,
                        int64_t n_rows, int C, int Lp, void* dst, void* stream);
 /* smoe_switch_gate_bwd: gradient of the SwitchGate's score and load-balance loss w.r.t. the router logits (fmoe.gates.SwitchGate:

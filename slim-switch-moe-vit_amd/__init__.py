@@ -6,7 +6,7 @@ from .fmoe import (FMoETransformerMLP, FMoELinear, NaiveGate, SwitchGate, fastmo
 from .vit import (Block, VisionTransformer, create_model, register_model, list_models,  # noqa: F401
                   deit_tiny_patch16_224, deit_base_patch16_224)
 from .resmoe import *  # noqa: F401,F403
-from .engine import evaluate, accuracy, train_one_epoch, GraphedForward  # noqa: F401
+from .engine import evaluate, accuracy, train_one_epoch, GraphedForward, GraphedTrainStep  # noqa: F401
 from .optim import AdamW, NativeScaler, invalidate_weight_images  # noqa: F401
 
 __version__ = "0.1.0"

@@ -33,9 +33,10 @@ class StreamCache:
             ev = sid = None
             if t.is_cuda:
                 st = torch.cuda.current_stream(t.device)
-                ev = torch.cuda.Event()
-                ev.record(st)
                 sid = st.cuda_stream
+                if not torch.cuda.is_current_stream_capturing():   # (inside a HIP-graph capture everything is on the capturing
+                    ev = torch.cuda.Event()                        #  stream; an event recorded there could not be waited for outside)
+                    ev.record(st)
             hit = (version, t, ev, sid)
             self._c[key] = hit
             return t
@@ -65,9 +66,10 @@ class StreamCache:
         ev = sid = None
         if tensor.is_cuda:
             st = torch.cuda.current_stream(tensor.device)
-            ev = torch.cuda.Event()
-            ev.record(st)
             sid = st.cuda_stream
+            if not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()
+                ev.record(st)
         self._c[key] = (version, tensor, ev, sid)
 
 

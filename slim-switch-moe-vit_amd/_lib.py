@@ -22,6 +22,7 @@ SIGNATURES = {
     "smoe_abi_version": (c_int, []),
     "smoe_build_id": (ctypes.c_char_p, []),
     "smoe_init": (c_int, []),
+    "smoe_set_reserved_cus": (c_int, [c_int]),
     "smoe_last_error": (ctypes.c_char_p, []),
     "smoe_router_workspace_bytes": (c_size_t, [c_int64]),
     "smoe_router_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
@@ -40,6 +41,7 @@ SIGNATURES = {
     "smoe_gelu": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "smoe_rowdot": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "smoe_pad_offsets": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "smoe_split_offsets": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "smoe_transpose_pad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "smoe_grouped_gemm_gelu_keep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int,
                                             c_void_p, c_void_p, c_void_p]),

@@ -203,14 +203,19 @@ class _GroupFFN(torch.autograd.Function):
             # colsum(dY_g) (x) A_row; the bias gradients are column sums as for every group.  The GEMMs run over the first E groups only.
             E = G - Z
             offs_e = offsets[: E + 1]
-            dW1 = ops.grouped_wgrad_rows(dH, rows, offs_e)
-            dW2 = ops.grouped_wgrad_rows(dY, A, offs_e)
+            S = ops.expert_wgrad_splits(E, dH.shape[1], rows.shape[1], dH.shape[0], dH.device)
+            offs_s = ops.split_offsets(offs_e.contiguous(), S) if S > 1 else None
+            dW1 = ops.grouped_wgrad_rows_split(dH, rows, offs_e, S, offs_s)
+            dW2 = ops.grouped_wgrad_rows_split(dY, A, offs_e, S, offs_s)
             # rank-1 terms into dW2 (in place) and the experts' bias gradients, one launch (smoe_zero_group_fold)
             db2, db1 = ops.zero_group_fold(cs2, cs1, A, offsets, gmap, E, dW2, want_b2=ctx.has_b2, want_b1=ctx.has_b1)
             G = E
         else:
-            dW1 = ops.grouped_wgrad_rows(dH, rows, offsets)
-            dW2 = ops.grouped_wgrad_rows(dY, A, offsets)
+            # (few, long groups at small widths -- DeiT-Tiny: 24 tiles -- are cut into pieces: ops.expert_wgrad_splits)
+            S = ops.expert_wgrad_splits(G, dH.shape[1], rows.shape[1], dH.shape[0], dH.device)
+            offs_s = ops.split_offsets(offsets, S) if S > 1 else None
+            dW1 = ops.grouped_wgrad_rows_split(dH, rows, offsets, S, offs_s)
+            dW2 = ops.grouped_wgrad_rows_split(dY, A, offsets, S, offs_s)
             db2, db1 = (cs2 if ctx.has_b2 else None), cs1
         if G != E_local:  # rank-major groups (source rank, local expert): fold the source ranks
             dW2, dW1 = dW2.view(-1, E_local, *dW2.shape[1:]).sum(0), dW1.view(-1, E_local, *dW1.shape[1:]).sum(0)

@@ -535,6 +535,29 @@ extern "C" int smoe_rowdot(const void* dout, int dout_dtype, const void* y, int 
   });
 }
 
+// out[g * S + s] = offsets[g] + min(s * step_g, count_g), step_g = count_g cut into S pieces of whole 64-row chunks; out[G * S] =
+// offsets[G]: every row group cut into S pseudo-groups (a weight gradient over few, long groups fills few CUs: smoe_grouped_wgrad_rows'
+// grid is groups x output tiles -- 24 workgroups for DeiT-Tiny's dW1 [8, 768, 192]).
+namespace {
+__global__ void split_offsets_kernel(const int32_t* __restrict__ offsets, int G, int S, int32_t* __restrict__ out) {
+  for (int i = threadIdx.x; i < G * S; i += blockDim.x) {
+    const int g = i / S, s = i - g * S;
+    const int32_t lo = offsets[g], cnt = offsets[g + 1] - lo;
+    const int32_t step = ((cnt + S * 64 - 1) / (S * 64)) * 64;
+    const int32_t at = s * step;
+    out[i] = lo + (at < cnt ? at : cnt);
+  }
+  if (threadIdx.x == 0) out[G * S] = offsets[G];
+}
+}  // namespace
+
+extern "C" int smoe_split_offsets(const int32_t* offsets, int G, int S, int32_t* out, void* stream) {
+  SMOE_REQUIRE(offsets && out && G >= 1 && S >= 1 && (int64_t)G * S <= 65536, "smoe_split_offsets: bad arguments G=%d S=%d", G, S);
+  hipLaunchKernelGGL(split_offsets_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, offsets, G, S, out);
+  SMOE_CHECK_LAUNCH("smoe_split_offsets");
+  return 0;
+}
+
 extern "C" int smoe_pad_offsets(const int32_t* offsets, int E, int32_t* offsets_pad, void* stream) {
   SMOE_REQUIRE(offsets && offsets_pad && E >= 1, "smoe_pad_offsets: bad arguments");
   hipLaunchKernelGGL(pad_offsets_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, offsets, E, offsets_pad);

@@ -1109,7 +1109,8 @@ int launch_ps(const void* A, const void* W, const float* bias, const int32_t* of
   constexpr int TBM = 64 * AFR, TBN = 256;
   const int n_tiles_n = (N + TBN - 1) / TBN;
   const int64_t max_tiles = ((m_rows_max + TBM - 1) / TBM + E) * n_tiles_n;
-  int grid = smoe_num_cus() & ~7;                 // one workgroup per CU (the LDS is full); a multiple of 8 (XCD slots)
+  int grid = (smoe_num_cus() - smoe_reserved_cus()) & ~7;   // one workgroup per CU (the LDS is full); a multiple of 8 (XCD slots);
+                                                            // minus the CUs left to other streams (smoe_set_reserved_cus)
   if (grid < 8) grid = 8;
   if (max_tiles < grid) grid = (int)((max_tiles + 7) & ~(int64_t)7);
   // tile order (see the kernel): XCD-contiguous runs over blocks of n_block n-tiles.  Measured on the bench model's shapes,

@@ -124,6 +124,7 @@ struct SmoeKernelEntry {
 };
 int smoe_kernel_ensure(SmoeKernelEntry& e);  // api.hip
 int smoe_num_cus();                          // CU count of the current device (cached per device)
+int smoe_reserved_cus();                     // CUs the persistent GEMM leaves to other streams' kernels (smoe_set_reserved_cus)
 // Zero `words` 32-bit words at p (4-byte aligned) with a kernel on stream s.  Used for the few device-side counters instead of
 // hipMemsetAsync: a plain kernel node orders like every other launch when the caller captures the stream into a graph.
 hipError_t smoe_zero_words(void* p, int64_t words, hipStream_t s);  // api.hip

@@ -182,6 +182,8 @@ def _wgrad_splits(M: int, N: int, K: int, device) -> int:
     """Row slices for a single-group weight gradient: enough (<= 16, >= 2,048 rows each) for one round of workgroups."""
     tiles = -(-N // 256) * -(-K // 256)
     cus = torch.cuda.get_device_properties(device).multi_processor_count
+    if tiles <= 4:      # DeiT-Tiny's widths (3 tiles for qkv, 1 for the projection): more, shorter slices -- 36 workgroups are not a round
+        return max(1, min(32, cus // max(tiles, 1), M // 512))
     return max(1, min(16, cus // max(tiles, 1), M // 2048))
 
 

@@ -153,6 +153,112 @@ def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: to
             "hip_graph": graphed is not None}
 
 
+class GraphedTrainStep:
+    """One training step -- autocast forward, criterion (+ the gates' aux losses), ``optimizer.zero_grad``, loss scaling, backward,
+    clipping, the optimizer step, the loss-scale update: engine.py:52-74 -- captured into ONE HIP graph per batch shape and replayed.
+
+    Possible because nothing in that step touches the host when it runs on this package's ``optim.AdamW`` + ``optim.NativeScaler``
+    (the non-finite check, the clip coefficient, the step count and the loss scale live on the device).  What it buys: the reference's
+    own model (resmoe_tiny_patch16_224_expert8, batch 128: models/resMoE.py:151-187, cmd.sh:7-13) issues ~1,060 launches per step for
+    11 ms of GPU work and took 21.5 ms eager -- the host's launch rate; replayed it takes **10.8 ms**.  ViT-B at batch 128 is GPU-bound
+    (28 ms either way).
+
+    The first WARM steps with a given batch shape run eagerly (they are ordinary steps on their own batches and fill every cache); the
+    next one is captured -- recording only -- and replayed for that batch and every later one of the same shape.  Inputs are copied
+    into the graph's static buffers.  Hyper-parameters that live on the host (lr, weight decay, betas: baked into the captured
+    tables) are compared before every replay; a change re-captures (a per-epoch scheduler costs one capture per epoch; under a
+    per-step scheduler the harness gives up and runs eagerly).  After the last replay -- ``finish()`` -- every parameter's version
+    counter is bumped: the captured kernels refreshed the 16-bit weight images in place, but images that the FORWARD re-derives (the
+    transposed dgrad operands) were made before the last update, and host-side version counters do not move under a replay.
+    Host-side counters the kernels cannot keep (``Gate._total_tokens``) are advanced by hand."""
+
+    WARM = 3
+
+    def __init__(self, model, criterion, optimizer, loss_scaler, max_norm, with_inputs, aux_loss_weight, autocast):
+        from .fmoe import FMoETransformerMLP
+        self.model, self.criterion, self.optimizer, self.scaler = model, criterion, optimizer, loss_scaler
+        self.max_norm, self.with_inputs, self.aux_w, self.autocast = max_norm, with_inputs, aux_loss_weight, autocast
+        self.moes = [m for m in model.modules() if isinstance(m, FMoETransformerMLP)]
+        self.gates = [m for m in model.modules() if hasattr(m, "_total_tokens") and hasattr(m, "skip_counter")]
+        self.graphs, self.seen, self.recaptures, self.replayed = {}, {}, 0, False
+        self.disabled = False
+
+    @staticmethod
+    def supported(model, optimizer, loss_scaler, device, model_ema) -> bool:
+        from .optim import NativeScaler as _OwnScaler
+        dev = torch.device(device)
+        ep = any(getattr(m, "ep_active", lambda: False)() for m in model.modules() if hasattr(m, "ep_active"))
+        return (dev.type == "cuda" and not ep and model_ema is None and getattr(optimizer, "_slimmoe_refreshes_images", False)
+                and isinstance(loss_scaler, _OwnScaler) and loss_scaler.enabled
+                and not getattr(optimizer, "is_second_order", False))
+
+    def _hyper(self):
+        return tuple((g.get("lr"), g.get("weight_decay"), tuple(g.get("betas", ())), g.get("eps")) for g in self.optimizer.param_groups)
+
+    def eager(self, samples, targets):
+        """The step itself (also what gets captured).  Returns the detached f32 loss."""
+        dev = samples.device
+        with torch.autocast(device_type=dev.type, dtype=torch.float16, enabled=self.autocast and dev.type == "cuda"):
+            outputs = self.model(samples)
+            loss = self.criterion(samples, outputs, targets) if self.with_inputs else self.criterion(outputs, targets)
+            if self.aux_w:
+                auxes = [a for a in (m.gate.get_loss() for m in self.moes) if a is not None]
+                if auxes:
+                    loss = loss + self.aux_w * torch.stack([a.reshape(()) for a in auxes]).sum()
+        lv = loss.detach().float()
+        self.optimizer.zero_grad()
+        self.scaler(loss, self.optimizer, clip_grad=self.max_norm, parameters=self.model.parameters(), create_graph=False)
+        return lv
+
+    def _capture(self, samples, targets):
+        static_s, static_t = samples.clone(), targets.clone()
+        before = [g._total_tokens for g in self.gates]
+        self.optimizer.zero_grad(set_to_none=True)        # the backward's gradients are allocated from the graph's own pool
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="relaxed"):   # (relaxed: the step allocates small pinned staging buffers)
+            lv = self.eager(static_s, static_t)
+        tokens = [(g, g._total_tokens - b) for g, b in zip(self.gates, before)]
+        for g, b in zip(self.gates, before):              # the capture computed nothing
+            g._total_tokens = b
+        return static_s, static_t, graph, lv, tokens, self._hyper()
+
+    def __call__(self, samples, targets):
+        if self.disabled:
+            return self.eager(samples, targets)
+        key = (tuple(samples.shape), samples.dtype, tuple(targets.shape), targets.dtype)
+        self.seen[key] = self.seen.get(key, 0) + 1
+        ent = self.graphs.get(key)
+        if ent is not None and ent[5] != self._hyper():   # lr / weight decay moved: the captured tables are stale
+            self.recaptures += 1
+            if self.recaptures > 8 and self.recaptures > self.seen.get(key, 0) // 4:
+                self.finish()                             # a per-step schedule: capturing every step costs more than it saves
+                self.disabled = True
+                return self.eager(samples, targets)
+            ent = None
+            self.graphs.pop(key, None)
+        if ent is None:
+            if self.seen[key] <= self.WARM:
+                if self.replayed:
+                    self.finish()                         # (a new shape after replays: the eager step must see current images)
+                return self.eager(samples, targets)
+            ent = self.graphs[key] = self._capture(samples, targets)
+        static_s, static_t, graph, lv, tokens, _ = ent
+        static_s.copy_(samples)
+        static_t.copy_(targets)
+        graph.replay()
+        self.replayed = True
+        for g, n in tokens:
+            g._total_tokens += n
+        return lv.clone()
+
+    def finish(self):
+        """Call when the replays end (end of the epoch, or before an eager step): host-side version counters catch up."""
+        if self.replayed:
+            from .optim import _bump_versions
+            _bump_versions([p for group in self.optimizer.param_groups for p in group["params"]])
+            self.replayed = False
+
+
 def _criterion_takes_inputs(criterion) -> bool:
     """The reference's criterion is ``DistillationLoss.forward(inputs, outputs, labels)`` (losses.py:28; called as
     ``criterion(samples, outputs, targets)`` at engine.py:54); a plain ``nn.CrossEntropyLoss`` takes (outputs, targets)."""
@@ -169,7 +275,7 @@ def _criterion_takes_inputs(criterion) -> bool:
 def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]],
                     optimizer: torch.optim.Optimizer, device, epoch: int, loss_scaler, max_norm=None, model_ema=None,
                     mixup_fn=None, set_training_mode=True, args=None, *, aux_loss_weight: float = 0.0, gate_delta=None,
-                    autocast: bool = True, check_every: int = 50):
+                    autocast: bool = True, check_every: int = 50, hip_graph=False):
     """The reference's training loop body (engine.py:22-85) around the HIP path, with the reference's positional
     parameters in the reference's order (main.py:825-838 calls it positionally: ``model_ema`` and ``mixup_fn`` sit in
     positions 9 and 10): autocast forward, criterion, ``loss_scaler(loss, optimizer, clip_grad=max_norm,
@@ -180,7 +286,9 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
 
     Keyword-only extensions: ``aux_loss_weight`` adds the MoE gates' load-balance losses (SwitchGate, BASELINE cfg 5);
     ``gate_delta`` runs the token-skip gates' threshold schedule (``Gate.step(delta)`` for every gate, as main.py:887-891
-    does after the epoch's steps); ``autocast``.
+    does after the epoch's steps); ``autocast``; ``hip_graph`` (default False; True, or "auto" = SLIMMOE_TRAIN_GRAPH=1): the whole step
+    replayed from one HIP graph per batch shape (GraphedTrainStep: needs this package's AdamW + NativeScaler, one rank, no EMA; 2 x on
+    the reference's DeiT-Tiny model, nothing on ViT-B) -- anything it cannot take runs eagerly, as before.
 
     The reference aborts on a non-finite loss by reading ``loss.item()`` in every step (engine.py:56-60: one host sync per
     step), BEFORE the optimizer step and the EMA update.  Here the check is a device-side count read every ``check_every`` steps
@@ -204,6 +312,12 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
         check_every = 1
     bce = bool(getattr(args, "bce_loss", False)) if args is not None else False
     loss_sum, bad, n = torch.zeros((), device=dev), torch.zeros((), device=dev), 0
+    if hip_graph == "auto":
+        import os
+        hip_graph = os.environ.get("SLIMMOE_TRAIN_GRAPH", "0") == "1"
+    graphed = None
+    if hip_graph and not every_step and GraphedTrainStep.supported(model, optimizer, loss_scaler, dev, model_ema):
+        graphed = GraphedTrainStep(model, criterion, optimizer, loss_scaler, max_norm, with_inputs, aux_loss_weight, autocast)
     for samples, targets in data_loader:
         samples = samples.to(dev, non_blocking=True)
         targets = targets.to(dev, non_blocking=True)
@@ -211,6 +325,17 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
             samples, targets = mixup_fn(samples, targets)
         if bce:
             targets = targets.gt(0.0).type(targets.dtype)
+        if graphed is not None:
+            # (an enabled optim.NativeScaler skips a non-finite step on the device by itself: the abort can wait for check_every)
+            lv = graphed(samples, targets)
+            finite = torch.isfinite(lv)
+            loss_sum += torch.where(finite, lv, torch.zeros_like(lv))
+            bad += (~finite).to(bad.dtype)
+            n += 1
+            if check_every > 1 and n % check_every == 0 and int(bad):
+                print(f"Loss is non-finite in {int(bad)} of {n} steps, stopping training")
+                raise SystemExit(1)
+            continue
         with torch.autocast(device_type=dev.type, dtype=torch.float16, enabled=autocast and dev.type == "cuda"):
             outputs = model(samples)
             loss = criterion(samples, outputs, targets) if with_inputs else criterion(outputs, targets)
@@ -234,6 +359,8 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
         if check_every > 1 and n % check_every == 0 and int(bad):
             print(f"Loss is non-finite in {int(bad)} of {n} steps, stopping training")
             raise SystemExit(1)
+    if graphed is not None:
+        graphed.finish()
     if gate_delta is not None:
         for m in model.modules():
             if isinstance(m, Gate):
@@ -245,4 +372,5 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
         print(f"Loss is non-finite in {n_bad} of {n} steps, stopping training")
         raise SystemExit(1)
     mean = float(loss_sum) / max(n, 1)
-    return {"loss": mean, "steps": n, "lr": optimizer.param_groups[0]["lr"]}
+    return {"loss": mean, "steps": n, "lr": optimizer.param_groups[0]["lr"],
+            "hip_graph_steps": 0 if graphed is None else sum(max(0, c - GraphedTrainStep.WARM) for c in graphed.seen.values())}

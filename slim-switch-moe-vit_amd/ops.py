@@ -696,6 +696,19 @@ def gather_combine_ln(y: torch.Tensor, inv_pos: torch.Tensor, score: torch.Tenso
     return out, xn
 
 
+_reserved_cus = 0
+
+
+def set_reserved_cus(n: int) -> int:
+    """The persistent grouped GEMM leaves ``n`` CUs free from now on (smoe_set_reserved_cus; process-wide): kernels on other streams
+    -- RCCL's all-to-all under the expert-parallel micro-batch pipeline -- can then run BESIDE the GEMMs instead of behind them.
+    Returns the previous value.  Results do not depend on it."""
+    global _reserved_cus
+    _lib.check(_lib.load().smoe_set_reserved_cus(int(n)), "smoe_set_reserved_cus")
+    prev, _reserved_cus = _reserved_cus, int(n)
+    return prev
+
+
 def _ps_variant(rows: int, G: int, K: int, N: int, device) -> int:
     """The persistent GEMM's tile height / schedule for ``rows`` real rows in G groups -- csrc/gemm.hip's variant-9 rule (expected
     tiles of 256 or 320 rows, cost-weighted rounds of workgroups, ties to the taller tile; deep schedule for K >= 2048) as an
@@ -991,6 +1004,40 @@ def pad_offsets(offsets: torch.Tensor) -> torch.Tensor:
     rc = _lib.load().smoe_pad_offsets(_ptr(offsets), offsets.numel() - 1, _ptr(out), _stream(offsets))
     _lib.check(rc, "smoe_pad_offsets")
     return out
+
+
+def split_offsets(offsets: torch.Tensor, S: int) -> torch.Tensor:
+    """i32 [G * S + 1]: every row group of ``offsets`` cut into S pseudo-groups of whole 64-row chunks (smoe_split_offsets)."""
+    _chk(offsets, "offsets", torch.int32, 1, align=4)
+    G = offsets.numel() - 1
+    out = torch.empty(G * int(S) + 1, dtype=torch.int32, device=offsets.device)
+    rc = _lib.load().smoe_split_offsets(_ptr(offsets), G, int(S), _ptr(out), _stream(offsets))
+    _lib.check(rc, "smoe_split_offsets")
+    return out
+
+
+def expert_wgrad_splits(G: int, R1: int, R2: int, rows: int, device) -> int:
+    """Pieces to cut every expert's rows into for its weight gradient [R1, R2]: the kernel's grid is groups x output tiles, and at
+    small widths that is a fraction of the chip (DeiT-Tiny, models/resMoE.py:151-187: 8 experts x 3 tiles = 24 workgroups walking 6 k rows
+    each, 100 us per launch and a third of the training step).  Enough pieces for ~one round of workgroups, at least ~512 rows each."""
+    tiles = G * min(-(-R1 // 256) * -(-R2 // 256), -(-R2 // 256) * -(-R1 // 256))
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    if tiles * 2 > cus:
+        return 1
+    return max(1, min(16, cus // max(tiles, 1), rows // max(G, 1) // 512))
+
+
+def grouped_wgrad_rows_split(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor, S: int,
+                             offsets_split: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``grouped_wgrad_rows`` with every group cut into S pieces (``offsets_split`` = split_offsets(offsets, S), reusable by the
+    layer's second weight gradient) and the partial products summed in piece order: f32 [G, R1, R2]."""
+    G = offsets.numel() - 1
+    if S <= 1:
+        return grouped_wgrad_rows(P, Q, offsets)
+    if offsets_split is None:
+        offsets_split = split_offsets(offsets, S)
+    part = grouped_wgrad_rows(P, Q, offsets_split)
+    return part.view(G, S, part.shape[1], part.shape[2]).sum(1)
 
 
 def padded_len(n_rows: int, E: int) -> int:

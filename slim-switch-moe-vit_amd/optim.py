@@ -56,10 +56,31 @@ def _block_table(numels, device):
     return hit
 
 
+_staging = []          # pinned staging buffers of tables copied to the device while a HIP graph was being captured: kept for good
+_staging_ring = []     # ... and of the eager steps: the last few (the copy is asynchronous)
+
+
+def _host_table(rows, dtype, device):
+    """A small table (addresses, element counts, per-tensor hyper-parameters) on the device.  The values change with every backward,
+    so this is one small host-to-device copy per step -- from PINNED memory, asynchronously: it costs the host no wait, and it can be
+    captured (a HIP graph of the whole training step replays the copy from the same pinned buffer, which therefore must outlive the
+    graph: buffers staged during a capture are never released)."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return torch.tensor(rows, dtype=dtype, device=dev)
+    host = torch.tensor(rows, dtype=dtype).pin_memory()
+    if torch.cuda.is_current_stream_capturing():
+        _staging.append(host)
+    else:
+        _staging_ring.append(host)
+        if len(_staging_ring) > 64:
+            del _staging_ring[:32]
+    return host.to(dev, non_blocking=True)
+
+
 def _pointer_table(rows, device):
-    """int64 [len(rows), n_t] on the device (addresses and element counts: they change with every backward, so this is one
-    small host-to-device copy per step)."""
-    return torch.tensor(rows, dtype=torch.int64, device=device)
+    """int64 [len(rows), n_t] on the device (addresses and element counts)."""
+    return _host_table(rows, torch.int64, device)
 
 
 class AdamW(torch.optim.Optimizer):
@@ -172,7 +193,7 @@ class AdamW(torch.optim.Optimizer):
             tab = _pointer_table([[it[0].data_ptr() for it in items], [it[1].data_ptr() for it in items],
                                   [it[2].data_ptr() for it in items], [it[3].data_ptr() for it in items],
                                   [it[0].numel() for it in items]], dev)
-            hyp = torch.tensor([[it[4] for it in items], [it[5] for it in items]], dtype=torch.float32, device=dev)
+            hyp = _host_table([[it[4] for it in items], [it[5] for it in items]], torch.float32, dev)
             # 16-bit operand images of the parameters that are current NOW (the modules' weight shadows): written in the same pass,
             # so the next forward finds them current (no f32 -> 16-bit cast pass over every weight per step)
             shadows = [shadow_of(it[0]) if SHADOW_STEP else None for it in items]

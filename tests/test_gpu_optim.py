@@ -298,3 +298,46 @@ def test_foreign_optimizer_step_invalidates_the_16_bit_weight_images():
             p.data.mul_(1.01)
     sm.invalidate_weight_images()
     assert torch.equal(infer(model), infer(fresh_copy()))
+
+
+def test_training_harness_on_one_hip_graph_reproduces_the_eager_harness():
+    """engine.train_one_epoch(hip_graph=True): after three eager steps per batch shape the whole step (forward, backward, clipping,
+    AdamW, loss-scale update) is captured once and replayed.  Same data, same seeds, stochastic depth off (its random draws come
+    from another point of the generator's stream under a graph): after 9 steps the PARAMETERS, the optimizer's moments, the loss scale
+    and the mean loss are bit for bit the eager harness', the 16-bit weight images are current afterwards (an eval forward equals a
+    freshly loaded model's), and the token-skip counters agree."""
+    name, kw = "resmoe_tiny_patch16_224_expert8", dict(num_classes=10, depth=2, starting_threshold=0.55, target_threshold=0.5)
+    g = torch.Generator().manual_seed(70)
+    batches = [(torch.randn(8, 3, 224, 224, generator=g), torch.randint(0, 10, (8,), generator=g)) for _ in range(9)]
+
+    def run(graph):
+        torch.manual_seed(0)
+        model = sm.create_model(name, **kw)
+        with torch.no_grad():
+            for n_, p in model.named_parameters():
+                if "_gate.head.1.weight" in n_:
+                    p.normal_(0, 0.3, generator=torch.Generator().manual_seed(5))
+        model = model.to(DEV)
+        opt = sm.AdamW(model.parameters(), lr=1e-3, weight_decay=0.05)
+        scaler = sm.NativeScaler()
+        stats = sm.train_one_epoch(model, torch.nn.CrossEntropyLoss(), batches, opt, DEV, 0, scaler, 1.0, hip_graph=graph)
+        gates = [(m._total_tokens, m._skipped_tokens) for m in model.modules() if isinstance(m, sm.Gate)]
+        model.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            logits = model(batches[0][0].to(DEV)).float()
+        moments = [opt.state[p]["exp_avg"].clone() for p in model.parameters() if p in opt.state]
+        return stats, [p.detach().clone() for p in model.parameters()], moments, scaler.state_dict(), gates, logits, model
+
+    s_e, p_e, m_e, sc_e, g_e, l_e, _ = run(False)
+    s_g, p_g, m_g, sc_g, g_g, l_g, model_g = run(True)
+    assert s_g["hip_graph_steps"] == 6 and s_e["hip_graph_steps"] == 0
+    assert s_g["loss"] == s_e["loss"], (s_g, s_e)
+    assert all(torch.equal(a, b) for a, b in zip(p_e, p_g)), "parameters after 9 steps"
+    assert all(torch.equal(a, b) for a, b in zip(m_e, m_g)), "AdamW moments after 9 steps"
+    assert sc_e == sc_g and g_e == g_g, (sc_e, sc_g, g_e, g_g)
+    assert torch.equal(l_e, l_g)
+    fresh = sm.create_model(name, **kw)
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model_g.state_dict().items()})
+    fresh = fresh.to(DEV).eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        assert torch.equal(fresh(batches[0][0].to(DEV)).float(), l_g), "the weight images are current after the replays"

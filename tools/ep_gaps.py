@@ -36,6 +36,10 @@ def main():
     def step():
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             return model(images)
+    if os.environ.get("EP_GAPS_RESERVE"):
+        from slim_switch_moe_vit_amd import ops
+        ops.set_reserved_cus(int(os.environ["EP_GAPS_RESERVE"]))
+        print(f"the persistent GEMM leaves {os.environ['EP_GAPS_RESERVE']} CUs free")
     alpha = os.environ.get("EP_GAPS_STATIC")
     if force and alpha:
         from slim_switch_moe_vit_amd import ep
@@ -76,6 +80,8 @@ def main():
     for e in ks:
         per[e.name[:72]][0] += 1
         per[e.name[:72]][1] += e.time_range.end - e.time_range.start
+    print(f"sum of kernel durations {sum(e.time_range.end - e.time_range.start for e in ks) / 2 / 1e3:.3f} ms (nccl kernels are listed twice; "
+          f"sum > busy = kernels of different streams ran side by side)")
     print("GPU time by kernel: count, total us, avg us")
     for name, (n, tot) in sorted(per.items(), key=lambda kv: -kv[1][1])[:24]:
         print(f"  {n:4d} {tot:9.1f} {tot / n:8.1f}   {name}")

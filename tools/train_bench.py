@@ -92,6 +92,22 @@ else:
         scaler(loss, opt, clip_grad=1.0, parameters=model.parameters())
 
     t = timed(train_step, iters)
+    if os.environ.get("TRAIN_BENCH_GRAPH"):
+        # the WHOLE step (forward, backward, clip, AdamW, loss-scale update: no host sync anywhere) captured into one HIP graph and
+        # replayed: what the ~1,000 launches per step cost the host
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                train_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(gr, capture_error_mode="relaxed"):     # (pinned staging buffers are allocated inside the step)
+            train_step()
+        tg = timed(gr.replay, iters)
+        print(f"{name} train step replayed from one HIP graph, batch {images}: {tg:.2f} ms = {images / tg * 1e3:.0f} images/s (eager {t:.2f} ms)", flush=True)
     gates = [m for m in model.modules() if isinstance(m, sm.Gate)]
     extra = ""
     if gates:
