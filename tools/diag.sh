@@ -86,7 +86,7 @@ print(d['ms_per_step'], {k: v['avg_ms'] for k, v in d['kernels'].items() if 'gem
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_attn -o w -- python3 tools/attn_prof.py > $O/write_attn.log 2>&1
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_dispatch -o f -- python3 tools/dispatch_prof.py 3 > $O/fetch_dispatch.log 2>&1
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write_dispatch -o w -- python3 tools/dispatch_prof.py 3 > $O/write_dispatch.log 2>&1
-    for shape in fc1 fc2 ffn; do
+    for shape in fc1 fc2; do      # (`ffn` = the fused launch: only with a library built with `make FFN=-DSMOE_FFN_FUSED`)
       rocprofv3 --pmc $PMC_A --output-format csv -d $O/pmcA_$shape -o a -- python3 tools/gemm_prof.py 9 $shape 3 > $O/pmcA_$shape.log 2>&1
       rocprofv3 --pmc $PMC_B --output-format csv -d $O/pmcB_$shape -o b -- python3 tools/gemm_prof.py 9 $shape 3 > $O/pmcB_$shape.log 2>&1
       rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$shape -o f -- python3 tools/gemm_prof.py 9 $shape 3 > $O/fetch_$shape.log 2>&1
@@ -94,6 +94,12 @@ print(d['ms_per_step'], {k: v['avg_ms'] for k, v in d['kernels'].items() if 'gem
       rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/tcc_$shape -o t -- python3 tools/gemm_prof.py 9 $shape 3 > $O/tcc_$shape.log 2>&1
     done
     find $O -name "*.csv" | wc -l ;;
+  profile2)        # second half (a gpurun call of its own): the reference's own models, cfg 4, the forced expert-parallel line
+    TAG=$1; O=gpurun_out/prof_$TAG; mkdir -p $O
+    "$0" tiny-profile $TAG > $O/tiny_profile.log 2>&1
+    "$0" cfg4-profile $TAG > $O/cfg4_profile.log 2>&1
+    python3 bench.py --force-ep --no-cpu-baseline --clock-seconds 0 --steps 20 --warmup 5 > $O/force_ep_line.json 2> $O/force_ep.err
+    tail -2 $O/tiny_profile.log $O/cfg4_profile.log; tail -c 600 $O/force_ep_line.json ;;
   train-profile)   # the two training steps only (kernel tables): tools/diag.sh train-profile TAG
     TAG=$1; O=gpurun_out/prof_$TAG; mkdir -p $O
     python3 tools/train_bench.py model 128 10 > $O/train_unprofiled.log 2>&1        # the step's wall time WITHOUT the profiler
@@ -107,7 +113,7 @@ print(d['ms_per_step'], {k: v['avg_ms'] for k, v in d['kernels'].items() if 'gem
       python3 tools/tiny_bench.py $m 128 20 > $O/tiny_$m.json 2> $O/tiny_$m.txt
       rocprofv3 --kernel-trace --stats --output-format csv -d $O/tiny_$m -o tiny -- python3 tools/tiny_bench.py $m 128 20 > $O/tiny_${m}_prof.log 2>&1
     done
-    python3 tools/train_bench.py model 128 10 resmoe_tiny_patch16_224_expert8 > $O/tiny_train_unprofiled.log 2>&1
+    TRAIN_BENCH_GRAPH=1 python3 tools/train_bench.py model 128 10 resmoe_tiny_patch16_224_expert8 > $O/tiny_train_unprofiled.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/tiny_train -o train -- python3 tools/train_bench.py model 128 6 resmoe_tiny_patch16_224_expert8 > $O/tiny_train.log 2>&1
     grep -h "images/s" $O/tiny_*.txt $O/tiny_train_unprofiled.log ;;
   cfg4-profile)    # BASELINE cfg 4's model at its per-rank batch (512 / 8 = 64): tools/diag.sh cfg4-profile TAG

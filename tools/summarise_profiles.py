@@ -18,7 +18,16 @@ def own(name: str) -> bool:
 
 for what, out in (("bench/bench_kernel_stats.csv", f"{tag}_bench_kernel_stats.csv"), ("train/train_kernel_stats.csv", f"{tag}_train_model_kernel_stats.csv"),
                   ("train_resmoe/train_kernel_stats.csv", f"{tag}_train_resmoe_kernel_stats.csv"),
-                  ("dispatch/dispatch_kernel_stats.csv", f"{tag}_dispatch_kernel_stats.csv")):
+                  ("dispatch/dispatch_kernel_stats.csv", f"{tag}_dispatch_kernel_stats.csv"),
+                  ("tiny_resmoe_tiny_patch16_224_expert8/tiny_kernel_stats.csv", f"{tag}_tiny_resmoe_eval_kernel_stats.csv"),
+                  ("tiny_moe_tiny_patch16_224_expert8/tiny_kernel_stats.csv", f"{tag}_tiny_moe_eval_kernel_stats.csv"),
+                  ("tiny_resmoe_tiny_patch16_224_expert8.json", f"{tag}_tiny_resmoe_eval.json"),
+                  ("tiny_moe_tiny_patch16_224_expert8.json", f"{tag}_tiny_moe_eval.json"),
+                  ("tiny_resmoe_tiny_patch16_224_expert8.txt", f"{tag}_tiny_resmoe_eval.txt"),
+                  ("tiny_moe_tiny_patch16_224_expert8.txt", f"{tag}_tiny_moe_eval.txt"),
+                  ("tiny_train/train_kernel_stats.csv", f"{tag}_tiny_resmoe_train_kernel_stats.csv"),
+                  ("cfg4/cfg4_kernel_stats.csv", f"{tag}_cfg4_kernel_stats.csv"), ("cfg4_b64.txt", f"{tag}_cfg4_b64.txt"),
+                  ("force_ep_line.json", f"{tag}_force_ep_line.json")):
     p = os.path.join(src, what)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, out))
@@ -62,7 +71,8 @@ open(os.path.join(dst, f"{tag}_pmc_digest.md"), "w").write("\n".join(lines))
 # ---- training steps: own-kernel share and the top kernels
 out = [f"# {tag}: training-step kernel tables (rocprofv3 --kernel-trace --stats -- python3 tools/train_bench.py model 128 6 [name]; 9 steps = 3 warm-up + 6 timed)", ""]
 for what, title in (("train", "moe_base_patch16_224_expert8_top1 (SwitchGate, capacity_factor 1.0, aux loss: BASELINE cfg 5)"),
-                    ("train_resmoe", "resmoe_base_patch16_224_expert8_top1 (the reference's live block: token-skip gates, residual on the normed activations, drop-path 0.1)")):
+                    ("train_resmoe", "resmoe_base_patch16_224_expert8_top1 (the reference's live block: token-skip gates, residual on the normed activations, drop-path 0.1)"),
+                    ("tiny_train", "resmoe_tiny_patch16_224_expert8 (the reference's OWN model: DeiT-Tiny, E 8, top-2, token-skip gates, batch 128 -- models/resMoE.py:151-187, cmd.sh:7-13)")):
     p = os.path.join(src, what, "train_kernel_stats.csv")
     if not os.path.exists(p):
         continue
@@ -72,7 +82,7 @@ for what, title in (("train", "moe_base_patch16_224_expert8_top1 (SwitchGate, ca
     log = open(os.path.join(src, what + ".log")).read().strip().splitlines()
     line = next((l for l in log if "train step" in l), "")
     plain = os.path.join(src, what + "_unprofiled.log")
-    plain_line = next((l for l in open(plain).read().splitlines() if "train step" in l), "") if os.path.exists(plain) else ""
+    plain_line = " / ".join(l for l in open(plain).read().splitlines() if "train step" in l) if os.path.exists(plain) else ""
     out += [f"## {title}", ""]
     if plain_line:
         out += [f"without the profiler, same box: `{plain_line}`", ""]
