@@ -21,11 +21,11 @@ bmm-combine) anchored on the reference's own call sites:
 * ``models/resMoE.py:32-85``   token-skip ``Gate``
 * ``models/resMoE.py:126-145`` ``forward_residule_moe`` block wrapper
 
-PARITY STATUS: **parity unpinned** for FastMoE's part of the operator -- gate
-top-k, slot order, capacity, aux loss -- (the reference has no tests, fixtures or
-golden vectors, and FastMoE cannot run here).  Everything whose arithmetic lives
-IN the reference tree is pinned by outputs of the reference's own code, run in
-the build container (generators committed beside the data in ``tests/golden/``):
+PARITY STATUS, in two parts.
+(1) PINNED by outputs of the reference's own code -- everything whose arithmetic lives
+IN the reference tree, run in the build container (generators committed beside the
+data in ``tests/golden/``; ``tests/test_oracle.py::test_committed_fixtures_regenerate_
+bit_identically`` re-runs them and compares every byte):
 
 * the per-expert FFN, LayerNorm and attention against ``models/layers.py``
   (``make_golden.py`` -> ``ref_mlp_tiny / ref_layernorm_tiny / ref_attention_tiny.npz``);
@@ -38,6 +38,12 @@ the build container (generators committed beside the data in ``tests/golden/``):
   ``skip_gate`` below from the reference: of 34 rows engineered within 1e-4 of the
   threshold in logit space, 3 (eval) / 5 (train) decide differently, each with
   ``|sigmoid_f32(z) - thr| <= 1 ulp``; no other token differs.
+
+(2) **parity unpinned** for FastMoE's part of the operator ONLY -- gate top-k order and
+tie-break, slot order, capacity, aux loss: the reference has no tests, fixtures or
+golden vectors, and FastMoE (third-party, absent from the tree and from this image)
+cannot run here.  That part is a restatement of the published algorithm (SURVEY.md
+Appendix B) with the determinism decisions below.
 
 Determinism decisions (normative; upstream leaves these to atomic races)
 -----------------------------------------------------------------------
