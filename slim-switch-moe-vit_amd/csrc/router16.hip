@@ -208,8 +208,15 @@ int launch_mt(const void* x, const LnArgs& ln, const float* wg, const float* bg,
               int gate_kind, int force_f64, int32_t* rc, int32_t* rl, int64_t* idx, float* score, float* logits_out,
               float* probs, hipStream_t s) {
   using namespace rmt;
-  constexpr size_t smem = router_mt_smem<MP, LN, EB>();
-  static_assert(smem <= 160 * 1024, "router_mt: LDS image too large");
+  constexpr size_t smem1 = router_mt_smem<MP, LN, EB, 1>();
+  static_assert(smem1 <= 160 * 1024, "router_mt: LDS image too large");
+  // An image that leaves room for ONE workgroup per CU (E = 32) runs the f32 pass on TWO four-wave halves per workgroup (HV = 2:
+  // two waves per SIMD on the same image; router_mt_kernel.h) when both halves' exchange areas fit; SMOE_ROUTER_MT_HALVES=1 = the
+  // one-half form (A/B).  The f64 re-do pass always runs one half.
+  constexpr bool can2 = 2 * smem1 > 160 * 1024 && router_mt_smem<MP, LN, EB, 2>() <= 160 * 1024;
+  static const bool want2 = [] { const char* v = getenv("SMOE_ROUTER_MT_HALVES"); return !(v && v[0] == '1'); }();
+  const bool two = can2 && want2;
+  const size_t smem = smem1;
   const int64_t n_tiles = (T + 15) / 16;
   const int per_cu = (int)((160 * 1024) / smem) < 1 ? 1 : (int)((160 * 1024) / smem);
   const int64_t max_wg = (int64_t)smoe_num_cus() * (per_cu > 2 ? 2 : per_cu);
@@ -222,6 +229,23 @@ int launch_mt(const void* x, const LnArgs& ln, const float* wg, const float* bg,
   hipLaunchKernelGGL((router_mt_kernel<XT, MP, MODE, LN, NT, EB>), dim3(GRID), dim3(MT_THREADS), smem, s, (const XT*)x, \
                      ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, noise, T, E, k, gate_kind, RC, RL, idx, score,  \
                      logits_out, probs)
+  // the f32 pass on two halves: half as many workgroups, each walking the tiles of two
+  auto launch_f32 = [&](int32_t* RC, int32_t* RL) {
+    if constexpr (can2) {
+      if (two) {
+        constexpr size_t smem2 = router_mt_smem<MP, LN, EB, 2>();
+        const int64_t pairs = (n_tiles + 1) / 2, cap = smoe_num_cus();
+        const int64_t it2 = (pairs + cap - 1) / cap;
+        const int grid2 = (int)(pairs < 1 ? 1 : (pairs + it2 - 1) / (it2 < 1 ? 1 : it2));
+        hipLaunchKernelGGL((router_mt_kernel<XT, MP, 0, LN, NT, EB, 2>), dim3(grid2), dim3(2 * MT_THREADS), smem2, s, (const XT*)x,
+                           ln.g, ln.b, ln.eps, (NT*)ln.xn16, ln.xn32, wg, bg, noise, T, E, k, gate_kind, RC, RL, idx, score,
+                           logits_out, probs);
+        return;
+      }
+    }
+    MT_LAUNCH(0, grid, RC, RL);
+  };
+  if constexpr (can2) SMOE_ENSURE_SMEM(router_mt_kernel<XT, MP, 0, LN, NT, EB, 2>);
   const bool ws_zero = (force_f64 & 2) != 0;
   force_f64 &= 1;
   if (force_f64 && !LN) {
@@ -236,7 +260,7 @@ int launch_mt(const void* x, const LnArgs& ln, const float* wg, const float* bg,
       return (int)me;
     }
   }
-  MT_LAUNCH(0, grid, rc, rl);
+  launch_f32(rc, rl);
   SMOE_CHECK_LAUNCH("smoe_router_topk/mt f32");
   if (force_f64) {   // f64 mode with LayerNorm: the f32 pass above wrote the normalised rows
     MT_LAUNCH(1, grid, nullptr, nullptr);

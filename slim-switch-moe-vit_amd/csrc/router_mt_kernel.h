@@ -30,9 +30,13 @@ using r16::store4_16;
 
 constexpr int MT_THREADS = 256;
 
-template <int MP, bool LN, int EB> constexpr size_t router_mt_smem() {
+// HV = 1: one four-wave workgroup, its exchange area double-buffered by the tile's parity.  HV = 2 (round 5; the E = 32 image leaves
+// room for ONE workgroup per CU): two four-wave HALVES share the weight image, each walks tiles of its own through an exchange area
+// of its own -- single-buffered, one more barrier per tile -- so that every SIMD holds TWO waves: one computes or waits for LDS while
+// the other's loads are out (the medicine that took the attention backward from 199 to 163 us in round 4).
+template <int MP, bool LN, int EB, int HV = 1> constexpr size_t router_mt_smem() {
   constexpr size_t d = 128 * MP;
-  return ((size_t)EB * (d + 16) + 2 * EB + (LN ? 2 * d : 0) + 2 * 64 + 2 * 4 * 16 * (EB + 4)) * 4;
+  return ((size_t)EB * (d + 16) + 2 * EB + (LN ? 2 * d : 0) + HV * (2 * 64 + (HV == 1 ? 2 : 1) * 4 * 16 * (EB + 4))) * 4;
 }
 
 // sum over the four k-slot lanes of a token (lanes ti, ti + 16, ti + 32, ti + 48); every one of them gets the total
@@ -65,8 +69,8 @@ __device__ __forceinline__ int row16_min(int v) {
   return v;
 }
 
-template <typename XT, int MP, int MODE, bool LN, typename NT, int EB>
-__global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
+template <typename XT, int MP, int MODE, bool LN, typename NT, int EB, int HV = 1>
+__global__ __launch_bounds__(MT_THREADS * HV, 1) void router_mt_kernel(
     const XT* __restrict__ x, const float* __restrict__ ln_g, const float* __restrict__ ln_b, float ln_eps,
     NT* __restrict__ xn16, float* __restrict__ xn32, const float* __restrict__ wg, const float* __restrict__ bg,
     const float* __restrict__ noise, int64_t T, int E, int k, int gate_kind, int32_t* __restrict__ redo_count,
@@ -74,19 +78,23 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
     float* __restrict__ logits_out, float* __restrict__ probs_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int d = 128 * MP, dq = 32 * MP, WP = d + 16, NTL = EB / 16, PS = EB + 4, NACC = 4;
+  constexpr int NPAR = HV == 1 ? 2 : 1;            // exchange buffers per half
+  constexpr int NTHREADS = MT_THREADS * HV;
   static_assert(EB == 16 || EB == 32, "16 or 32 expert rows");
+  static_assert(HV == 1 || MODE == 0, "the f64 re-do pass runs on one half");
   float* lds_w = reinterpret_cast<float*>(smem);   // [EB][WP = d + 16] (the 64-byte row pad and the XOR below make the fragment reads
                                                    // conflict-free), rows >= E repeat row E - 1 (masked by every consumer); 16-byte slot s of a 128-byte group of row e sits at s ^ (e & 7)
   float* lds_wn2 = lds_w + EB * WP;                // [EB]
   float* lds_bias = lds_wn2 + EB;                  // [EB]
   float* lds_g = lds_bias + EB;                    // [d] LayerNorm weight, [d] bias (LN only)
   float* lds_be = lds_g + (LN ? d : 0);
-  float* st1 = lds_be + (LN ? d : 0);              // [4 waves][16 tokens] row sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, half = HV == 1 ? 0 : (tid >> 8), gwave = tid >> 6;
+  constexpr int AREA = 2 * 64 + NPAR * 4 * 16 * PS;   // floats of one half's exchange area
+  float* st1 = lds_be + (LN ? d : 0) + half * AREA; // [4 waves][16 tokens] row sums
   float* st2 = st1 + 64;                           // [4][16] centred sums of squares
-  float* part = st2 + 64;                          // [2 parities][4 waves][16 tokens][PS]: partial logits, slot EB = |row|^2 part
+  float* part = st2 + 64;                          // [NPAR parities][4 waves][16 tokens][PS]: partial logits, slot EB = |row|^2 part
   double* dpart = reinterpret_cast<double*>(part); // MODE 1: [4][16][EB] f64 partial logits (same bytes, one buffer)
-  static_assert(4 * 16 * EB * 8 <= 2 * 4 * 16 * PS * 4, "f64 partials fit the exchange area");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(MODE == 0 || 4 * 16 * EB * 8 <= 2 * 4 * 16 * PS * 4, "f64 partials fit the exchange area");
   const int ti = lane & 15, kk = lane >> 4;
   if (MODE == 1 && redo_list && *redo_count == 0) return;  // nothing to redo (the common case)
 
@@ -120,7 +128,12 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
       dst[m][1] = f32x4{b[0], b[1], b[2], b[3]};
     }
   };
-  if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x, xv);   // the first rows travel under the weight staging
+  // tiles: half h of workgroup b takes b HV + h, then every (gridDim.x HV)-th; BOTH halves run the same number of iterations (the
+  // workgroup's barriers order all eight waves), a tile past the end is dead: clamped reads, no stores
+  const int64_t tile0 = (int64_t)blockIdx.x * HV + half, tstep = (int64_t)gridDim.x * HV;
+  const int64_t n_iter = (n_tiles - (int64_t)blockIdx.x * HV + tstep - 1) / tstep;   // of half 0; >= half 1's
+  if (tile0 < n_tiles) fetch(tile0, xv);   // the first rows travel under the weight staging
+  else fetch(n_tiles > 0 ? n_tiles - 1 : 0, xv);
 
   {  // weight image -> LDS by LDS-DMA (no registers, every piece in flight at once: staging through VGPRs was four dependent
      // rounds of loads, ~8 us per launch).  A wave-instruction fills 1 KiB of LDS linearly, so the SOURCE address carries the
@@ -128,8 +141,8 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
      // group.  Pad slots read any valid address (never read back); rows >= E repeat row E - 1 (every consumer masks e >= E).
     constexpr int UNITS_PER_ROW = WP / 4, N_KIB = EB * WP * 4 / 1024;
     static_assert(EB * WP * 4 % 1024 == 0, "whole 1-KiB pieces");
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // the DMA's LDS base is wave-uniform (M0)
-    for (int pc = wave_u; pc < N_KIB; pc += MT_THREADS / 64) {
+    const int wave_u = __builtin_amdgcn_readfirstlane(gwave);   // the DMA's LDS base is wave-uniform (M0)
+    for (int pc = wave_u; pc < N_KIB; pc += NTHREADS / 64) {
       const int L = pc * 64 + lane;
       const int e = L / UNITS_PER_ROW, sl = L - e * UNITS_PER_ROW;
       const int ec = e < E ? e : E - 1;
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
     }
     if (tid < EB) lds_bias[tid] = (bg && tid < E) ? bg[tid] : 0.f;
     if (LN) {
-      for (int i = tid; i < d; i += MT_THREADS) {
+      for (int i = tid; i < d; i += NTHREADS) {
         lds_g[i] = ln_g ? ln_g[i] : 1.f;
         lds_be[i] = ln_b ? ln_b[i] : 0.f;
       }
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces (and the first rows) have landed
   __syncthreads();
-  for (int e = wave; MODE == 0 && e < EB; e += MT_THREADS / 64) {  // squared row norms (any column order): 16-byte reads, all in flight
+  for (int e = gwave; MODE == 0 && e < EB; e += NTHREADS / 64) {  // squared row norms (any column order): 16-byte reads, all in flight
     f32x4 q4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < d; c += 256) {
@@ -168,10 +181,13 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
   const int colw = wave * dq + 8 * kk;   // this lane's first column; piece m sits 32 m further
 
   int par = 0;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
+  int64_t tile = tile0;
+  for (int64_t it = 0; it < n_iter; ++it, tile += tstep, par ^= (NPAR - 1)) {
+    const bool tile_live = tile < n_tiles;
     bool live_l;
-    const int64_t t_l = token_of(tile * 16 + ti, live_l);
-    if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x, xnx);
+    const int64_t t_l = token_of((tile_live ? tile : n_tiles - 1) * 16 + ti, live_l);
+    live_l = live_l && tile_live;
+    if (tile + tstep < n_tiles) fetch(tile + tstep, xnx);
     int lz = 0;
     asm volatile("" : "+v"(lz));  // per-tile opaque zero: keeps the loop-invariant LDS reads inside the loop
     // ---- LayerNorm: two-pass statistics, the four column quarters meet in LDS (fixed order) -----------------------
@@ -298,7 +314,8 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
     {
       const int q = lane >> 4, u = lane & 15, tl = 4 * wave + q;
       bool live;
-      const int64_t t = token_of(tile * 16 + tl, live);
+      const int64_t t = token_of((tile_live ? tile : n_tiles - 1) * 16 + tl, live);
+      live = live && tile_live;
       float lgv[NTL];
       float xs = 0.f;
       if constexpr (MODE == 0) {
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(MT_THREADS, 1) void router_mt_kernel(
         }
       }
     }
-    if constexpr (MODE == 1) __syncthreads();   // the single f64 exchange buffer is rewritten by the next tile
+    if constexpr (MODE == 1 || NPAR == 1) __syncthreads();   // a single exchange buffer is rewritten by the next tile
 #pragma unroll
     for (int m = 0; m < MP; ++m) {
       xv[m][0] = xnx[m][0];

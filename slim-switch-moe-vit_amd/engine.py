@@ -46,6 +46,7 @@ class GraphedForward:
 
     def __init__(self, model: torch.nn.Module, autocast: bool = True):
         self.model, self.autocast, self.graphs = model, autocast, {}
+        self.failed = None       # the exception of a capture that did not work: from then on every call runs eagerly
 
     @staticmethod
     def supported(model: torch.nn.Module, device) -> bool:
@@ -81,14 +82,25 @@ class GraphedForward:
         return static_in, graph, static_out, tokens
 
     def __call__(self, images: torch.Tensor) -> torch.Tensor:
+        if self.failed is not None:
+            return self._run(images)
         key = (tuple(images.shape), images.dtype, str(images.device))
         ent = self.graphs.get(key)
         if ent is None:
             gates = self._gates()
             before = [(g, g._total_tokens, g._skipped_tokens) for g in gates]   # the two warm-up forwards count for nothing
-            ent = self.graphs[key] = self._capture(images)
+            try:
+                ent = self.graphs[key] = self._capture(images)
+            except Exception as exc:      # a model the capture cannot take (a host sync in a foreign module, ...): say so, run eagerly
+                import warnings
+                self.failed = exc
+                torch.cuda.synchronize(images.device)
+                warnings.warn(f"evaluate(): the forward could not be captured into a HIP graph ({type(exc).__name__}: {exc}); "
+                              "running eagerly (hip_graph=False avoids the attempt)")
             for g, t, s in before:
                 g._total_tokens, g._skipped_tokens = t, s
+            if self.failed is not None:
+                return self._run(images)
         static_in, graph, static_out, tokens = ent
         static_in.copy_(images)
         graph.replay()
@@ -241,7 +253,16 @@ class GraphedTrainStep:
                 if self.replayed:
                     self.finish()                         # (a new shape after replays: the eager step must see current images)
                 return self.eager(samples, targets)
-            ent = self.graphs[key] = self._capture(samples, targets)
+            try:
+                ent = self.graphs[key] = self._capture(samples, targets)
+            except Exception as exc:      # (nothing ran on the GPU during the failed capture: the step is still to be done)
+                import warnings
+                torch.cuda.synchronize(samples.device)
+                warnings.warn(f"train_one_epoch(): the step could not be captured into a HIP graph ({type(exc).__name__}: {exc}); "
+                              "running eagerly")
+                self.finish()
+                self.disabled = True
+                return self.eager(samples, targets)
         static_s, static_t, graph, lv, tokens, _ = ent
         static_s.copy_(samples)
         static_t.copy_(targets)
