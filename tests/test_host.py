@@ -423,3 +423,38 @@ def test_foreign_optimizer_step_bumps_parameter_versions():
         assert seen == [1]
     finally:
         optim._bump_versions = real
+
+
+def test_slot_table_layout_and_all_to_all_splits():
+    """ep._SlotTable: global expert e owns caps[e] payload rows + one header row of the send buffer, regions in expert order; the
+    all-to-all splits follow from the table alone (no count exchange): what rank r sends to rank w = w's experts' regions; what it
+    receives from every source = its own experts' regions."""
+    from slim_switch_moe_vit_amd import ep
+    caps = [5, 1, 7, 3, 2, 9]
+    for rank in range(3):
+        t = ep._SlotTable(caps, rank, 2, "cpu")
+        base = t.base_dev.tolist()
+        assert base == [0, 6, 8, 16, 20, 23, 33] and t.rows == 33
+        assert t.in_splits == [8, 12, 13]
+        own = t.in_splits[rank]
+        assert t.out_splits == [own] * 3 and t.recv_rows == 3 * own
+        lb = t.lbase_dev.tolist()
+        assert lb == [0, caps[2 * rank] + 1, caps[2 * rank] + caps[2 * rank + 1] + 2]
+    assert ep._SlotTable([0, -3], 0, 1, "cpu").caps == [1, 1]            # a slot never has fewer than one payload row
+
+
+def test_harness_switch_parsing():
+    from slim_switch_moe_vit_amd import engine
+    assert engine._speculative_alpha(None) is None and engine._speculative_alpha(0) is None
+    assert engine._speculative_alpha(1.3) == 1.3
+    old = os.environ.pop("SLIMMOE_EP_ALPHA", None)
+    try:
+        assert engine._speculative_alpha("auto") == 1.5
+        os.environ["SLIMMOE_EP_ALPHA"] = "0"
+        assert engine._speculative_alpha("auto") is None
+    finally:
+        os.environ.pop("SLIMMOE_EP_ALPHA", None)
+        if old is not None:
+            os.environ["SLIMMOE_EP_ALPHA"] = old
+    m = sm.create_model("moe_tiny_patch16_224_expert4_top1", depth=1, num_classes=10)
+    assert not engine.GraphedForward.supported(m.eval(), "cpu")            # graphs are a GPU matter; CPU models run eagerly
