@@ -183,10 +183,14 @@ def test_training_step_on_own_dense_kernels_matches_torch_autocast_path(name, de
     print(f"{name}: loss {l_own:.5f} vs {l_ref:.5f}; worst relative L2 gradient difference {worst[0]:.2e} ({worst[1]})")
     assert worst[0] <= 3e-2, worst
     from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CUDA]) as prof:
-        _train_losses_and_grads(model, images, target, "own")
-        torch.cuda.synchronize()
-    names = {e.key for e in prof.key_averages()}
+    names = set()
+    for _attempt in range(3):      # (roctracer now and then delivers the runtime-API rows of a cycle without its kernel rows: ask again)
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            _train_losses_and_grads(model, images, target, "own")
+            torch.cuda.synchronize()
+        names = {e.key for e in prof.key_averages()}
+        if any(not n.startswith("hip") for n in names):
+            break
     aotriton = {"bwd_kernel_dk_dv", "bwd_kernel_dq", "bwd_preprocess", "attn_fwd"}           # exact symbol names
     torch_ln = ("layer_norm_grad_input_kernel", "cuComputePartGradGammaBeta", "vectorized_layer_norm_kernel")
     # hipBLASLt GEMMs (the dense projections; the router's thin dx product is a streaming kernel now), aotriton attention and
