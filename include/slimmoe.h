@@ -421,7 +421,10 @@ int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E,
  *   smoe_a2a_tokens : all-to-all-v of d-element rows; `send` holds the rows for rank 0, 1, ... (send_rows[w] each: the
  *                     expert-sorted send buffer has that order), `recv` receives recv_rows[w] rows from rank w, rank-major
  *                     (the [source rank][local expert] layout smoe_grouped_gemm takes through group_expert);
- *                     send_rows / recv_rows are HOST i64 [W]                                                        */
+ *                     send_rows / recv_rows are HOST i64 [W]
+ * wait = SMOE_A2A_INLINE posts the exchange on the caller's `stream` itself (no communication stream, no events, no ticket):
+ * in stream order with the kernels either side of it, for a caller that has nothing to run beside the exchange.             */
+#define SMOE_A2A_INLINE 2
 typedef struct smoe_ctx smoe_ctx;
 int smoe_unique_id_bytes(void);
 int smoe_unique_id(void* out_id);

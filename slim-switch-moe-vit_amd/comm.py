@@ -69,7 +69,8 @@ class ExchangeContext:
                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """all-to-all-v of whole rows (``rows[:sum(send_rows)]`` split by destination rank); returns the receive buffer.
         With ``wait=False`` the caller's stream does NOT wait for the exchange: call ``wait_stream(ref, ticket)`` with
-        ``last_ticket()`` taken right after this call (or ``wait_stream(ref)`` = the latest exchange) before reading it."""
+        ``last_ticket()`` taken right after this call (or ``wait_stream(ref)`` = the latest exchange) before reading it.
+        ``wait="inline"`` posts the exchange on the caller's stream itself (SMOE_A2A_INLINE: no second stream, no events)."""
         ops._chk(rows, "rows", ndim=2, align=4)
         W = self.world_size
         if len(send_rows) != W or len(recv_rows) != W:
@@ -84,8 +85,10 @@ class ExchangeContext:
         r_arr = (ctypes.c_int64 * W)(*[int(v) for v in recv_rows])
         rc = _lib.load().smoe_a2a_tokens(self._h, rows.data_ptr() if rows.numel() else None, s_arr,
                                          out.data_ptr() if out.numel() else None, r_arr, rows.shape[1],
-                                         self._size_code(rows), ops._stream(rows), 1 if wait else 0)
+                                         self._size_code(rows), ops._stream(rows), 2 if wait == "inline" else 1 if wait else 0)
         _lib.check(rc, "smoe_a2a_tokens")
+        if wait == "inline":
+            return out
         # both buffers are in use on the context's stream: keep the allocator from recycling them under it
         cs = torch.cuda.ExternalStream(_lib.load().smoe_ctx_comm_stream(self._h), device=rows.device)
         rows.record_stream(cs)

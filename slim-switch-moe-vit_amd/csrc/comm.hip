@@ -195,13 +195,17 @@ extern "C" int smoe_a2a_counts(smoe_ctx* c, const int32_t* send_counts, int32_t*
   SMOE_REQUIRE(c && send_counts && recv_counts && E_local >= 1, "smoe_a2a_counts: bad arguments");
   RcclApi* api = rccl();
   SMOE_REQUIRE(api, "smoe_a2a_counts: librccl.so not found");
-  if (int rc = fence_in(c, (hipStream_t)stream)) return rc;
+  const bool in_line = wait == SMOE_A2A_INLINE;   // posted on the caller's stream itself: no event on either side
+  hipStream_t cs = in_line ? (hipStream_t)stream : c->comm_stream;
+  if (!in_line)
+    if (int rc = fence_in(c, (hipStream_t)stream)) return rc;
   SMOE_NCCL(api->GroupStart(), "ncclGroupStart");
   for (int w = 0; w < c->world; ++w) {
-    SMOE_NCCL_IN_GROUP(api->Send(send_counts + (size_t)w * E_local, (size_t)E_local, ncclInt32, w, c->comm, c->comm_stream), "ncclSend");
-    SMOE_NCCL_IN_GROUP(api->Recv(recv_counts + (size_t)w * E_local, (size_t)E_local, ncclInt32, w, c->comm, c->comm_stream), "ncclRecv");
+    SMOE_NCCL_IN_GROUP(api->Send(send_counts + (size_t)w * E_local, (size_t)E_local, ncclInt32, w, c->comm, cs), "ncclSend");
+    SMOE_NCCL_IN_GROUP(api->Recv(recv_counts + (size_t)w * E_local, (size_t)E_local, ncclInt32, w, c->comm, cs), "ncclRecv");
   }
   SMOE_NCCL(api->GroupEnd(), "ncclGroupEnd");
+  if (in_line) return 0;
   if (int rc = fence_out(c)) return rc;
   if (wait) return smoe_a2a_wait(c, stream);
   return 0;
@@ -222,17 +226,21 @@ extern "C" int smoe_a2a_tokens(smoe_ctx* c, const void* send, const int64_t* sen
     SMOE_REQUIRE(send || send_rows[w] == 0, "smoe_a2a_tokens: null send buffer");
     SMOE_REQUIRE(recv || recv_rows[w] == 0, "smoe_a2a_tokens: null receive buffer");
   }
-  if (int rc = fence_in(c, (hipStream_t)stream)) return rc;
+  const bool in_line = wait == SMOE_A2A_INLINE;
+  hipStream_t cs = in_line ? (hipStream_t)stream : c->comm_stream;
+  if (!in_line)
+    if (int rc = fence_in(c, (hipStream_t)stream)) return rc;
   SMOE_NCCL(api->GroupStart(), "ncclGroupStart");
   size_t so = 0, ro = 0;
   for (int w = 0; w < c->world; ++w) {
     const size_t sb = (size_t)send_rows[w] * d * es, rb = (size_t)recv_rows[w] * d * es;
-    if (sb) SMOE_NCCL_IN_GROUP(api->Send((const char*)send + so, sb, ncclUint8, w, c->comm, c->comm_stream), "ncclSend");
-    if (rb) SMOE_NCCL_IN_GROUP(api->Recv((char*)recv + ro, rb, ncclUint8, w, c->comm, c->comm_stream), "ncclRecv");
+    if (sb) SMOE_NCCL_IN_GROUP(api->Send((const char*)send + so, sb, ncclUint8, w, c->comm, cs), "ncclSend");
+    if (rb) SMOE_NCCL_IN_GROUP(api->Recv((char*)recv + ro, rb, ncclUint8, w, c->comm, cs), "ncclRecv");
     so += sb;
     ro += rb;
   }
   SMOE_NCCL(api->GroupEnd(), "ncclGroupEnd");
+  if (in_line) return 0;
   if (int rc = fence_out(c)) return rc;
   if (wait) return smoe_a2a_wait(c, stream);
   return 0;

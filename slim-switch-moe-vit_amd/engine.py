@@ -30,6 +30,10 @@ def _speculative_alpha(value):
     return float(value) if value else None
 
 
+def _ep_world_size(model) -> int:
+    return max([int(getattr(m, "world_size", 1)) for m in model.modules() if hasattr(m, "ep_active")] or [1])
+
+
 class GraphedForward:
     """``model(images)`` under fp16 autocast / no_grad, replayed from ONE HIP graph per input shape.
 
@@ -41,19 +45,48 @@ class GraphedForward:
     profiles/r05_tiny_models.md.  One graph per (shape, dtype) of the input; the first call with a new shape runs two eager
     forwards (they fill every cache: 16-bit weight images, constant tables) and captures the third.  Host-side bookkeeping the
     captured kernels cannot do is replayed by hand: the token-skip gates' ``_total_tokens`` (the skipped-token counters live on
-    the device and are updated by the captured kernels themselves).  Not for expert-parallel models: hipStreamEndCapture dies on
-    RCCL kernels on this stack (tools/ep_graph_debug.py)."""
+    the device and are updated by the captured kernels themselves).
+
+    Expert-parallel models capture too when NOTHING of the forward needs the host: every MoE layer on the static exchange (ep.static_kind:
+    a capacity gate, or ep.set_speculative's slots) with its collectives posted on the compute stream itself (ep.exchange_inline: one
+    micro-batch, one chunk -- RCCL kernels inside a capture are fine, a cross-stream join around them is what hipStreamEndCapture
+    dies on on this stack: tools/ep_graph_debug.py).  The graph holds the slot tables it was captured with: after every replay the
+    routing histograms the captured kernels left on the device are queued for the overflow watch (ep.post_captured_stats), so an
+    overflow voids the step exactly as it does eagerly (ep.run_guarded repeats it on the counted exchange -- which this object runs
+    eagerly), and a re-sized table (overflow, or slots cut to the observed routing) re-captures.  Free the object before
+    torch.distributed.destroy_process_group(): tearing down a communicator whose kernels sit in a live graph hangs."""
 
     def __init__(self, model: torch.nn.Module, autocast: bool = True):
         self.model, self.autocast, self.graphs = model, autocast, {}
         self.failed = None       # the exception of a capture that did not work: from then on every call runs eagerly
+        self.captures = 0
+        self._ep = self._ep_mods(model)
 
     @staticmethod
-    def supported(model: torch.nn.Module, device) -> bool:
+    def _ep_mods(model):
+        return [m for m in model.modules() if hasattr(m, "ep_active") and m.ep_active()]
+
+    @staticmethod
+    def supported(model: torch.nn.Module, device, ep_graph: bool = True) -> bool:
+        """``ep_graph``: whether an expert-parallel model may be captured at all (evaluate(): "auto" = a group of ONE rank only -- no
+        run between distinct GPUs exists yet; hip_graph=True asks for it on any group)."""
         dev = torch.device(device)
         if dev.type != "cuda" or model.training:
             return False
-        return not any(getattr(m, "ep_active", lambda: False)() for m in model.modules() if hasattr(m, "ep_active"))
+        mods = GraphedForward._ep_mods(model)
+        if not mods:
+            return True
+        if not ep_graph or int(getattr(model, "ep_micro_batches", 1)) != 1:
+            return False
+        from . import ep
+        from .fmoe import default_compute_dtype
+        return all(ep.static_kind(m, m.compute_dtype or default_compute_dtype()) is not None
+                   and ep.exchange_inline(m, 1) for m in mods)
+
+    def _ep_signature(self):
+        """The slot tables the expert-parallel layers use right now (a graph is valid for exactly the tables it was captured with)."""
+        return tuple((getattr(m, "ep_speculative", None), getattr(m, "ep_static_tokens", None),
+                      tuple(id(st.table) for st in m.__dict__.get("_ep_slots", {}).values())) for m in self._ep)
 
     def _run(self, images):
         with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.float16, enabled=self.autocast):
@@ -71,27 +104,45 @@ class GraphedForward:
                 self._run(static_in)
         torch.cuda.current_stream(images.device).wait_stream(side)
         torch.cuda.synchronize(images.device)
+        if self._ep:
+            from . import ep
+            ep.check_static_overflow(flush=True)     # the warm-up's routing: may re-size the slots (or raise: the caller repeats the step)
         gates = self._gates()
         before = [g._total_tokens for g in gates]
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, **({"capture_error_mode": "relaxed"} if self._ep else {})):
             static_out = self._run(static_in)
         tokens = [(g, g._total_tokens - b) for g, b in zip(gates, before)]
         for g, b in zip(gates, before):       # the capture itself computed nothing: its host-side counts are taken back
             g._total_tokens = b
-        return static_in, graph, static_out, tokens
+        self.captures += 1
+        stats = ep.captured_stats(self.model) if self._ep else []
+        return static_in, graph, static_out, tokens, self._ep_signature(), stats
 
     def __call__(self, images: torch.Tensor) -> torch.Tensor:
         if self.failed is not None:
             return self._run(images)
+        if self._ep:
+            from . import ep
+            from .fmoe import default_compute_dtype
+            if ep.static_kind(self._ep[0], self._ep[0].compute_dtype or default_compute_dtype()) is None:
+                # the repeat of an overflowed step (ep.dynamic_only): on the counted exchange, eagerly
+                return self._run(images)
         key = (tuple(images.shape), images.dtype, str(images.device))
         ent = self.graphs.get(key)
+        if ent is not None and ent[4] != self._ep_signature():        # slots re-sized since: that graph's buffers have the old layout
+            ent = None
+            del self.graphs[key]
         if ent is None:
             gates = self._gates()
             before = [(g, g._total_tokens, g._skipped_tokens) for g in gates]   # the two warm-up forwards count for nothing
             try:
                 ent = self.graphs[key] = self._capture(images)
             except Exception as exc:      # a model the capture cannot take (a host sync in a foreign module, ...): say so, run eagerly
+                if self._ep and isinstance(exc, ep.StaticExchangeOverflow):
+                    for g, t, s in before:
+                        g._total_tokens, g._skipped_tokens = t, s
+                    raise
                 import warnings
                 self.failed = exc
                 torch.cuda.synchronize(images.device)
@@ -101,11 +152,13 @@ class GraphedForward:
                 g._total_tokens, g._skipped_tokens = t, s
             if self.failed is not None:
                 return self._run(images)
-        static_in, graph, static_out, tokens = ent
+        static_in, graph, static_out, tokens, _, stats = ent
         static_in.copy_(images)
         graph.replay()
         for g, n in tokens:
             g._total_tokens += n
+        if self._ep:
+            ep.post_captured_stats(stats)          # the replay's routing goes to the overflow watch like an eager forward's
         return static_out.clone()        # (the graph's own output buffer is overwritten by the next replay)
 
 
@@ -135,9 +188,10 @@ def evaluate(data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]], model: to
     if any(m.ep_active() for m in ep._ep_modules(model)):
         ep.set_speculative(model, _speculative_alpha(ep_speculative))
     import os
+    ep_graph = hip_graph is True or _ep_world_size(model) == 1     # (captured RCCL between distinct GPUs: only on request so far)
     if hip_graph == "auto":
         hip_graph = os.environ.get("SLIMMOE_EVAL_GRAPH", "1") != "0"
-    graphed = GraphedForward(model, autocast) if (hip_graph and GraphedForward.supported(model, dev)) else None
+    graphed = GraphedForward(model, autocast) if (hip_graph and GraphedForward.supported(model, dev, ep_graph)) else None
     n, loss_sum, a1, a5, repeats = 0, 0.0, 0.0, 0.0, 0
     t0 = time.perf_counter()
     for images, target in data_loader:

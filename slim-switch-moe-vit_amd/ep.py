@@ -63,8 +63,21 @@ class _CtxWork:
         return True
 
 
-def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None, async_op: bool = False):
-    """``dist.all_to_all_single`` on the group's own transport.  RCCL ("nccl") moves device buffers directly; a gloo
+def exchange_inline(mod, n_chunks: int = 1) -> bool:
+    """Whether this layer's exchanges go on the COMPUTE stream itself.  With one micro-batch and one chunk nothing runs beside an
+    exchange, so the communication stream buys no overlap and costs a stream hand-over on either side of each of the 2 x depth
+    collectives (~0.8 ms of 15.4 per forward on the one-GPU proxy).  SLIMMOE_EP_INLINE = auto (default) | 0 | 1."""
+    mode = os.environ.get("SLIMMOE_EP_INLINE", "auto")
+    if mode in ("0", "1"):
+        return mode == "1"
+    return n_chunks == 1 and max(1, int(getattr(mod, "ep_rows_div", 1))) == 1
+
+
+def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None, async_op: bool = False,
+         inline: bool = False):
+    """``dist.all_to_all_single`` on the group's own transport; ``inline`` = on the caller's stream (torch.distributed runs a
+    collective called with async_op=False on the current stream; the C-ABI transport has SMOE_A2A_INLINE), returning a finished
+    work handle where one was asked for.  RCCL ("nccl") moves device buffers directly; a gloo
     group cannot take CUDA tensors through all-to-all, so there the buffers are staged through the host -- slow, but
     it lets the complete multi-rank data path (routing, exchange layouts, group->expert GEMMs, the micro-batch
     pipeline) run as several processes on ONE GPU in tests/test_gpu_model.py."""
@@ -78,6 +91,9 @@ def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, 
             rows_in = rows_in.contiguous()
         sr = in_splits if in_splits is not None else [rows_in.shape[0] // W] * W
         rr = out_splits if out_splits is not None else [rows_out.shape[0] // W] * W
+        if inline:                                              # on the compute stream itself: no hand-over either side
+            ctx.all_to_all_rows(rows_in, sr, rr, wait="inline", out=rows_out)
+            return _DoneWork() if async_op else None
         ctx.all_to_all_rows(rows_in, sr, rr, wait=not async_op, out=rows_out)
         return _CtxWork(ctx, out) if async_op else None
     if inp.is_cuda and dist.get_backend(group) == "gloo":
@@ -85,6 +101,9 @@ def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, 
         h_out = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(h_out, h_in, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
         out.copy_(h_out)
+        return _DoneWork() if async_op else None
+    if inline:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group, async_op=False)
         return _DoneWork() if async_op else None
     return dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
                                   async_op=async_op)
@@ -220,12 +239,13 @@ def _group_expert_ids(W: int, E_local: int, device) -> torch.Tensor:
                            lambda: torch.arange(E_local, dtype=torch.int32, device=device).repeat(W))
 
 
-def all_to_all_rows(rows: torch.Tensor, send_rows: List[int], recv_rows: List[int], group=None, async_op: bool = False):
+def all_to_all_rows(rows: torch.Tensor, send_rows: List[int], recv_rows: List[int], group=None, async_op: bool = False,
+                    inline: bool = False):
     """all-to-all-v of whole rows: ``rows[:sum(send_rows)]`` is split by destination rank; returns
     (received [sum(recv_rows), d], work handle or None)."""
     n_send, n_recv = int(sum(send_rows)), int(sum(recv_rows))
     out = torch.empty((n_recv, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-    work = _a2a(out, rows[:n_send], [int(v) for v in recv_rows], [int(v) for v in send_rows], group, async_op)
+    work = _a2a(out, rows[:n_send], [int(v) for v in recv_rows], [int(v) for v in send_rows], group, async_op, inline)
     return out, work
 
 
@@ -499,6 +519,25 @@ def captured_overflow(model: torch.nn.Module) -> bool:
     return bad
 
 
+def captured_stats(model: torch.nn.Module):
+    """Right after capturing an expert-parallel forward: [(module, stats matrix in the graph's memory, slot state, caps)] of THAT graph."""
+    return [(m,) + tuple(m.__dict__["_ep_last_stats"]) for m in _ep_modules(model) if m.__dict__.get("_ep_last_stats") is not None]
+
+
+def post_captured_stats(entries) -> None:
+    """After replaying a captured expert-parallel forward (``entries`` = captured_stats() of that graph, or the model = its latest
+    capture): queue the stats matrices the replay left on the device for the overflow watch, judged against the slot tables of the
+    capture -- the same deferred, collective-free check an eager forward gets."""
+    if isinstance(entries, torch.nn.Module):
+        entries = captured_stats(entries)
+    for m, stats, st, caps in entries:
+        host = _pinned.take(stats.shape, stats.dtype)
+        host.copy_(stats, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _overflow_pending.append((ev, host, st, caps, _rows_div(m), True))
+
+
 def check_static_overflow(flush: bool = False) -> None:
     """Reads the stats matrices posted at least OVERFLOW_LAG exchanges ago (all of them with ``flush``: the harness calls that
     at the end of a step).  Every rank holds the SAME matrices and runs the same sequence of exchanges, so every rank takes the same
@@ -642,7 +681,8 @@ def _ep_forward_static(mod, x, src, idx, plan_idx, score, probs, cd, residual, n
     # the counts, this rank's row count and its whole routing histogram ride in the header rows; nobody on the host reads them
     ops.ep_pack_headers(send, counts, raw, tab.base_dev, T)
     recv = torch.empty((tab.recv_rows, d), dtype=cd, device=dev)
-    work = _a2a(recv, send, tab.out_splits, tab.in_splits, group, async_op=True)
+    inline = exchange_inline(mod)
+    work = _a2a(recv, send, tab.out_splits, tab.in_splits, group, async_op=True, inline=inline)
     yield                                                              # dispatch all-to-all in flight
     if work is not None:
         work.wait()
@@ -653,7 +693,7 @@ def _ep_forward_static(mod, x, src, idx, plan_idx, score, probs, cd, residual, n
     y = mod._experts_fwd(recv, starts, cd, out_dtype=cd, group_expert=gexp, group_end=ends,
                          rows_hint=(T if T > 0 else agreed) * k)
     back = torch.empty((tab.rows, d), dtype=cd, device=dev)
-    work2 = _a2a(back, y, tab.in_splits, tab.out_splits, group, async_op=True)
+    work2 = _a2a(back, y, tab.in_splits, tab.out_splits, group, async_op=True, inline=inline)
     yield                                                              # return all-to-all in flight
     if work2 is not None:
         work2.wait()
@@ -767,11 +807,12 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
     send_rows_c, recv_rows_c = pending.finish_rows()                     # the only host sync: [C][W] Python ints
 
     # stage A: dispatch all-to-all (async; chunk c+1 travels under chunk c's GEMMs)
+    inline = exchange_inline(mod, len(bounds))
     inflight = []
     for c, (t0, t1) in enumerate(bounds):
         send = sends[c]
         send_rows, recv_rows = send_rows_c[c], recv_rows_c[c]
-        recv, work = all_to_all_rows(send, send_rows, recv_rows, group, async_op=True)
+        recv, work = all_to_all_rows(send, send_rows, recv_rows, group, async_op=True, inline=inline)
         inflight.append((send, recv, work, send_rows, recv_rows))
     yield                                                                # (2) dispatch all-to-all in flight
     # stage B: expert FFN on the received rows + return all-to-all (async)
@@ -784,7 +825,7 @@ def ep_forward_steps(mod, x: torch.Tensor, cd: torch.dtype, residual: Optional[t
             y = mod._experts_fwd(recv, offs_dev[c], cd, out_dtype=cd, group_expert=gexp_dev)
         else:
             y = recv
-        back, work2 = all_to_all_rows(y, recv_rows, send_rows, group, async_op=True)
+        back, work2 = all_to_all_rows(y, recv_rows, send_rows, group, async_op=True, inline=inline)
         returning.append((y, back, work2))
     yield                                                                # (3) return all-to-all in flight
     # stage C: gather + combine in sender order

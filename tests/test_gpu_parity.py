@@ -834,8 +834,9 @@ def test_persistent_gemm_f32_epilogue_and_tile_orders_bitwise(N, K):
 def test_cabi_exchange_context_world_of_one_and_ep_transport():
     """include/slimmoe.h smoe_ctx_* / smoe_a2a_*: RCCL communicator from a unique-id blob, dedicated communication
     stream, event fences.  One GPU = a world of one rank (what hardware this box has): counts and rows come back
-    unchanged, blocking and split (wait=False + wait_stream) forms; then the expert-parallel forward on this
-    transport (SLIMMOE_EP_TRANSPORT=cabi) reproduces the torch.distributed transport bit for bit."""
+    unchanged, blocking, split (wait=False + wait_stream) and in-line (on the caller's stream) forms; then the expert-parallel
+    forward on this transport (SLIMMOE_EP_TRANSPORT=cabi, and with SLIMMOE_EP_INLINE=1) reproduces the torch.distributed
+    transport bit for bit."""
     import socket
     import torch.distributed as dist
     from slim_switch_moe_vit_amd.comm import ExchangeContext
@@ -873,6 +874,13 @@ def test_cabi_exchange_context_world_of_one_and_ep_transport():
             assert torch.equal(o, rows[:100 + i])
         with pytest.raises(Exception):
             ctx.wait_stream(rows, ctx.last_ticket() + 5)    # no such exchange
+        # SMOE_A2A_INLINE: on the caller's stream itself -- in order with the kernels either side, no ticket taken
+        t_before = ctx.last_ticket()
+        src = big.clone()
+        src.mul_(2)
+        inl = ctx.all_to_all_rows(src, [50000], [50000], wait="inline")
+        src.zero_()                                          # later on the same stream: must not reach the exchange
+        assert torch.equal(inl, big * 2) and ctx.last_ticket() == t_before
     finally:
         ctx.close()
     with socket.socket() as sk:
@@ -889,10 +897,13 @@ def test_cabi_exchange_context_world_of_one_and_ep_transport():
             os.environ["SLIMMOE_EP_TRANSPORT"] = "cabi"
             try:
                 got = mod(x.to(DEV))
+                os.environ["SLIMMOE_EP_INLINE"] = "1"
+                got_inline = mod(x.to(DEV))
             finally:
                 os.environ.pop("SLIMMOE_EP_TRANSPORT", None)
+                os.environ.pop("SLIMMOE_EP_INLINE", None)
         assert len(ep._ctx_cache) == 1, "the C-ABI transport must have been the one that ran"
-        assert torch.equal(got, ref)
+        assert torch.equal(got, ref) and torch.equal(got_inline, ref)
     finally:
         for c in ep._ctx_cache.values():
             c.close()

@@ -458,3 +458,23 @@ def test_harness_switch_parsing():
             os.environ["SLIMMOE_EP_ALPHA"] = old
     m = sm.create_model("moe_tiny_patch16_224_expert4_top1", depth=1, num_classes=10)
     assert not engine.GraphedForward.supported(m.eval(), "cpu")            # graphs are a GPU matter; CPU models run eagerly
+
+
+def test_exchange_inline_decision(monkeypatch):
+    """ep.exchange_inline: the exchanges go on the compute stream exactly when nothing could run beside them (one micro-batch, one
+    chunk); SLIMMOE_EP_INLINE = 0 / 1 overrides."""
+    from slim_switch_moe_vit_amd import ep
+
+    class M:
+        pass
+
+    m = M()
+    monkeypatch.delenv("SLIMMOE_EP_INLINE", raising=False)
+    assert ep.exchange_inline(m) and ep.exchange_inline(m, 1) and not ep.exchange_inline(m, 2)
+    m.ep_rows_div = 2
+    assert not ep.exchange_inline(m)
+    monkeypatch.setenv("SLIMMOE_EP_INLINE", "1")
+    assert ep.exchange_inline(m, 3)
+    monkeypatch.setenv("SLIMMOE_EP_INLINE", "0")
+    m.ep_rows_div = 1
+    assert not ep.exchange_inline(m)

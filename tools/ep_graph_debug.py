@@ -38,6 +38,36 @@ if what == "a2a":
     g.replay()
     torch.cuda.synchronize()
     print("replayed", bool(torch.equal(a, b)), flush=True)
+elif what in ("a2a_sync", "a2a_cabi_inline"):
+    # the collective posted on the CAPTURING stream itself (no cross-stream join inside the capture)
+    a = torch.randn(1024, 768, device=DEV).half()
+    b = torch.empty_like(a)
+    if what == "a2a_sync":
+        def go():
+            dist.all_to_all_single(b, a, async_op=False)
+    else:
+        from slim_switch_moe_vit_amd.comm import ExchangeContext
+        ctx = ExchangeContext(ExchangeContext.new_unique_id(), 1, 0, torch.device(DEV))
+
+        def go():
+            ctx.all_to_all_rows(a, [1024], [1024], wait="inline", out=b)
+    go()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        go()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    b.zero_()
+    print("capturing", what, flush=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="relaxed"):
+        go()
+    print("captured", flush=True)
+    g.replay()
+    torch.cuda.synchronize()
+    print("replayed", bool(torch.equal(a, b)), flush=True)
 else:
     from test_gpu_model import _init
     model = _init(sm.create_model("moe_base_patch16_224_expert8_top1", num_classes=100, depth=2), 23).eval().to(DEV)
@@ -62,10 +92,16 @@ else:
     ep.check_static_overflow(flush=True)
     print("capturing model", flush=True)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="relaxed"):
         out = step()
     print("captured", flush=True)
     g.replay()
     torch.cuda.synchronize()
     print("replayed", float((out.float() - eager).abs().max()), flush=True)
+g = None
+torch.cuda.synchronize()
+print("graph freed", flush=True)
+if os.environ.get("EP_GRAPH_DEBUG_HARD_EXIT", "0") == "1":   # (the process-group teardown after a captured collective is a probe of its own)
+    os._exit(0)
 dist.destroy_process_group()
+print("group destroyed", flush=True)

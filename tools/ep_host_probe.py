@@ -33,6 +33,7 @@ def main():
             return model(images)
 
     def measure(tag):
+        step = cell[0]
         for _ in range(3):
             ep.run_guarded(step)
         torch.cuda.synchronize()
@@ -48,6 +49,7 @@ def main():
             tag += " (OVERFLOWED)"
         print(f"{tag:34s} host enqueue {1e3 * (t1 - t0) / steps:7.3f} ms/step   wall {1e3 * (t2 - t0) / steps:7.3f} ms/step", flush=True)
 
+    cell = [step]
     for blk in model.blocks:
         blk.mlp.force_ep = False
     measure("single-rank path")
@@ -59,6 +61,26 @@ def main():
     measure("EP, speculative static exchange")
     measure("EP, speculative static (again)")
     print("slot rows per layer / routed rows:", [round(b.mlp.__dict__["_ep_slots"][1].table.rows / (256 * 197), 3) for b in model.blocks])
+    # the same static forward replayed from ONE HIP graph (engine.GraphedForward: the exchanges sit on the compute stream)
+    import slim_switch_moe_vit_amd as sm
+    if sm.GraphedForward.supported(model, dev):
+        gf = sm.GraphedForward(model)
+        eager = step().float()
+
+        cell[0] = lambda: gf(images)
+        measure("EP, static, HIP graph replay")
+        measure("EP, static, HIP graph (again)")
+        print("graph captures:", gf.captures, " failed:", gf.failed, " replay == eager:", bool(torch.equal(gf(images).float(), eager)))
+        gf = None
+    for blk in model.blocks:
+        blk.mlp.force_ep = False
+    if sm.GraphedForward.supported(model, dev):
+        gf = sm.GraphedForward(model)
+
+        cell[0] = lambda: gf(images)
+        measure("single-rank path, HIP graph")
+        gf = None
+    torch.cuda.synchronize()
     dist.destroy_process_group()
 
 
