@@ -76,17 +76,16 @@ class GraphedForward:
         mods = GraphedForward._ep_mods(model)
         if not mods:
             return True
-        if not ep_graph or int(getattr(model, "ep_micro_batches", 1)) != 1:
-            return False
         from . import ep
         from .fmoe import default_compute_dtype
-        return all(ep.static_kind(m, m.compute_dtype or default_compute_dtype()) is not None
-                   and ep.exchange_inline(m, 1) for m in mods)
+        if not ep_graph or int(getattr(model, "ep_micro_batches", 1)) > 1 or not ep.inline_possible(model):
+            return False
+        return all(ep.static_kind(m, m.compute_dtype or default_compute_dtype()) is not None for m in mods)
 
     def _ep_signature(self):
         """The slot tables the expert-parallel layers use right now (a graph is valid for exactly the tables it was captured with)."""
         return tuple((getattr(m, "ep_speculative", None), getattr(m, "ep_static_tokens", None),
-                      tuple(id(st.table) for st in m.__dict__.get("_ep_slots", {}).values())) for m in self._ep)
+                      tuple(st.table.serial for st in m.__dict__.get("_ep_slots", {}).values())) for m in self._ep)
 
     def _run(self, images):
         with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.float16, enabled=self.autocast):

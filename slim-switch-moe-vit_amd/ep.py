@@ -22,6 +22,7 @@ are exercised on CPU with the gloo backend in tests/test_ep_gloo.py.
 """
 from __future__ import annotations
 
+import itertools
 import os
 from typing import List, Optional, Tuple
 
@@ -71,6 +72,15 @@ def exchange_inline(mod, n_chunks: int = 1) -> bool:
     if mode in ("0", "1"):
         return mode == "1"
     return n_chunks == 1 and max(1, int(getattr(mod, "ep_rows_div", 1))) == 1
+
+
+def inline_possible(model: torch.nn.Module) -> bool:
+    """exchange_inline for every layer of the model's NEXT forward, from the model's own settings (``ep_rows_div`` on the modules is
+    what the previous forward left there)."""
+    mode = os.environ.get("SLIMMOE_EP_INLINE", "auto")
+    if mode in ("0", "1"):
+        return mode == "1"
+    return int(getattr(model, "ep_micro_batches", 1)) <= 1
 
 
 def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None, async_op: bool = False,
@@ -418,7 +428,10 @@ class _SlotTable:
     regions in expert order (so that the E_local regions of a destination rank are contiguous).  Host lists for the buffer shapes
     and the all-to-all splits, device tables for the plan / header kernels."""
 
+    _serials = itertools.count(1)
+
     def __init__(self, caps, rank: int, E_local: int, device):
+        self.serial = next(_SlotTable._serials)      # never re-used (an id() can be): what a captured forward is keyed on
         self.caps = [max(1, int(c)) for c in caps]
         E = len(self.caps)
         W = E // E_local

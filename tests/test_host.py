@@ -478,3 +478,14 @@ def test_exchange_inline_decision(monkeypatch):
     monkeypatch.setenv("SLIMMOE_EP_INLINE", "0")
     m.ep_rows_div = 1
     assert not ep.exchange_inline(m)
+    # the model-level form (what decides whether a forward can be captured) looks at the model's setting, not at what the previous
+    # forward left on the modules
+    model = M()
+    assert not ep.inline_possible(model)
+    monkeypatch.delenv("SLIMMOE_EP_INLINE")
+    assert ep.inline_possible(model)
+    model.ep_micro_batches = 2
+    assert not ep.inline_possible(model)
+    # slot tables carry a serial that is never re-used (a captured forward is keyed on it; id() of a freed table can come back)
+    a, b = ep._SlotTable([3, 4], 0, 2, "cpu"), ep._SlotTable([3, 4], 0, 2, "cpu")
+    assert b.serial > a.serial
