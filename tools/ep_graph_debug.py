@@ -1,5 +1,13 @@
 #!/usr/bin/env python3
-"""Debug probe: which piece of the world-of-one static EP forward survives HIP-graph capture (run under faulthandler)."""
+"""Debug probe: which piece of the world-of-one static EP forward survives HIP-graph capture (run under faulthandler).
+
+    python tools/ep_graph_debug.py a2a               all_to_all_single(async_op=True): RCCL's stream joined into the capture by events
+                                                     -> hipStreamEndCapture segfaults (torch 2.10 + rocm 7.0, RCCL 2.26.6)
+    python tools/ep_graph_debug.py a2a_sync          the same collective with async_op=False (on the capturing stream): captures, replays
+    python tools/ep_graph_debug.py a2a_cabi_inline   the library's own transport with SMOE_A2A_INLINE: captures, replays
+    python tools/ep_graph_debug.py model             two blocks of the bench model on the speculative static exchange (exchanges on the
+                                                     compute stream: ep.exchange_inline): captures, replays bit-exactly
+A live graph holding RCCL kernels makes destroy_process_group() hang: the graph is dropped first."""
 import faulthandler
 import os
 import sys
