@@ -332,10 +332,11 @@ int smoe_expert_ffn(const void* X, const int64_t* a_gather, int a_div, const voi
 /* smoe_grouped_gemm_gelu_keep: the first expert linear of the TRAINING forward (fmoe_cuda.linear_forward + the activation, whose
  * input autograd keeps): pre_out = A W^T + bias and out = gelu(pre_out), both [m_rows, N] in the operand dtype (f16 / bf16), from one
  * epilogue.  Returns -1 (no error set) for shapes outside the persistent kernel's reach (K % 64 != 0, operands >= 4 GiB, G > 63):
- * use smoe_grouped_gemm(SMOE_EPI_NONE) + smoe_gelu then.                                                                        */
+ * use smoe_grouped_gemm(SMOE_EPI_NONE) + smoe_gelu then.  group_end (optional, i32 [G]): separate row ranges [offsets[g], group_end[g])
+ * as in smoe_grouped_gemm -- the slots of the static expert exchange in training; rows outside the ranges are neither read nor written. */
 int smoe_grouped_gemm_gelu_keep(const void* A, const void* W, const float* bias, const int32_t* offsets,
-                                const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
-                                int ab_dtype, void* pre_out, void* out, void* stream);
+                                const int32_t* group_expert, const int32_t* group_end, int G, int n_experts, int64_t m_rows_max,
+                                int K, int N, int ab_dtype, void* pre_out, void* out, void* stream);
 
 /* ---- backward pieces (fmoe_cuda.linear_backward and the adjoints of scatter / gather) ---------
  * smoe_gelu:            dst = gelu_erf(src), n % 8 == 0 (training forward keeps the pre-activations)
@@ -345,7 +346,9 @@ int smoe_grouped_gemm_gelu_keep(const void* A, const void* W, const float* bias,
  * smoe_grouped_wgrad:   out[e] (f32 [R1,R2]) = PT[:, range e] @ QT[:, range e]^T   (PT [R1,Lp], QT [R2,Lp], 16-bit)
  * smoe_group_colsum:    out[e, c] = sum over expert e's rows of src[:, c]  (bias gradients); C % 4 == 0; two passes
  *                       (512-row chunk partials in `workspace`, then a per-expert sum in chunk order: deterministic);
- *                       n_rows_max >= offsets[E] sizes the launch                                                   */
+ *                       n_rows_max >= offsets[E] sizes the launch; group_end (optional, i32 [E]): expert e's rows are
+ *                       [offsets[e], group_end[e]) -- separate ranges (slots of the static expert exchange), n_rows_max >=
+ *                       the sum of their lengths                                                                        */
 int smoe_gelu(const void* src, void* dst, int dtype, int64_t n, void* stream);
 int smoe_rowdot(const void* dout, int dout_dtype, const void* y, int y_dtype, const int64_t* inv_pos,
                 int64_t n, int k, int d, float* dscore, void* stream);
@@ -380,9 +383,10 @@ int smoe_grouped_wgrad(const void* PT, const void* QT, int ab_dtype, const int32
 /* smoe_grouped_wgrad_rows: the same weight gradients as smoe_grouped_wgrad, straight from the token-major operands
  * (P [n_rows,R1], Q [n_rows,R2], f16 / bf16, expert-sorted rows; offsets i32 [E+1] = plain row ranges, any lengths):
  * out[e] (f32 [R1,R2]) = sum_{r in expert e} P[r,:]^T Q[r,:].  No transposed copies: the MFMA fragments are read
- * from LDS with transposing reads.  R1, R2 multiples of 8; zero16 = 16 zero bytes in device memory. */
-int smoe_grouped_wgrad_rows(const void* P, const void* Q, int ab_dtype, const int32_t* offsets, int E, int R1, int R2,
-                            const void* zero16, float* out, void* stream);
+ * from LDS with transposing reads.  R1, R2 multiples of 8; zero16 = 16 zero bytes in device memory.  group_end (optional, i32 [E]):
+ * expert e's rows are [offsets[e], group_end[e]) -- separate ranges; nothing behind group_end[e] is read. */
+int smoe_grouped_wgrad_rows(const void* P, const void* Q, int ab_dtype, const int32_t* offsets, const int32_t* group_end, int E,
+                            int R1, int R2, const void* zero16, float* out, void* stream);
 /* smoe_gate_wgrad: router weight gradient dWg [E, C] f32 = dl^T x, dl [n_rows, E] f32 (d loss / d logits), x [n_rows, C]
  * f32 / f16 / bf16; E <= 16, C % 4 == 0; HBM-bound two-pass weighted column sum (what torch's matmul backward of the gate
  * nn.Linear computes, models/resmoe_flop_hook.py:7-8 names that layer).  db (f32 [E], may be NULL) = column sums of dl, the gate
@@ -399,8 +403,8 @@ int smoe_gate_wgrad(const float* dl, const void* x, int x_dtype, int64_t n_rows,
 int smoe_zero_group_fold(const float* cs2, const float* cs1, const void* A, int a_dtype, const int32_t* offsets, const int32_t* gmap,
                          int E, int Z, int d, int h, int64_t n_rows, float* dW2, float* db2, float* db1, void* stream);
 size_t smoe_group_colsum_workspace_bytes(int64_t n_rows_max, int E, int C);
-int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int64_t n_rows_max, int C, float* out,
-                      void* workspace, size_t workspace_bytes, void* stream);
+int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, const int32_t* group_end, int E, int64_t n_rows_max, int C,
+                      float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- expert exchange (expert parallelism over RCCL / xGMI) ----------------------------------------------------------
  * Replaces fmoe_cuda.ensure_nccl / expert_exchange / global_scatter / global_gather (reached from

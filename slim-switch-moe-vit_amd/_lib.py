@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SLIMMOE_LIB: another build of the same sources (a diagnostic build, `make DIAG=-DSMOE_DIAG`, whose environment switches the
 # tools under tools/ use); the ABI and symbol checks below apply to it all the same
 LIB_PATH = os.environ.get("SLIMMOE_LIB") or os.path.join(_HERE, "libslimmoe_hip.so")
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 c_void_p, c_int, c_int64, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
 
@@ -43,8 +43,8 @@ SIGNATURES = {
     "smoe_pad_offsets": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "smoe_split_offsets": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "smoe_transpose_pad": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
-    "smoe_grouped_gemm_gelu_keep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int,
-                                            c_void_p, c_void_p, c_void_p]),
+    "smoe_grouped_gemm_gelu_keep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
+                                            c_int, c_void_p, c_void_p, c_void_p]),
     "smoe_switch_gate_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "smoe_gate_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "smoe_gate_ln_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_int,
@@ -56,11 +56,11 @@ SIGNATURES = {
     "smoe_switch_aux": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_transpose_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "smoe_grouped_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "smoe_grouped_wgrad_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "smoe_grouped_wgrad_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "smoe_gate_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
     "smoe_gate_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_group_colsum_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
-    "smoe_group_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "smoe_group_colsum": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "smoe_gather_combine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p,
                                     c_int, c_void_p]),
     "smoe_gather_combine_ln": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,

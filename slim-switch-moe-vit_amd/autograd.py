@@ -143,34 +143,43 @@ class _GroupFFN(torch.autograd.Function):
     """rows [n, d] in G groups (group g uses expert group_expert[g], or g) -> Y [n, d]."""
 
     @staticmethod
-    def forward(ctx, rows, w1, b1, w2, b2, mod, offsets, group_expert, drop_mask, zero_groups=0):
+    def forward(ctx, rows, w1, b1, w2, b2, mod, offsets, group_expert, drop_mask, zero_groups=0, group_end=None, rows_hint=None):
+        """``group_end`` (i32 [G]; ``offsets`` then holds the G starts): separate row ranges [offsets[g], group_end[g]) -- the slots of
+        the static expert exchange.  Rows outside the ranges (padding, header rows) are neither read nor written by any kernel of
+        the forward or the backward: Y / drows are garbage there, and nobody downstream reads them."""
         cd = rows.dtype
         ex = mod.experts
         w1c, w2c = ex.htoh4.weight_as(cd), ex.h4toh.weight_as(cd)
         Hp, A = ops.grouped_gemm_gelu_keep(rows, w1c, b1.detach().float() if b1 is not None else None, offsets,
-                                           group_expert=group_expert, variant=mod.gemm_variant)
+                                           group_expert=group_expert, variant=mod.gemm_variant, group_end=group_end)
         if drop_mask is not None:
             A = A * drop_mask
         Y = ops.grouped_gemm(A, w2c, b2.detach().float() if b2 is not None else None, offsets, ops.EPI_NONE, cd,
-                             variant=mod.gemm_variant, group_expert=group_expert)
+                             variant=mod.gemm_variant, group_expert=group_expert, group_end=group_end, rows_hint=rows_hint)
         ctx.mod = mod
         ctx.zero_groups = zero_groups
+        ctx.rows_hint = rows_hint
         ctx.has_b1, ctx.has_b2 = b1 is not None, b2 is not None
-        ctx.has_map, ctx.has_drop = group_expert is not None, drop_mask is not None
+        ctx.has_map, ctx.has_drop, ctx.has_end = group_expert is not None, drop_mask is not None, group_end is not None
+        if group_end is not None and zero_groups:
+            raise RuntimeError("_GroupFFN: zero-row groups and separate row ranges do not combine")
         ctx.save_for_backward(rows, Hp, A, offsets,
                               group_expert if group_expert is not None else torch.empty(0, device=rows.device),
-                              drop_mask if drop_mask is not None else torch.empty(0, device=rows.device))
+                              drop_mask if drop_mask is not None else torch.empty(0, device=rows.device),
+                              group_end if group_end is not None else torch.empty(0, device=rows.device))
         return Y
 
     @staticmethod
     def backward(ctx, dY):
-        rows, Hp, A, offsets, gmap, drop_mask = ctx.saved_tensors
+        rows, Hp, A, offsets, gmap, drop_mask, gend = ctx.saved_tensors
         mod = ctx.mod
         cd = rows.dtype
         gexp = gmap if ctx.has_map else None
+        gend = gend if ctx.has_end else None
+        hint = ctx.rows_hint
         ex = mod.experts
         E_local = ex.htoh4.weight.shape[0]
-        G = offsets.numel() - 1
+        G = offsets.numel() - 1 if gend is None else gend.numel()
         n = rows.shape[0]
         dY = dY.contiguous()
         # column sums (bias gradients) right behind the kernel that produced their operand, while it still sits in the 256-MB
@@ -178,20 +187,20 @@ class _GroupFFN(torch.autograd.Function):
         # weight-gradient GEMMs, which stream 600 MB through the cache first
         need_cs2 = ctx.has_b2 or bool(ctx.zero_groups)
         need_cs1 = ctx.has_b1
-        cs2 = ops.group_colsum(dY, offsets) if need_cs2 else None                        # [G, d]
+        cs2 = ops.group_colsum(dY, offsets, gend) if need_cs2 else None                  # [G, d]
         w2t = ex.h4toh.weight_t_as(cd)                                                   # [E, h, d]  (N = h, K = d)
         # dH = (dY W2) * gelu'(H) [* dropout mask]: gelu' rides in the dgrad GEMM's epilogue; the (elementwise, commuting)
         # dropout mask of the rare drop > 0 training configuration is one multiply behind it
         dH = ops.grouped_gemm(dY, w2t, None, offsets, ops.EPI_GELU_GRAD, cd, variant=mod.gemm_variant,
-                              group_expert=gexp, residual=Hp)
+                              group_expert=gexp, residual=Hp, group_end=gend, rows_hint=hint)
         if ctx.has_drop:
             dH = dH * drop_mask
-        cs1 = ops.group_colsum(dH, offsets) if need_cs1 else None                        # [G, h]
+        cs1 = ops.group_colsum(dH, offsets, gend) if need_cs1 else None                  # [G, h]
         drows = None
         if ctx.needs_input_grad[0]:                                                      # (dH's other reader, same reason)
             w1t = ex.htoh4.weight_t_as(cd)                                               # [E, d, h]  (N = d, K = h)
             drows = ops.grouped_gemm(dH, w1t, None, offsets, ops.EPI_NONE, cd, variant=mod.gemm_variant,
-                                     group_expert=gexp)
+                                     group_expert=gexp, group_end=gend, rows_hint=hint)
         # dW2[e] = dY_e^T A_e, dW1[e] = dH_e^T R_e straight from the token-major tensors (transposing LDS reads;
         # smoe_transpose_pad + smoe_grouped_wgrad is the older two-step form, kept in ops for A/B tests)
         Z = ctx.zero_groups
@@ -210,6 +219,11 @@ class _GroupFFN(torch.autograd.Function):
             # rank-1 terms into dW2 (in place) and the experts' bias gradients, one launch (smoe_zero_group_fold)
             db2, db1 = ops.zero_group_fold(cs2, cs1, A, offsets, gmap, E, dW2, want_b2=ctx.has_b2, want_b1=ctx.has_b1)
             G = E
+        elif gend is not None:
+            # separate row ranges (static expert exchange): one product per (source rank, local expert) slot, nothing read behind its end
+            dW1 = ops.grouped_wgrad_rows(dH, rows, offsets, group_end=gend)
+            dW2 = ops.grouped_wgrad_rows(dY, A, offsets, group_end=gend)
+            db2, db1 = (cs2 if ctx.has_b2 else None), cs1
         else:
             # (few, long groups at small widths -- DeiT-Tiny: 24 tiles -- are cut into pieces: ops.expert_wgrad_splits)
             S = ops.expert_wgrad_splits(G, dH.shape[1], rows.shape[1], dH.shape[0], dH.device)
@@ -221,7 +235,7 @@ class _GroupFFN(torch.autograd.Function):
             dW2, dW1 = dW2.view(-1, E_local, *dW2.shape[1:]).sum(0), dW1.view(-1, E_local, *dW1.shape[1:]).sum(0)
             db2 = db2.view(-1, E_local, db2.shape[1]).sum(0) if db2 is not None else None
             db1 = db1.view(-1, E_local, db1.shape[1]).sum(0) if db1 is not None else None
-        return drows, dW1, db1, dW2, db2, None, None, None, None, None
+        return drows, dW1, db1, dW2, db2, None, None, None, None, None, None, None
 
 
 class _GateLogits(torch.autograd.Function):
@@ -308,14 +322,16 @@ def _zero_row_routing(mod):
     return idx0, g_map, zero_ids
 
 
-def _route_train(mod, x, zero_rows=None, scatter_cd=None):
+def _route_train(mod, x, zero_rows=None, scatter_cd=None, slots=None):
     """HIP routing + the differentiable gate score; returns (score, counts, offsets, pos, inv_pos, group map | None, zero groups, S).
     ``scatter_cd``: also scatter the rows (compute dtype) -- S, else None; when the gate's logits carry a gradient the scatter and
     the gate linear are one autograd node (_GateScatter: one gradient for x, no add kernel).
     ``zero_rows`` (bool [T], NaiveGate only): tokens whose row is all zero (masked by the token-skip gate).  They get row groups of
     their own -- group E + j for their j-th choice -- that use the expert the gate bias sends every zero row to (the group ->
     expert map): same numbers as dispatching them with everybody else, but the experts' own groups stay balanced and the zero
-    groups' weight gradients are rank-1 (_GroupFFN.backward)."""
+    groups' weight gradients are rank-1 (_GroupFFN.backward).
+    ``slots`` (dict with "tab": ep._SlotTable, "agreed": rows the table was agreed for): the plan in the slot layout of the static
+    expert exchange (smoe_dispatch_plan_slots: pos has tab.rows entries, S is the send buffer); "counts" / "raw" come back in it."""
     from .fmoe import SwitchGate
 
     g = mod.gate
@@ -332,7 +348,17 @@ def _route_train(mod, x, zero_rows=None, scatter_cd=None):
                                                           want_probs=is_switch)
         cap = g.capacity(T)
         E = g.tot_expert
-        if zero_rows is not None and not is_switch and cap < 0 and E + k <= 63:
+        if slots is not None:
+            tab, agreed = slots["tab"], slots["agreed"]
+            if T <= agreed:
+                counts, offsets, _gend, pos, inv_pos, pruned, raw = ops.dispatch_plan_slots(idx, E, tab.base_dev, tab.rows, cap)
+            else:   # over the agreed size: the buffers keep their shape (the peers must not hang); reported by the overflow watch
+                counts, offsets, _gend, pos, inv_h, _pr, raw = ops.dispatch_plan_slots(idx[:agreed].contiguous(), E, tab.base_dev,
+                                                                                      tab.rows, cap)
+                inv_pos = torch.full((T * k,), -1, dtype=torch.int64, device=x.device)
+                inv_pos[: agreed * k].copy_(inv_h)
+            slots["counts"], slots["raw"] = counts, raw
+        elif zero_rows is not None and not is_switch and cap < 0 and E + k <= 63:
             _idx0, g_map, zero_ids = _zero_row_routing(mod)                                # (cached per gate-parameter version)
             idx_plan = torch.where(zero_rows.reshape(T, 1), zero_ids, idx)
             counts, offsets, pos, inv_pos, pruned = ops.dispatch_plan(idx_plan, E + k, cap)
@@ -379,9 +405,35 @@ def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row
     ep = mod.world_size > 1 or getattr(mod, "force_ep", False)
     if mod._drop_p > 0 and mod.training:
         zero_rows = None      # (the rank-1 form of the zero groups' gradients needs identical activation rows: no dropout behind GELU)
-    score, counts, offsets, pos, inv_pos, zmap, zero_groups, S = _route_train(mod, x, None if ep else zero_rows, scatter_cd=cd)
-    ex = mod.experts
+    slots = None
     if ep:
+        # A capacity gate's exchange has a static shape ("cfg 5 (capacity-bounded) can use fixed-size padded buffers ->
+        # no host sync"): the slot layout of the no-grad forward (ep._ep_forward_static), here with autograd nodes around it.  Decided
+        # from the configuration and the AGREED row count only, so every rank takes the same branch.
+        from . import ep as _ep
+        _ep.check_static_overflow()    # (deferred, deterministic: every rank reads the same stats matrices at the same call)
+        if _ep.static_kind(mod, cd) == "capacity":
+            agreed = _ep.static_slot_tokens(mod, T, x.device)
+            if _ep.static_plan_fits(mod, agreed):
+                if T == 0:
+                    raise RuntimeError("expert-parallel training: this rank has no rows -- its backward would never run and its peers' "
+                                       "gradient exchange would wait for it forever")
+                st = _ep._slot_state(mod, "capacity", agreed, x.device)
+                slots = {"tab": st.table, "agreed": agreed, "state": st}
+    score, counts, offsets, pos, inv_pos, zmap, zero_groups, S = _route_train(mod, x, None if ep else zero_rows, scatter_cd=cd,
+                                                                              slots=slots)
+    ex = mod.experts
+    if slots is not None:
+        tab = slots["tab"]
+        W, E_local = mod.world_size, mod.num_expert
+        # the counts, this rank's row count and its routing histogram ride in the header rows (nobody on the host reads them); S is
+        # the send buffer: the scatter's own output, its unused slots zero-filled
+        ops.ep_pack_headers(S, slots["counts"], slots["raw"], tab.base_dev, T)
+        rows = _AllToAll.apply(S, tab.in_splits, tab.out_splits, mod.moe_group)
+        starts, ends, stats = ops.ep_unpack_headers(rows, W, tab.lbase_dev, mod.gate.tot_expert)
+        _ep._watch_overflow(stats, slots["state"])
+        g_offsets, g_map, g_end = starts, _ep._group_expert_ids(W, E_local, x.device), ends
+    elif ep:
         from .ep import exchange_counts, segment_table
         lec, gec = exchange_counts([counts], mod.world_size, mod.moe_group)
         send_rows, recv_rows = lec[0].sum(1).tolist(), gec[0].sum(1).tolist()
@@ -395,9 +447,13 @@ def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row
     if mod._drop_p > 0 and mod.training:
         keep = 1.0 - mod._drop_p
         drop_mask = (torch.rand(rows.shape[0], mod.d_hidden, device=x.device) < keep).to(cd) / keep
+    if slots is None:
+        g_end = None
     Y = _GroupFFN.apply(rows, ex.htoh4.weight, ex.htoh4.bias, ex.h4toh.weight, ex.h4toh.bias, mod, g_offsets, g_map,
-                        drop_mask, zero_groups)
-    if ep:
+                        drop_mask, zero_groups, g_end, (T * k if slots is not None else None))
+    if slots is not None:
+        back = _AllToAll.apply(Y, slots["tab"].out_splits, slots["tab"].in_splits, mod.moe_group)
+    elif ep:
         back = _AllToAll.apply(Y, recv_rows, send_rows, mod.moe_group)
         if back.shape[0] < pos.numel():  # slots past the kept count carry no row
             back = torch.cat([back, back.new_zeros(pos.numel() - back.shape[0], d)], 0)

@@ -244,11 +244,13 @@ constexpr int CS_ROWS = 256;
 constexpr int CS_COLS = 256;    // slab of the router weight gradient below
 constexpr int CS_WAVES = 16;
 
-__device__ __forceinline__ bool colsum_find_chunk(const int32_t* __restrict__ offsets, int E, int chunk, int& e_out,
-                                                  int& r0, int& r1) {
+// (ends: optional i32 [E] -- group e's rows are [offsets[e], ends[e]) instead of [offsets[e], offsets[e + 1]): the slots of a static
+//  expert exchange, whose padding rows are never read)
+__device__ __forceinline__ bool colsum_find_chunk(const int32_t* __restrict__ offsets, const int32_t* __restrict__ ends, int E,
+                                                  int chunk, int& e_out, int& r0, int& r1) {
   int base = 0;
   for (int e = 0; e < E; ++e) {
-    const int lo = offsets[e], hi = offsets[e + 1];
+    const int lo = offsets[e], hi = ends ? ends[e] : offsets[e + 1];
     const int nc = (hi - lo + CS_ROWS - 1) / CS_ROWS;
     if (chunk < base + nc) {
       e_out = e;
@@ -263,7 +265,8 @@ __device__ __forceinline__ bool colsum_find_chunk(const int32_t* __restrict__ of
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(64 * CS_WAVES) void group_colsum_partial_kernel(const T* __restrict__ src,
-                                                                             const int32_t* __restrict__ offsets, int E, int C,
+                                                                             const int32_t* __restrict__ offsets,
+                                                                             const int32_t* __restrict__ ends, int E, int C,
                                                                              float* __restrict__ partial) {
   static_assert(VEC == 4 || (VEC == 8 && !std::is_same<T, float>::value), "16-byte loads at most");
   constexpr int SLAB = 64 * VEC;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(64 * CS_WAVES) void group_colsum_partial_kernel(con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * SLAB + lane * VEC;
   int e, r0, r1;
-  const bool have = colsum_find_chunk(offsets, E, (int)blockIdx.y, e, r0, r1);
+  const bool have = colsum_find_chunk(offsets, ends, E, (int)blockIdx.y, e, r0, r1);
   float a[VEC];
 #pragma unroll
   for (int q = 0; q < VEC; ++q) a[q] = 0.f;
@@ -318,14 +321,15 @@ __global__ __launch_bounds__(64 * CS_WAVES) void group_colsum_partial_kernel(con
 
 // one workgroup per (64-column slab, group): wave w adds the group's chunks w, w+4, ... (lane = column; two chains), the four meet in LDS
 __global__ __launch_bounds__(256) void group_colsum_final_kernel(const float* __restrict__ partial,
-                                                                 const int32_t* __restrict__ offsets, int C,
+                                                                 const int32_t* __restrict__ offsets,
+                                                                 const int32_t* __restrict__ ends, int C,
                                                                  float* __restrict__ out) {
   __shared__ float red[4][64];
   const int e = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   int base = 0;
-  for (int q = 0; q < e; ++q) base += (offsets[q + 1] - offsets[q] + CS_ROWS - 1) / CS_ROWS;
-  const int nc = (offsets[e + 1] - offsets[e] + CS_ROWS - 1) / CS_ROWS;
+  for (int q = 0; q < e; ++q) base += ((ends ? ends[q] : offsets[q + 1]) - offsets[q] + CS_ROWS - 1) / CS_ROWS;
+  const int nc = ((ends ? ends[e] : offsets[e + 1]) - offsets[e] + CS_ROWS - 1) / CS_ROWS;
   float a0 = 0.f, a1 = 0.f;
   if (c < C) {
     int k = wave;
@@ -590,8 +594,8 @@ extern "C" size_t smoe_group_colsum_workspace_bytes(int64_t n_rows_max, int E, i
   return (size_t)colsum_chunks(n_rows_max, E) * (size_t)C * 4;
 }
 
-extern "C" int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, int E, int64_t n_rows_max, int C,
-                                 float* out, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int smoe_group_colsum(const void* src, int dtype, const int32_t* offsets, const int32_t* group_end, int E,
+                                 int64_t n_rows_max, int C, float* out, void* workspace, size_t workspace_bytes, void* stream) {
   SMOE_REQUIRE(offsets && out && E >= 1 && C > 0 && C % 4 == 0 && n_rows_max >= 0, "smoe_group_colsum: bad arguments");
   SMOE_REQUIRE(n_rows_max == 0 || src, "smoe_group_colsum: null pointer");
   SMOE_REQUIRE(workspace && workspace_bytes >= smoe_group_colsum_workspace_bytes(n_rows_max, E, C),
@@ -606,13 +610,13 @@ extern "C" int smoe_group_colsum(const void* src, int dtype, const int32_t* offs
   return by_dtype(dtype, [&](auto* tag) {
     using T = std::remove_pointer_t<decltype(tag)>;
     if constexpr (std::is_same<T, float>::value) {
-      hipLaunchKernelGGL((group_colsum_partial_kernel<T, 4>), grid1, dim3(64 * CS_WAVES), 0, s, (const T*)src, offsets, E, C, partial);
+      hipLaunchKernelGGL((group_colsum_partial_kernel<T, 4>), grid1, dim3(64 * CS_WAVES), 0, s, (const T*)src, offsets, group_end, E, C, partial);
     } else {
-      if (wide) hipLaunchKernelGGL((group_colsum_partial_kernel<T, 8>), grid1, dim3(64 * CS_WAVES), 0, s, (const T*)src, offsets, E, C, partial);
-      else hipLaunchKernelGGL((group_colsum_partial_kernel<T, 4>), grid1, dim3(64 * CS_WAVES), 0, s, (const T*)src, offsets, E, C, partial);
+      if (wide) hipLaunchKernelGGL((group_colsum_partial_kernel<T, 8>), grid1, dim3(64 * CS_WAVES), 0, s, (const T*)src, offsets, group_end, E, C, partial);
+      else hipLaunchKernelGGL((group_colsum_partial_kernel<T, 4>), grid1, dim3(64 * CS_WAVES), 0, s, (const T*)src, offsets, group_end, E, C, partial);
     }
     SMOE_CHECK_LAUNCH("smoe_group_colsum/partial");
-    hipLaunchKernelGGL(group_colsum_final_kernel, grid2, dim3(256), 0, s, partial, offsets, C, out);
+    hipLaunchKernelGGL(group_colsum_final_kernel, grid2, dim3(256), 0, s, partial, offsets, group_end, C, out);
     SMOE_CHECK_LAUNCH("smoe_group_colsum/final");
     return 0;
   });

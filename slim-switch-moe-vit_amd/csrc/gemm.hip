@@ -666,10 +666,13 @@ __global__ __launch_bounds__(512, 2) void grouped_gemm_pp256(
     n0 = (rem / group_m) * TBN;
     m_end = m_rows;
     k_base = offsets[e];
-    nk = MODE == 2 ? (offsets[e + 1] - k_base + 63) / 64 : (offsets[e + 1] - k_base) / 64;
+    // MODE 2 takes separate row ranges [offsets[e], group_end[e]) through the `group_expert` argument, which a weight gradient has
+    // no other use for (the slots of a static expert exchange: the padding rows behind group_end are never read)
+    const int k_end = (MODE == 2 && group_expert) ? group_expert[e] : offsets[e + 1];
+    nk = MODE == 2 ? (k_end - k_base + 63) / 64 : (k_end - k_base) / 64;
     out += (int64_t)e * m_rows * N;
   }
-  const int k_hi = (MODE == 2) ? offsets[e + 1] : 0;  // MODE 2: first row past this expert's range
+  const int k_hi = (MODE == 2) ? (group_expert ? group_expert[e] : offsets[e + 1]) : 0;  // MODE 2: first row past this expert's range
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1231,8 +1234,8 @@ int launch_wgrad(const void* PT, const void* QT, const int32_t* offsets_pad, int
 
 // token-major weight gradient (MODE 2): P [n_rows, R1], Q [n_rows, R2] row-major, offsets = plain row ranges
 template <typename AB>
-int launch_wgrad_rows(const void* P, const void* Q, const int32_t* offsets, int E, int R1, int R2, const void* zero16,
-                      float* out, hipStream_t s) {
+int launch_wgrad_rows(const void* P, const void* Q, const int32_t* offsets, const int32_t* group_end, int E, int R1, int R2,
+                      const void* zero16, float* out, hipStream_t s) {
   // Tile height 256 or 320 output rows, whichever needs fewer cost-weighted rounds of workgroups: the static grid has E x
   // tm x tn equal tiles, e.g. ViT-B's dW1 [3072, 768] x 8 experts = 288 tiles of 256 rows (two rounds on 256 CUs, the
   // second one an eighth full) or 240 of 320 rows (one round).
@@ -1245,14 +1248,14 @@ int launch_wgrad_rows(const void* P, const void* Q, const int32_t* offsets, int 
     auto kern = grouped_gemm_pp256<AB, float, 0, 2, 5>;
     SMOE_ENSURE_SMEM(grouped_gemm_pp256<AB, float, 0, 2, 5>);
     hipLaunchKernelGGL(kern, dim3(E * tm5 * tn), dim3(512), smem, s, (const AB*)P, (const AB*)Q, (const float*)nullptr, offsets,
-                       (const int32_t*)nullptr, E, 0, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
+                       group_end, E, 0, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
                        (const float*)zero16, out, tn, tm5, R1, (const int64_t*)nullptr, 1);
   } else {
     const size_t smem = 2 * (size_t)(256 + TBN) * BK_BYTES;
     auto kern = grouped_gemm_pp256<AB, float, 0, 2>;
     SMOE_ENSURE_SMEM(grouped_gemm_pp256<AB, float, 0, 2>);
     hipLaunchKernelGGL(kern, dim3(E * tm4 * tn), dim3(512), smem, s, (const AB*)P, (const AB*)Q, (const float*)nullptr, offsets,
-                       (const int32_t*)nullptr, E, 0, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
+                       group_end, E, 0, R2, (int)SMOE_EPI_NONE, (const int64_t*)nullptr, (const float*)nullptr,
                        (const float*)zero16, out, tn, tm4, R1, (const int64_t*)nullptr, 1);
   }
   SMOE_CHECK_LAUNCH("smoe_grouped_wgrad_rows");
@@ -1485,8 +1488,8 @@ extern "C" int smoe_expert_ffn(const void* X, const int64_t* a_gather, int a_div
 // both in the operand dtype, from one epilogue of the persistent kernel.  Returns -1 when the shape is outside that kernel's
 // reach (K % 64, operands of 4 GiB and more, more than 63 row groups): the caller then runs SMOE_EPI_NONE + smoe_gelu.
 extern "C" int smoe_grouped_gemm_gelu_keep(const void* A, const void* W, const float* bias, const int32_t* offsets,
-                                           const int32_t* group_expert, int G, int n_experts, int64_t m_rows_max, int K, int N,
-                                           int ab_dtype, void* pre_out, void* out, void* stream) {
+                                           const int32_t* group_expert, const int32_t* group_end, int G, int n_experts,
+                                           int64_t m_rows_max, int K, int N, int ab_dtype, void* pre_out, void* out, void* stream) {
   SMOE_REQUIRE(offsets && G >= 1 && n_experts >= 1 && (group_expert || n_experts == G), "smoe_grouped_gemm_gelu_keep: bad groups");
   SMOE_REQUIRE(m_rows_max >= 0 && m_rows_max < (1ll << 31) && K > 0 && N > 0 && N % 8 == 0, "smoe_grouped_gemm_gelu_keep: bad sizes");
   SMOE_REQUIRE(ab_dtype == SMOE_F16 || ab_dtype == SMOE_BF16, "smoe_grouped_gemm_gelu_keep: 16-bit operands only");
@@ -1496,8 +1499,8 @@ extern "C" int smoe_grouped_gemm_gelu_keep(const void* A, const void* W, const f
   if (K % 64 != 0 || G > 63 || a_bytes >= (1ull << 32) || w_bytes >= (1ull << 32)) return -1;
   hipStream_t s = (hipStream_t)stream;
   if (ab_dtype == SMOE_F16)
-    return launch_ps<f16, f16, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1, nullptr, 0);
-  return launch_ps<bf16_bits, bf16_bits, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1, nullptr, 0);
+    return launch_ps<f16, f16, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1, group_end, 0);
+  return launch_ps<bf16_bits, bf16_bits, 5, false, true>(A, W, bias, offsets, group_expert, G, m_rows_max, K, N, SMOE_EPI_GELU, nullptr, nullptr, pre_out, out, 4, s, nullptr, 1, group_end, 0);
 }
 
 // Weight gradients of a grouped linear (fmoe_cuda.linear_backward's grad_W):
@@ -1519,13 +1522,15 @@ extern "C" int smoe_grouped_wgrad(const void* PT, const void* QT, int ab_dtype, 
 // Weight gradients straight from the token-major operands (no transposed copies):
 //   out[e] (f32 [R1,R2]) = sum over rows r of expert e of P[r, :]^T Q[r, :]     P [n_rows,R1], Q [n_rows,R2], 16-bit
 // offsets i32 [E+1] = the experts' row ranges (any lengths, empty allowed); zero16 = 16 bytes of zeros in device memory.
-extern "C" int smoe_grouped_wgrad_rows(const void* P, const void* Q, int ab_dtype, const int32_t* offsets, int E, int R1,
-                                       int R2, const void* zero16, float* out, void* stream) {
+// group_end (optional, i32 [E]): expert e's rows are [offsets[e], group_end[e]) -- separate ranges, nothing behind group_end[e] is read.
+extern "C" int smoe_grouped_wgrad_rows(const void* P, const void* Q, int ab_dtype, const int32_t* offsets,
+                                       const int32_t* group_end, int E, int R1, int R2, const void* zero16, float* out,
+                                       void* stream) {
   SMOE_REQUIRE(P && Q && offsets && out && zero16, "smoe_grouped_wgrad_rows: null pointer");
   SMOE_REQUIRE(E >= 1 && R1 >= 8 && R2 >= 8 && R1 % 8 == 0 && R2 % 8 == 0, "smoe_grouped_wgrad_rows: bad sizes E=%d R1=%d R2=%d", E, R1, R2);
   hipStream_t s = (hipStream_t)stream;
-  if (ab_dtype == SMOE_F16) return launch_wgrad_rows<f16>(P, Q, offsets, E, R1, R2, zero16, out, s);
-  if (ab_dtype == SMOE_BF16) return launch_wgrad_rows<bf16_bits>(P, Q, offsets, E, R1, R2, zero16, out, s);
+  if (ab_dtype == SMOE_F16) return launch_wgrad_rows<f16>(P, Q, offsets, group_end, E, R1, R2, zero16, out, s);
+  if (ab_dtype == SMOE_BF16) return launch_wgrad_rows<bf16_bits>(P, Q, offsets, group_end, E, R1, R2, zero16, out, s);
   smoe_set_error("smoe_grouped_wgrad_rows: operands must be f16 or bf16");
   return 1;
 }

@@ -888,7 +888,8 @@ def expert_ffn(X: torch.Tensor, W1: torch.Tensor, b1: Optional[torch.Tensor], W2
 
 
 def grouped_gemm_gelu_keep(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], offsets: torch.Tensor,
-                           group_expert: Optional[torch.Tensor] = None, variant: int = DEFAULT_GEMM_VARIANT):
+                           group_expert: Optional[torch.Tensor] = None, variant: int = DEFAULT_GEMM_VARIANT,
+                           group_end: Optional[torch.Tensor] = None):
     """(H, gelu(H)) with H = A W[e]^T + bias[e] per row group -- the first expert linear of the training forward, which keeps
     both (gelu' needs H, the second linear's weight gradient needs gelu(H)): one epilogue with two stores where the kernel
     has it, else the GEMM followed by the GELU pass."""
@@ -897,7 +898,9 @@ def grouped_gemm_gelu_keep(A: torch.Tensor, W: torch.Tensor, bias: Optional[torc
     _chk(offsets, "offsets", torch.int32, 1)
     M, K = A.shape
     E, N, _ = W.shape
-    G = offsets.numel() - 1
+    G = offsets.numel() - 1 if group_end is None else group_end.numel()
+    if group_end is not None:
+        _chk(group_end, "group_end", torch.int32, 1)
     if A.dtype in (torch.float16, torch.bfloat16) and W.shape[2] == K and (group_expert is not None or G == E):
         if bias is not None:
             _chk(bias, "bias", torch.float32, 2)
@@ -905,12 +908,15 @@ def grouped_gemm_gelu_keep(A: torch.Tensor, W: torch.Tensor, bias: Optional[torc
             _chk(group_expert, "group_expert", torch.int32, 1)
         pre = torch.empty((M, N), dtype=A.dtype, device=A.device)
         out = torch.empty((M, N), dtype=A.dtype, device=A.device)
-        rc = _lib.load().smoe_grouped_gemm_gelu_keep(_ptr(A), _ptr(W), _ptr(bias), _ptr(offsets), _ptr(group_expert), G, E, M, K, N,
-                                                     dtype_code(A.dtype), _ptr(pre), _ptr(out), _stream(A))
+        rc = _lib.load().smoe_grouped_gemm_gelu_keep(_ptr(A), _ptr(W), _ptr(bias), _ptr(offsets), _ptr(group_expert), _ptr(group_end),
+                                                     G, E, M, K, N, dtype_code(A.dtype), _ptr(pre), _ptr(out), _stream(A))
         if rc == 0:
             return pre, out
         if rc != -1:
             _lib.check(rc, "smoe_grouped_gemm_gelu_keep")
+    if group_end is not None:
+        raise RuntimeError("grouped_gemm_gelu_keep: separate row ranges (group_end) need the persistent kernel's shapes "
+                           "(16-bit operands, K % 64 == 0, <= 63 groups)")
     pre = grouped_gemm(A, W, bias, offsets, EPI_NONE, A.dtype, variant=variant, group_expert=group_expert)
     return pre, gelu(pre)
 
@@ -1102,8 +1108,10 @@ def _wgrad_rounds(E: int, R1: int, R2: int, cus: int) -> float:
     return min(c4, c5)
 
 
-def grouped_wgrad_rows(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor, allow_swap: bool = True) -> torch.Tensor:
+def grouped_wgrad_rows(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor, allow_swap: bool = True,
+                       group_end: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[e] (f32 [R1, R2]) = P[rows of e]^T @ Q[rows of e] from the token-major operands (no transposed copies).
+    ``group_end`` (i32 [G]): separate row ranges [offsets[g], group_end[g]) (``offsets`` then needs G entries only).
     The kernel's tile is taller (256 / 320 output rows) than wide along R1 only, so when the transposed problem needs fewer
     rounds of workgroups (ViT-B's dW2 [768, 3072]: 288 tiles = two rounds on 256 CUs; as [3072, 768]: 240 taller tiles = one)
     it is computed as Q^T P and transposed back by smoe_transpose_cast (one pass over the f32 result)."""
@@ -1111,7 +1119,12 @@ def grouped_wgrad_rows(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor, 
     _chk(Q, "Q", ndim=2)
     if P.dtype != Q.dtype or P.dtype not in (torch.float16, torch.bfloat16) or P.shape[0] != Q.shape[0]:
         raise RuntimeError("grouped_wgrad_rows: P and Q must be f16 / bf16 with the same row count")
-    E = offsets.numel() - 1
+    _chk(offsets, "offsets", torch.int32, 1)
+    if group_end is not None:
+        _chk(group_end, "group_end", torch.int32, 1)
+        if offsets.numel() < group_end.numel() or P.numel() >= 2 ** 32 or Q.numel() >= 2 ** 32:
+            raise RuntimeError("grouped_wgrad_rows: group_end needs an offsets entry per group and operands under 2^32 elements")
+    E = offsets.numel() - 1 if group_end is None else group_end.numel()
     R1, R2 = P.shape[1], Q.shape[1]
     if P.numel() >= 2 ** 32 or Q.numel() >= 2 ** 32:
         # the token-major kernel addresses its operands with 32-bit ELEMENT offsets (csrc/gemm.hip MODE 2): an operand of
@@ -1122,9 +1135,9 @@ def grouped_wgrad_rows(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor, 
     if allow_swap and R1 % 64 == 0 and R2 % 64 == 0:
         cus = torch.cuda.get_device_properties(P.device).multi_processor_count
         if _wgrad_rounds(E, R2, R1, cus) + 0.15 < _wgrad_rounds(E, R1, R2, cus):
-            return transpose_cast(grouped_wgrad_rows(Q, P, offsets, allow_swap=False), torch.float32)
+            return transpose_cast(grouped_wgrad_rows(Q, P, offsets, allow_swap=False, group_end=group_end), torch.float32)
     out = torch.empty((E, R1, R2), dtype=torch.float32, device=P.device)
-    rc = _lib.load().smoe_grouped_wgrad_rows(_ptr(P), _ptr(Q), dtype_code(P.dtype), _ptr(offsets), E, R1, R2,
+    rc = _lib.load().smoe_grouped_wgrad_rows(_ptr(P), _ptr(Q), dtype_code(P.dtype), _ptr(offsets), _ptr(group_end), E, R1, R2,
                                               _ptr(_zero16(P.device)), _ptr(out), _stream(P))
     _lib.check(rc, "smoe_grouped_wgrad_rows")
     return out
@@ -1191,16 +1204,22 @@ def zero_group_fold(cs2: torch.Tensor, cs1: Optional[torch.Tensor], A: torch.Ten
     return db2, db1
 
 
-def group_colsum(src: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
-    """out[e, c] = sum of the rows of group e (bias gradients); deterministic two-pass reduction."""
+def group_colsum(src: torch.Tensor, offsets: torch.Tensor, group_end: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[e, c] = sum of the rows of group e (bias gradients); deterministic two-pass reduction.  ``group_end`` (i32 [G]): separate
+    row ranges [offsets[g], group_end[g]) -- ``offsets`` then needs G entries only."""
     _chk(src, "src", ndim=2)
-    E = offsets.numel() - 1
+    _chk(offsets, "offsets", torch.int32, 1)
+    if group_end is not None:
+        _chk(group_end, "group_end", torch.int32, 1)
+        if offsets.numel() < group_end.numel():
+            raise RuntimeError("group_colsum: offsets must have an entry per group")
+    E = offsets.numel() - 1 if group_end is None else group_end.numel()
     n, C = src.shape
     lib = _lib.load()
     out = torch.empty((E, C), dtype=torch.float32, device=src.device)
     ws_bytes = lib.smoe_group_colsum_workspace_bytes(n, E, C)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=src.device)
-    rc = lib.smoe_group_colsum(_ptr(src), dtype_code(src.dtype), _ptr(offsets), E, n, C, _ptr(out), _ptr(ws), ws_bytes,
-                               _stream(src))
+    rc = lib.smoe_group_colsum(_ptr(src), dtype_code(src.dtype), _ptr(offsets), _ptr(group_end), E, n, C, _ptr(out), _ptr(ws),
+                               ws_bytes, _stream(src))
     _lib.check(rc, "smoe_group_colsum")
     return out

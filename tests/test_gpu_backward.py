@@ -167,8 +167,12 @@ def test_expert_parallel_training_path_on_one_gpu():
     try:
         T, d, h, E = 900, 128, 256, 4
         x, wg, bg, w1, b1, w2, b2, gout = _params(T, d, h, E, seed=5, skew=True)
+        from slim_switch_moe_vit_amd import ep
+        import contextlib
         grads = {}
-        for mode in ("single", "ep"):
+        # "ep": the capacity gate's STATIC exchange (fixed slots, counts in-band, no host round trip: SURVEY.md 8e on cfg 5), with
+        # autograd around it; "ep_counted": the count exchange + all-to-all-v
+        for mode in ("single", "ep", "ep_counted"):
             mod = sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=1, gate="switch", capacity_factor=1.0).to(DEV)
             mod.gate.switch_eps = 0.0
             with torch.no_grad():
@@ -176,13 +180,20 @@ def test_expert_parallel_training_path_on_one_gpu():
                 mod.experts.htoh4.weight.copy_(w1); mod.experts.htoh4.bias.copy_(b1)
                 mod.experts.h4toh.weight.copy_(w2); mod.experts.h4toh.bias.copy_(b2)
             mod.train()
-            mod.force_ep = mode == "ep"
+            mod.force_ep = mode != "single"
             xg = x.to(DEV).requires_grad_(True)
-            out = mod(xg)
-            ((out * gout.to(DEV)).sum() + 2.0 * mod.gate.get_loss()).backward()
+            with (ep.dynamic_only() if mode == "ep_counted" else contextlib.nullcontext()):
+                assert mode == "single" or (ep.static_kind(mod, torch.float16) == "capacity") == (mode == "ep")
+                out = mod(xg)
+                ((out * gout.to(DEV)).sum() + 2.0 * mod.gate.get_loss()).backward()
             grads[mode] = [out.detach(), xg.grad] + [p.grad for p in mod.parameters()]
+        ep.check_static_overflow(flush=True)
         for a, b in zip(grads["single"], grads["ep"]):
             assert _rel(b.cpu(), a.cpu()) < 1e-3
+        worst = max(_rel(b.cpu(), a.cpu()) for a, b in zip(grads["ep_counted"], grads["ep"]))
+        print("static vs counted exchange, training step: worst rel-L2", worst,
+              "bit-identical" if all(torch.equal(a, b) for a, b in zip(grads["ep_counted"], grads["ep"])) else "")
+        assert worst == 0.0      # the same rows in the same groups through the same kernels: bit-identical
     finally:
         dist.destroy_process_group()
 
@@ -203,7 +214,7 @@ def test_block_level_training_step_runs():
     assert m.blocks[0].mlp.experts.htoh4.weight.grad is not None
 
 
-def _two_rank_train_worker(rank, world, port, q):
+def _two_rank_train_worker(rank, world, port, q, gate="naive"):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -214,7 +225,7 @@ def _two_rank_train_worker(rank, world, port, q):
         d, h, E = 128, 256, 4
         E_local = E // world
         T = [700, 433]
-        _, wg, bg, w1, b1, w2, b2, _ = _params(1, d, h, E, seed=21)
+        _, wg, bg, w1, b1, w2, b2, _ = _params(1, d, h, E, seed=21, skew=(gate == "switch"))
         xs = [torch.randn(T[r], d, generator=_gen(30 + r)) for r in range(world)]
         gs = [torch.randn(T[r], d, generator=_gen(40 + r)) for r in range(world)]
 
@@ -225,8 +236,15 @@ def _two_rank_train_worker(rank, world, port, q):
                 mod.experts.h4toh.weight.copy_(w2[sl]); mod.experts.h4toh.bias.copy_(b2[sl])
             return mod.to(DEV).train()
 
+        def make(n_exp, ws):
+            if gate == "switch":   # BASELINE cfg 5's gate: capacity 1.0 of the rank's own batch, tokens dropped -> the STATIC exchange
+                m = sm.FMoETransformerMLP(n_exp, d, h, torch.nn.GELU(), top_k=1, gate="switch", capacity_factor=1.0, world_size=ws)
+                m.gate.switch_eps = 0.0
+                return m
+            return sm.FMoETransformerMLP(n_exp, d, h, torch.nn.GELU(), top_k=2, world_size=ws)
+
         # reference: one rank holding all experts, both shards (expert gradients add up over the shards)
-        full = load(sm.FMoETransformerMLP(E, d, h, torch.nn.GELU(), top_k=2), slice(0, E))
+        full = load(make(E, 1), slice(0, E))
         ref_dx, ref_out, ref_gate = {}, {}, {}
         for r in range(world):
             full.gate.gate.weight.grad = None
@@ -238,10 +256,15 @@ def _two_rank_train_worker(rank, world, port, q):
             ref_gate[r] = (full.gate.gate.weight.grad.clone(), full.gate.gate.bias.grad.clone())
         # this rank of the expert-parallel pair
         sl = slice(rank * E_local, (rank + 1) * E_local)
-        part = load(sm.FMoETransformerMLP(E_local, d, h, torch.nn.GELU(), top_k=2, world_size=world), sl)
+        part = load(make(E_local, world), sl)
         xg = xs[rank].to(DEV).requires_grad_(True)
+        from slim_switch_moe_vit_amd import ep
+        static = ep.static_kind(part, torch.float16) == "capacity"
+        assert static == (gate == "switch")
         out = part(xg)
         (out * gs[rank].to(DEV)).sum().backward()
+        ep.check_static_overflow(flush=True)
+        dropped = int((part.last_plan[5] < 0).sum())
         errs = {
             "out": _rel(out.detach().cpu(), ref_out[rank].cpu()),
             "dx": _rel(xg.grad.cpu(), ref_dx[rank].cpu()),
@@ -251,16 +274,20 @@ def _two_rank_train_worker(rank, world, port, q):
             "dW2": _rel(part.experts.h4toh.weight.grad.cpu(), full.experts.h4toh.weight.grad[sl].cpu()),
             "db2": _rel(part.experts.h4toh.bias.grad.cpu(), full.experts.h4toh.bias.grad[sl].cpu()),
         }
+        if gate == "switch":
+            assert dropped > 0, "the capacity must have dropped tokens for this test to mean anything"
         q.put((rank, errs))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_expert_parallel_ranks_training_step_on_one_gpu():
+@pytest.mark.parametrize("gate", ["naive", "switch"])
+def test_two_expert_parallel_ranks_training_step_on_one_gpu(gate):
     """fwd + bwd of the MoE operator across TWO expert-parallel ranks (two processes on one GPU, gloo transport):
     outputs, dx and the router gradient of every rank match the single-rank operator on that rank's tokens, and each
     rank's expert weight / bias gradients are the single-rank gradients (summed over both ranks' tokens) of the
-    experts it owns."""
+    experts it owns.  "naive": top-2 NaiveGate on the counted exchange; "switch": cfg 5's capacity gate on the static exchange
+    (fixed slots, counts in-band, ragged ranks: 700 / 433 rows against slots agreed for the larger one)."""
     import socket
     import torch.multiprocessing as mp
 
@@ -269,7 +296,7 @@ def test_two_expert_parallel_ranks_training_step_on_one_gpu():
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_train_worker, args=(r, 2, port, q, gate)) for r in range(2)]
     for p in procs:
         p.start()
     from _mp import join_or_kill
@@ -380,6 +407,46 @@ def test_grouped_gemm_gelu_keep_matches_the_two_step_form(counts, K, N, dtype):
     assert (act.float() - ref_act.float()).abs().max().item() <= tol * max(1.0, float(ref_act.float().abs().max()))
     fused = ops.grouped_gemm(A, W, b, offsets, ops.EPI_GELU, dtype, variant=10)
     assert torch.equal(act, fused)   # the same epilogue arithmetic as the inference kernel's
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_backward_kernels_on_separate_row_ranges_never_touch_the_padding(dtype):
+    """group_end (the slots of the static expert exchange in training): weight gradient, bias-gradient column sums and the
+    H / gelu(H) forward take row ranges [starts[g], ends[g]) with gaps between them -- the same bits as on the compacted rows, with NaN in
+    every row outside the ranges (padding and header rows of a received buffer are never read)."""
+    counts = [700, 0, 513, 64, 1, 320]                   # rows in use per slot
+    slot = [800, 7, 513, 100, 130, 321]                  # slot sizes (payload + header rows): gaps of 100, 7, 0, 36, 129, 1 rows
+    G, K, N = len(counts), 128, 256
+    starts = np.concatenate([[0], np.cumsum(slot)])[:-1].astype(np.int32)
+    ends = (starts + np.array(counts)).astype(np.int32)
+    n_pad = int(sum(slot))
+    g = _gen(77)
+    X = (torch.randn(n_pad, K, generator=g) * 0.5).to(dtype)
+    dY = (torch.randn(n_pad, N, generator=g) * 0.5).to(dtype)
+    keep = torch.zeros(n_pad, dtype=torch.bool)
+    for s0, e0 in zip(starts, ends):
+        keep[s0:e0] = True
+    X[~keep] = float("nan")
+    dY[~keep] = float("nan")
+    Xc, dYc = X[keep].contiguous().to(DEV), dY[keep].contiguous().to(DEV)
+    offs_c = torch.tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device=DEV)
+    st, en = torch.from_numpy(starts).to(DEV), torch.from_numpy(ends).to(DEV)
+    X, dY = X.to(DEV), dY.to(DEV)
+    # weight gradient (both orientations: the second is computed transposed where that needs fewer rounds)
+    for P, Q, Pc, Qc in ((dY, X, dYc, Xc), (X, dY, Xc, dYc)):
+        got = ops.grouped_wgrad_rows(P, Q, st, group_end=en)
+        ref = ops.grouped_wgrad_rows(Pc, Qc, offs_c)
+        assert torch.isfinite(got).all() and torch.equal(got, ref)
+    # column sums
+    got = ops.group_colsum(dY, st, en)
+    assert torch.isfinite(got).all() and torch.equal(got, ops.group_colsum(dYc, offs_c))
+    # the training forward's first linear: H and gelu(H) inside the ranges
+    W = (torch.randn(G, N, K, generator=g) * 0.05).to(dtype).to(DEV)
+    b = (torch.randn(G, N, generator=g) * 0.1).to(DEV)
+    pre, act = ops.grouped_gemm_gelu_keep(X, W, b, st, group_end=en)
+    pre_c, act_c = ops.grouped_gemm_gelu_keep(Xc, W, b, offs_c)
+    km = keep.to(DEV)
+    assert torch.equal(pre[km], pre_c) and torch.equal(act[km], act_c)
 
 
 @pytest.mark.parametrize("T,E", [(1, 8), (1000, 8), (4097, 16), (333, 27)])

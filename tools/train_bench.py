@@ -3,7 +3,9 @@
 aux loss, (a) for ONE MoE layer at ViT-B dims (T = images x 197 rows) and (b) for the whole ViT-B/16 E=8 model.
 usage: train_bench.py [layer|model] [images] [iters] [model name]     (run under rocprofv3 --kernel-trace --stats for the per-kernel table)
 model name: default moe_base_patch16_224_expert8_top1 with the SwitchGate (cfg 5); a resmoe_* name = the reference's live block
-(token-skip gates, residual on the normed activations, naive gate; thresholds set so that ~40 % of the tokens skip)."""
+(token-skip gates, residual on the normed activations, naive gate; thresholds set so that ~40 % of the tokens skip).
+TRAIN_BENCH_EP=static|counted (model mode): the step through the EXPERT-PARALLEL code path on a one-rank RCCL group -- cfg 5's capacity
+gate on the static exchange (fixed slots, counts in-band, no host round trip) or on the counted one (a count read-back per layer)."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -73,6 +75,17 @@ else:
         model = model.to(dev)
     else:
         model = sm.create_model(name, num_classes=1000, gate="switch", capacity_factor=1.0).to(dev)
+    ep_mode = os.environ.get("TRAIN_BENCH_EP")
+    if ep_mode:
+        import contextlib
+        import torch.distributed as dist
+        from slim_switch_moe_vit_amd import ep
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29591", rank=0, world_size=1, device_id=dev)
+        for m in model.modules():
+            if isinstance(m, sm.FMoETransformerMLP):
+                m.force_ep = True
+        ep.set_static_tokens(model, images * 197, 197)
     model.train()
     opt = smo.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
     scaler = smo.NativeScaler()
@@ -91,6 +104,22 @@ else:
         opt.zero_grad()
         scaler(loss, opt, clip_grad=1.0, parameters=model.parameters())
 
+    if ep_mode:
+        calls = {"n": 0}
+        orig_counts = ep.exchange_counts
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return orig_counts(*a, **k)
+        ep.exchange_counts = counting
+        with (ep.dynamic_only() if ep_mode == "counted" else contextlib.nullcontext()):
+            t = timed(train_step, iters)
+            ep.check_static_overflow(flush=True)
+        print(f"{name} train step through the expert-parallel path ({ep_mode} exchange, one-rank group), batch {images}: {t:.2f} ms = "
+              f"{images / t * 1e3:.0f} images/s; count exchanges with a host read-back: {calls['n'] / (iters + 3):.1f} per step", flush=True)
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        sys.exit(0)
     t = timed(train_step, iters)
     if os.environ.get("TRAIN_BENCH_GRAPH"):
         # the WHOLE step (forward, backward, clip, AdamW, loss-scale update: no host sync anywhere) captured into one HIP graph and
