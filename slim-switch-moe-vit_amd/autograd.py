@@ -409,16 +409,19 @@ def moe_forward_train(mod, inp: torch.Tensor, residual: torch.Tensor = None, row
     if ep:
         # A capacity gate's exchange has a static shape ("cfg 5 (capacity-bounded) can use fixed-size padded buffers ->
         # no host sync"): the slot layout of the no-grad forward (ep._ep_forward_static), here with autograd nodes around it.  Decided
-        # from the configuration and the AGREED row count only, so every rank takes the same branch.
+        # from the configuration and the AGREED row count only, so every rank takes the same branch.  A gate without a capacity takes
+        # it speculatively when the harness that owns the step asked for it (rows that do not fit a slot are dropped here and the
+        # forward is void: engine.train_one_epoch reads the report before the backward and repeats the forward).
         from . import ep as _ep
         _ep.check_static_overflow()    # (deferred, deterministic: every rank reads the same stats matrices at the same call)
-        if _ep.static_kind(mod, cd) == "capacity":
+        kind = _ep.static_kind(mod, cd)      # "capacity", or "speculative" where the training harness opted in (set_speculative)
+        if kind is not None:
             agreed = _ep.static_slot_tokens(mod, T, x.device)
             if _ep.static_plan_fits(mod, agreed):
                 if T == 0:
                     raise RuntimeError("expert-parallel training: this rank has no rows -- its backward would never run and its peers' "
                                        "gradient exchange would wait for it forever")
-                st = _ep._slot_state(mod, "capacity", agreed, x.device)
+                st = _ep._slot_state(mod, kind, agreed, x.device)
                 slots = {"tab": st.table, "agreed": agreed, "state": st}
     score, counts, offsets, pos, inv_pos, zmap, zero_groups, S = _route_train(mod, x, None if ep else zero_rows, scatter_cd=cd,
                                                                               slots=slots)

@@ -349,7 +349,7 @@ def _criterion_takes_inputs(criterion) -> bool:
 def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tuple[torch.Tensor, torch.Tensor]],
                     optimizer: torch.optim.Optimizer, device, epoch: int, loss_scaler, max_norm=None, model_ema=None,
                     mixup_fn=None, set_training_mode=True, args=None, *, aux_loss_weight: float = 0.0, gate_delta=None,
-                    autocast: bool = True, check_every: int = 50, hip_graph=False):
+                    autocast: bool = True, check_every: int = 50, hip_graph=False, ep_speculative="auto"):
     """The reference's training loop body (engine.py:22-85) around the HIP path, with the reference's positional
     parameters in the reference's order (main.py:825-838 calls it positionally: ``model_ema`` and ``mixup_fn`` sit in
     positions 9 and 10): autocast forward, criterion, ``loss_scaler(loss, optimizer, clip_grad=max_norm,
@@ -362,7 +362,11 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
     ``gate_delta`` runs the token-skip gates' threshold schedule (``Gate.step(delta)`` for every gate, as main.py:887-891
     does after the epoch's steps); ``autocast``; ``hip_graph`` (default False; True, or "auto" = SLIMMOE_TRAIN_GRAPH=1): the whole step
     replayed from one HIP graph per batch shape (GraphedTrainStep: needs this package's AdamW + NativeScaler, one rank, no EMA; 2 x on
-    the reference's DeiT-Tiny model, nothing on ViT-B) -- anything it cannot take runs eagerly, as before.
+    the reference's DeiT-Tiny model, nothing on ViT-B) -- anything it cannot take runs eagerly, as before; ``ep_speculative`` (under
+    expert parallelism; alpha, "auto" = SLIMMOE_EP_ALPHA, None / 0 = off): gates WITHOUT a capacity (the reference's NaiveGate) train on
+    the speculative static exchange -- no host round trip per layer; the forward's overflow report is read once, before the backward,
+    and a forward whose routing did not fit its slots is repeated on the counted exchange by all ranks together (capacity gates are on
+    the static exchange anyway: their slots cannot overflow).
 
     The reference aborts on a non-finite loss by reading ``loss.item()`` in every step (engine.py:56-60: one host sync per
     step), BEFORE the optimizer step and the EMA update.  Here the check is a device-side count read every ``check_every`` steps
@@ -392,47 +396,68 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
     graphed = None
     if hip_graph and not every_step and GraphedTrainStep.supported(model, optimizer, loss_scaler, dev, model_ema):
         graphed = GraphedTrainStep(model, criterion, optimizer, loss_scaler, max_norm, with_inputs, aux_loss_weight, autocast)
-    for samples, targets in data_loader:
-        samples = samples.to(dev, non_blocking=True)
-        targets = targets.to(dev, non_blocking=True)
-        if mixup_fn is not None:
-            samples, targets = mixup_fn(samples, targets)
-        if bce:
-            targets = targets.gt(0.0).type(targets.dtype)
-        if graphed is not None:
-            # (an enabled optim.NativeScaler skips a non-finite step on the device by itself: the abort can wait for check_every)
-            lv = graphed(samples, targets)
+    from . import ep as _ep
+    ep_spec, ep_repeats = False, 0
+    if any(m.ep_active() for m in _ep._ep_modules(model)):
+        alpha = _speculative_alpha(ep_speculative)
+        ep_spec = bool(alpha) and _ep.set_speculative(model, alpha, train=True) > 0
+        if not alpha:
+            _ep.set_speculative(model, None)
+    try:
+        for samples, targets in data_loader:
+            samples = samples.to(dev, non_blocking=True)
+            targets = targets.to(dev, non_blocking=True)
+            if mixup_fn is not None:
+                samples, targets = mixup_fn(samples, targets)
+            if bce:
+                targets = targets.gt(0.0).type(targets.dtype)
+            if graphed is not None:
+                # (an enabled optim.NativeScaler skips a non-finite step on the device by itself: the abort can wait for check_every)
+                lv = graphed(samples, targets)
+                finite = torch.isfinite(lv)
+                loss_sum += torch.where(finite, lv, torch.zeros_like(lv))
+                bad += (~finite).to(bad.dtype)
+                n += 1
+                if check_every > 1 and n % check_every == 0 and int(bad):
+                    print(f"Loss is non-finite in {int(bad)} of {n} steps, stopping training")
+                    raise SystemExit(1)
+                continue
+            def forward_loss():
+                with torch.autocast(device_type=dev.type, dtype=torch.float16, enabled=autocast and dev.type == "cuda"):
+                    outputs = model(samples)
+                    loss = criterion(samples, outputs, targets) if with_inputs else criterion(outputs, targets)
+                    if aux_loss_weight:
+                        auxes = [a for a in (m.gate.get_loss() for m in moes) if a is not None]
+                        if auxes:     # one stack + sum instead of two tiny kernels (and two backward nodes) per layer
+                            loss = loss + aux_loss_weight * torch.stack([a.reshape(()) for a in auxes]).sum()
+                return loss
+            if ep_spec:
+                # speculative static exchange: the forward's overflow report is read BEFORE the backward (one host sync per step where
+                # the counted exchange has one per layer); a forward whose routing did not fit is dropped -- by every rank together -- and
+                # run again on the counted exchange, so no gradient ever comes from a step that lost rows
+                loss, again = _ep.run_guarded(forward_loss, flush=True)
+                ep_repeats += int(again)
+            else:
+                loss = forward_loss()
+            lv = loss.detach().float()
             finite = torch.isfinite(lv)
+            if every_step and not bool(finite):           # the reference's order: abort before the step and the EMA update
+                print(f"Loss is {float(lv)}, stopping training")
+                raise SystemExit(1)
+            optimizer.zero_grad()
+            is_second_order = hasattr(optimizer, "is_second_order") and optimizer.is_second_order
+            loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=is_second_order)
+            if model_ema is not None:
+                model_ema.update(model)
             loss_sum += torch.where(finite, lv, torch.zeros_like(lv))
             bad += (~finite).to(bad.dtype)
             n += 1
             if check_every > 1 and n % check_every == 0 and int(bad):
                 print(f"Loss is non-finite in {int(bad)} of {n} steps, stopping training")
                 raise SystemExit(1)
-            continue
-        with torch.autocast(device_type=dev.type, dtype=torch.float16, enabled=autocast and dev.type == "cuda"):
-            outputs = model(samples)
-            loss = criterion(samples, outputs, targets) if with_inputs else criterion(outputs, targets)
-            if aux_loss_weight:
-                auxes = [a for a in (m.gate.get_loss() for m in moes) if a is not None]
-                if auxes:     # one stack + sum instead of two tiny kernels (and two backward nodes) per layer
-                    loss = loss + aux_loss_weight * torch.stack([a.reshape(()) for a in auxes]).sum()
-        lv = loss.detach().float()
-        finite = torch.isfinite(lv)
-        if every_step and not bool(finite):           # the reference's order: abort before the step and the EMA update
-            print(f"Loss is {float(lv)}, stopping training")
-            raise SystemExit(1)
-        optimizer.zero_grad()
-        is_second_order = hasattr(optimizer, "is_second_order") and optimizer.is_second_order
-        loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=model.parameters(), create_graph=is_second_order)
-        if model_ema is not None:
-            model_ema.update(model)
-        loss_sum += torch.where(finite, lv, torch.zeros_like(lv))
-        bad += (~finite).to(bad.dtype)
-        n += 1
-        if check_every > 1 and n % check_every == 0 and int(bad):
-            print(f"Loss is non-finite in {int(bad)} of {n} steps, stopping training")
-            raise SystemExit(1)
+    finally:
+        if ep_spec:      # outside this harness nobody repeats a forward that lost rows: training forwards go back to the counted exchange
+            _ep.set_speculative(model, alpha, train=False)
     if graphed is not None:
         graphed.finish()
     if gate_delta is not None:
@@ -446,5 +471,5 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
         print(f"Loss is non-finite in {n_bad} of {n} steps, stopping training")
         raise SystemExit(1)
     mean = float(loss_sum) / max(n, 1)
-    return {"loss": mean, "steps": n, "lr": optimizer.param_groups[0]["lr"],
+    return {"loss": mean, "steps": n, "lr": optimizer.param_groups[0]["lr"], "ep_repeated_steps": ep_repeats,
             "hip_graph_steps": 0 if graphed is None else sum(max(0, c - GraphedTrainStep.WARM) for c in graphed.seen.values())}

@@ -363,13 +363,16 @@ def set_static_tokens(model: torch.nn.Module, rows: int, unit: int = 1) -> int:
 # repeated on the dynamic path (run_guarded) -- so the results are those of the dynamic path: bit for bit when nothing overflows
 # (same rows, same groups, same kernels), and after the repeat when something did.  It is OPT-IN per model (set_speculative):
 # somebody has to repeat an overflowing step, and only a harness that owns the step can (engine.evaluate, bench.py).
-def set_speculative(model: torch.nn.Module, alpha: Optional[float]) -> int:
+def set_speculative(model: torch.nn.Module, alpha: Optional[float], train: bool = False) -> int:
     """Switch the speculative static exchange on (alpha >= 1: slot = ceil(alpha * rows * k / E)) or off (None) for every
-    expert-parallel MoE module of ``model`` whose gate has no capacity.  Same value on every rank.  Returns the modules touched."""
+    expert-parallel MoE module of ``model`` whose gate has no capacity.  Same value on every rank.  ``train``: also for forwards
+    WITH autograd (engine.train_one_epoch: it reads the forward's overflow report before the backward and repeats a forward that
+    lost rows); without it a training forward keeps the counted exchange.  Returns the modules touched."""
     n = 0
     for m in _ep_modules(model):
         if m.gate.capacity(1 << 20) < 0:
             m.ep_speculative = None if alpha is None else max(1.0, float(alpha))
+            m.ep_speculative_train = bool(train) and alpha is not None
             n += 1
     return n
 
@@ -404,7 +407,7 @@ def static_kind(mod, cd) -> Optional[str]:
         return None
     if g.capacity(1 << 20) >= 0:
         return "capacity"
-    if getattr(mod, "ep_speculative", None) is not None and not mod.training:
+    if getattr(mod, "ep_speculative", None) is not None and (not mod.training or getattr(mod, "ep_speculative_train", False)):
         return "speculative"
     return None
 

@@ -27,13 +27,20 @@ def _port():
 def _count_readbacks(ep):
     """Patch the counted exchange's host sync so that the test can tell which exchange ran."""
     calls = {"n": 0}
-    real = ep.PendingCounts.finish_rows
+    real, real_t = ep.PendingCounts.finish_rows, ep.PendingCounts.finish     # (the no-grad forward's read-back, the training path's)
 
     def counting(self):
         calls["n"] += 1
         return real(self)
-    ep.PendingCounts.finish_rows = counting
-    return calls, lambda: setattr(ep.PendingCounts, "finish_rows", real)
+
+    def counting_t(self):
+        calls["n"] += 1
+        return real_t(self)
+    ep.PendingCounts.finish_rows, ep.PendingCounts.finish = counting, counting_t
+
+    def restore():
+        ep.PendingCounts.finish_rows, ep.PendingCounts.finish = real, real_t
+    return calls, restore
 
 
 def _one_rank_worker(q):
@@ -250,6 +257,73 @@ def test_static_expert_parallel_forward_captured_in_a_hip_graph_replays_bit_exac
     assert (not rep3) or recaptures >= 1, res             # an overflow re-sized the slots: the next call captured again
     g_on, e_on, loss_g, loss_e, a_g, a_e, _, _ = res["evaluate"]
     assert g_on and not e_on and loss_g == loss_e and a_g == a_e, res
+
+
+def _train_worker(q):
+    """engine.train_one_epoch under expert parallelism with the reference's capacity-less gates on the SPECULATIVE static exchange."""
+    import torch.distributed as dist
+    from slim_switch_moe_vit_amd import ep
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_port()}", rank=0, world_size=1, device_id=torch.device(DEV))
+    res = {}
+    try:
+        calls, restore = _count_readbacks(ep)
+        loader = []
+        for s in range(3):
+            g = torch.Generator().manual_seed(200 + s)
+            loader.append((torch.randn(8, 3, 224, 224, generator=g), torch.randint(0, 10, (8,), generator=g)))
+        for name in ("moe_tiny_patch16_224_expert8", "resmoe_tiny_patch16_224_expert8"):
+            finals = {}
+            for tag, alpha in (("counted", None), ("roomy", 3.0), ("tight", 1.0)):
+                torch.manual_seed(0)
+                kw = dict(starting_threshold=0.5, target_threshold=0.5) if name.startswith("resmoe") else {}
+                model = _init(sm.create_model(name, num_classes=10, depth=2, drop_path_rate=0.0, **kw), 41)
+                if name.startswith("resmoe"):
+                    with torch.no_grad():
+                        for blk in model.blocks:
+                            for gt in (blk.dense_gate, blk.moe_gate):
+                                gt.head[1].weight.normal_(0, 0.5, generator=torch.Generator().manual_seed(3))
+                model = model.to(DEV)
+                for blk in model.blocks:
+                    blk.mlp.force_ep = True
+                opt = sm.AdamW(model.parameters(), lr=1e-3, weight_decay=0.05)
+                calls["n"] = 0
+                st = sm.train_one_epoch(model, torch.nn.CrossEntropyLoss(), loader, opt, DEV, 0, sm.NativeScaler(), max_norm=1.0,
+                                        ep_speculative=alpha)
+                torch.cuda.synchronize()
+                finals[tag] = ({n: p.detach().clone() for n, p in model.named_parameters()}, st["ep_repeated_steps"], calls["n"],
+                               st["loss"], any(getattr(b.mlp, "ep_speculative_train", False) for b in model.blocks))
+            ref = finals["counted"][0]
+            res[name] = {tag: (all(torch.equal(ref[n], v[0][n]) for n in ref), v[1], v[2], v[3], v[4]) for tag, v in finals.items()}
+        restore()
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_harness_on_the_speculative_static_exchange_one_rank_group():
+    """NaiveGate models (the reference's) under expert parallelism in engine.train_one_epoch: with ``ep_speculative`` the training forward
+    takes the static exchange -- no count read-back per layer --, its overflow report is read before the backward, and a forward whose
+    routing did not fit is repeated on the counted exchange.  Either way the parameters after three AdamW steps are those of the counted
+    exchange, bit for bit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_train_worker, args=(q,))
+    p.start()
+    _join_or_kill([p], 400)
+    res = q.get(timeout=10)
+    print(res)
+    for name, r in res.items():
+        layers = 2
+        same, rep, reads, loss, left_on = r["counted"]
+        assert same and rep == 0 and reads == 3 * layers and not left_on, (name, r)
+        same, rep, reads, loss_r, left_on = r["roomy"]
+        # no host round trip at all -- but for the residual model's first step: the tokens its skip gates masked are zero rows, which the
+        # gate bias sends to the SAME two experts (half of the batch: more than 3 x the balanced share); the slots follow after one repeat
+        assert same and rep <= (1 if name.startswith("resmoe") else 0) and reads == rep * layers and loss_r == loss and not left_on, (name, r)
+        same, rep, reads, loss_t, left_on = r["tight"]
+        assert same and rep >= 1 and reads == rep * layers and loss_t == loss and not left_on, (name, r)
 
 
 def _ranks_worker(rank, world, port, q):
