@@ -611,7 +611,7 @@ def check_static_overflow(flush: bool = False) -> None:
             if st.kind == "speculative":          # the next _slot_state call re-makes the table for the new row count; keep what
                 st.obs = [0] * len(st.obs)        # was learnt out of it (the observed groups belong to a dropped batch)
         elif st.kind == "speculative":
-            st.headroom = min(2.0, st.headroom * 1.05) if st.n_obs > 1 else st.headroom
+            st.headroom = min(2.0, st.headroom * 1.10) if st.n_obs > 1 else st.headroom
             st._install([max(c, f) for c, f in zip(st.table.caps, st.fitted_caps())])
     raise StaticExchangeOverflow(
         f"expert-parallel static exchange: {report}; the outputs since then are void.  {len(overflowed)} module(s) re-sized: "

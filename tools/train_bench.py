@@ -73,9 +73,12 @@ else:
                 if "_gate.head.1.weight" in n:
                     p.copy_(torch.randn(p.shape, generator=g) * 0.05)
         model = model.to(dev)
+    elif os.environ.get("TRAIN_BENCH_GATE") == "naive":     # the reference's capacity-less gate (speculative slots under TRAIN_BENCH_EP=static)
+        model = sm.create_model(name, num_classes=1000).to(dev)
     else:
         model = sm.create_model(name, num_classes=1000, gate="switch", capacity_factor=1.0).to(dev)
     ep_mode = os.environ.get("TRAIN_BENCH_EP")
+    speculative = False
     if ep_mode:
         import contextlib
         import torch.distributed as dist
@@ -86,6 +89,8 @@ else:
             if isinstance(m, sm.FMoETransformerMLP):
                 m.force_ep = True
         ep.set_static_tokens(model, images * 197, 197)
+        if ep_mode == "static":
+            speculative = ep.set_speculative(model, 1.25, train=True) > 0
     model.train()
     opt = smo.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05)
     scaler = smo.NativeScaler()
@@ -94,13 +99,23 @@ else:
     y = torch.randint(0, 1000, (images,), generator=g).to(dev)
     moes = [m for m in model.modules() if isinstance(m, sm.FMoETransformerMLP)]
 
-    def train_step():
+    repeats = [0]
+
+    def forward_loss():
         with torch.autocast("cuda", dtype=torch.float16):
             out = model(x)
             loss = crit(out, y)
             auxes = [a for a in (m.gate.get_loss() for m in moes) if a is not None]
             if auxes:
                 loss = loss + 0.01 * torch.stack([a.reshape(()) for a in auxes]).sum()
+        return loss
+
+    def train_step():
+        if speculative:      # what engine.train_one_epoch does: the overflow report is read before the backward
+            loss, again = ep.run_guarded(forward_loss, flush=True)
+            repeats[0] += int(again)
+        else:
+            loss = forward_loss()
         opt.zero_grad()
         scaler(loss, opt, clip_grad=1.0, parameters=model.parameters())
 
@@ -116,7 +131,8 @@ else:
             t = timed(train_step, iters)
             ep.check_static_overflow(flush=True)
         print(f"{name} train step through the expert-parallel path ({ep_mode} exchange, one-rank group), batch {images}: {t:.2f} ms = "
-              f"{images / t * 1e3:.0f} images/s; count exchanges with a host read-back: {calls['n'] / (iters + 3):.1f} per step", flush=True)
+              f"{images / t * 1e3:.0f} images/s; count exchanges with a host read-back: {calls['n'] / (iters + 3):.1f} per step"
+              + (f"; speculative slots, {repeats[0]} forwards repeated in {iters + 3} steps" if speculative else ""), flush=True)
         torch.cuda.synchronize()
         dist.destroy_process_group()
         sys.exit(0)
