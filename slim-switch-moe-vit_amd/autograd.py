@@ -124,15 +124,16 @@ class _AllToAll(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rows, send_rows: List[int], recv_rows: List[int], group):
-        from .ep import all_to_all_rows
+        from .ep import all_to_all_rows, inline_possible
         ctx.send_rows, ctx.recv_rows, ctx.group, ctx.n_in = send_rows, recv_rows, group, rows.shape[0]
-        out, _ = all_to_all_rows(rows.contiguous(), send_rows, recv_rows, group)
+        # (nothing runs beside an exchange of the training path: on the compute stream itself unless SLIMMOE_EP_INLINE=0)
+        out, _ = all_to_all_rows(rows.contiguous(), send_rows, recv_rows, group, inline=inline_possible(None, training=True))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        from .ep import all_to_all_rows
-        back, _ = all_to_all_rows(dout.contiguous(), ctx.recv_rows, ctx.send_rows, ctx.group)
+        from .ep import all_to_all_rows, inline_possible
+        back, _ = all_to_all_rows(dout.contiguous(), ctx.recv_rows, ctx.send_rows, ctx.group, inline=inline_possible(None, training=True))
         if back.shape[0] < ctx.n_in:  # rows past the kept slots were never sent
             pad = torch.zeros((ctx.n_in - back.shape[0], back.shape[1]), dtype=back.dtype, device=back.device)
             back = torch.cat([back, pad], 0)

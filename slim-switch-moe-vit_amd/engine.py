@@ -222,6 +222,9 @@ class GraphedTrainStep:
     """One training step -- autocast forward, criterion (+ the gates' aux losses), ``optimizer.zero_grad``, loss scaling, backward,
     clipping, the optimizer step, the loss-scale update: engine.py:52-74 -- captured into ONE HIP graph per batch shape and replayed.
 
+    Expert-parallel models too when their gates have a capacity (BASELINE cfg 5): on the static exchange with the collectives on the
+    compute stream the step has no host round trip either (tools/train_bench.py: cfg 5's ViT-B step through the expert-parallel path
+    on a one-rank group 30.2 ms eager -> 29.0 ms replayed).  Drop this object before the process group.
     Possible because nothing in that step touches the host when it runs on this package's ``optim.AdamW`` + ``optim.NativeScaler``
     (the non-finite check, the clip coefficient, the step count and the loss scale live on the device).  What it buys: the reference's
     own model (resmoe_tiny_patch16_224_expert8, batch 128: models/resMoE.py:151-187, cmd.sh:7-13) issues ~1,060 launches per step for
@@ -249,11 +252,21 @@ class GraphedTrainStep:
         self.disabled = False
 
     @staticmethod
-    def supported(model, optimizer, loss_scaler, device, model_ema) -> bool:
+    def supported(model, optimizer, loss_scaler, device, model_ema, ep_graph: bool = False) -> bool:
+        """``ep_graph``: whether an expert-parallel model may be captured (train_one_epoch: a group of ONE rank, or hip_graph=True).
+        It can be when the step has no host round trip: every expert-parallel layer a CAPACITY gate on the static exchange (its slots
+        cannot overflow and a fixed batch shape cannot outgrow the agreed row count) with the collectives on the compute stream."""
         from .optim import NativeScaler as _OwnScaler
         dev = torch.device(device)
-        ep = any(getattr(m, "ep_active", lambda: False)() for m in model.modules() if hasattr(m, "ep_active"))
-        return (dev.type == "cuda" and not ep and model_ema is None and getattr(optimizer, "_slimmoe_refreshes_images", False)
+        mods = [m for m in model.modules() if hasattr(m, "ep_active") and m.ep_active()]
+        if mods:
+            from . import ep
+            from .fmoe import default_compute_dtype
+            if not (ep_graph and ep.inline_possible(model, training=True) and not any(m._drop_p > 0 for m in mods)
+                    and all(m.gate.capacity(1 << 20) >= 0 and ep.static_kind(m, m.compute_dtype or default_compute_dtype()) == "capacity"
+                            for m in mods)):
+                return False
+        return (dev.type == "cuda" and model_ema is None and getattr(optimizer, "_slimmoe_refreshes_images", False)
                 and isinstance(loss_scaler, _OwnScaler) and loss_scaler.enabled
                 and not getattr(optimizer, "is_second_order", False))
 
@@ -277,6 +290,9 @@ class GraphedTrainStep:
 
     def _capture(self, samples, targets):
         static_s, static_t = samples.clone(), targets.clone()
+        if any(m.ep_active() for m in self.moes):
+            from . import ep
+            ep.check_static_overflow(flush=True)          # the eager steps' reports are read here, not by the captured forward
         before = [g._total_tokens for g in self.gates]
         self.optimizer.zero_grad(set_to_none=True)        # the backward's gradients are allocated from the graph's own pool
         graph = torch.cuda.CUDAGraph()
@@ -390,11 +406,12 @@ def train_one_epoch(model: torch.nn.Module, criterion, data_loader: Iterable[Tup
         check_every = 1
     bce = bool(getattr(args, "bce_loss", False)) if args is not None else False
     loss_sum, bad, n = torch.zeros((), device=dev), torch.zeros((), device=dev), 0
+    graphed = None
+    ep_graph = hip_graph is True or _ep_world_size(model) == 1      # (captured RCCL between distinct GPUs: only on request so far)
     if hip_graph == "auto":
         import os
         hip_graph = os.environ.get("SLIMMOE_TRAIN_GRAPH", "0") == "1"
-    graphed = None
-    if hip_graph and not every_step and GraphedTrainStep.supported(model, optimizer, loss_scaler, dev, model_ema):
+    if hip_graph and not every_step and GraphedTrainStep.supported(model, optimizer, loss_scaler, dev, model_ema, ep_graph):
         graphed = GraphedTrainStep(model, criterion, optimizer, loss_scaler, max_norm, with_inputs, aux_loss_weight, autocast)
     from . import ep as _ep
     ep_spec, ep_repeats = False, 0

@@ -74,13 +74,13 @@ def exchange_inline(mod, n_chunks: int = 1) -> bool:
     return n_chunks == 1 and max(1, int(getattr(mod, "ep_rows_div", 1))) == 1
 
 
-def inline_possible(model: torch.nn.Module) -> bool:
+def inline_possible(model: torch.nn.Module, training: bool = False) -> bool:
     """exchange_inline for every layer of the model's NEXT forward, from the model's own settings (``ep_rows_div`` on the modules is
-    what the previous forward left there)."""
+    what the previous forward left there).  A training forward is never cut into micro-batches (vit._ep_pipeline_depth)."""
     mode = os.environ.get("SLIMMOE_EP_INLINE", "auto")
     if mode in ("0", "1"):
         return mode == "1"
-    return int(getattr(model, "ep_micro_batches", 1)) <= 1
+    return training or int(getattr(model, "ep_micro_batches", 1)) <= 1
 
 
 def _a2a(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None, group=None, async_op: bool = False,

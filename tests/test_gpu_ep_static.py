@@ -326,6 +326,53 @@ def test_training_harness_on_the_speculative_static_exchange_one_rank_group():
         assert same and rep >= 1 and reads == rep * layers and loss_t == loss and not left_on, (name, r)
 
 
+def _train_graph_worker(q):
+    """BASELINE cfg 5's kind of model (SwitchGate, capacity 1.0, aux loss) through the expert-parallel path: with the static exchange in
+    training and the collectives on the compute stream the WHOLE step captures into one HIP graph."""
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_port()}", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        g = torch.Generator().manual_seed(71)
+        batches = [(torch.randn(8, 3, 224, 224, generator=g), torch.randint(0, 10, (8,), generator=g)) for _ in range(9)]
+
+        def run(graph):
+            torch.manual_seed(0)
+            model = _init(sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=10, depth=2, drop_path_rate=0.0,
+                                          gate="switch", capacity_factor=1.0), 43).to(DEV)
+            for blk in model.blocks:
+                blk.mlp.force_ep = True
+                blk.mlp.gate.switch_eps = 0.0        # (the gate's training noise is a random draw: another stream position under a graph)
+            opt = sm.AdamW(model.parameters(), lr=1e-3, weight_decay=0.05)
+            scaler = sm.NativeScaler()
+            st = sm.train_one_epoch(model, torch.nn.CrossEntropyLoss(), batches, opt, DEV, 0, scaler, 1.0, aux_loss_weight=0.01,
+                                    hip_graph=graph)
+            torch.cuda.synchronize()
+            dropped = int(sum((blk.mlp.last_plan[5] < 0).sum() for blk in model.blocks))
+            return st, [p.detach().clone() for p in model.parameters()], scaler.state_dict(), dropped
+
+        s_e, p_e, sc_e, d_e = run(False)
+        s_g, p_g, sc_g, d_g = run(True)
+        q.put({"graph_steps": (s_e["hip_graph_steps"], s_g["hip_graph_steps"]), "loss": (s_e["loss"], s_g["loss"]),
+               "params_equal": all(torch.equal(a, b) for a, b in zip(p_e, p_g)), "scaler_equal": sc_e == sc_g, "dropped": (d_e, d_g)})
+    finally:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+
+
+def test_expert_parallel_training_step_on_one_hip_graph_reproduces_the_eager_harness():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_train_graph_worker, args=(q,))
+    p.start()
+    _join_or_kill([p], 400)
+    res = q.get(timeout=10)
+    print("expert-parallel training step on one HIP graph:", res)
+    assert res["graph_steps"] == (0, 6), res
+    assert res["params_equal"] and res["scaler_equal"] and res["loss"][0] == res["loss"][1], res
+
+
 def _ranks_worker(rank, world, port, q):
     """One rank of W sharing cuda:0 over gloo: the MoE operator (NaiveGate, top-2, E = 8) and the residual-MoE block."""
     import torch.distributed as dist

@@ -133,6 +133,25 @@ else:
         print(f"{name} train step through the expert-parallel path ({ep_mode} exchange, one-rank group), batch {images}: {t:.2f} ms = "
               f"{images / t * 1e3:.0f} images/s; count exchanges with a host read-back: {calls['n'] / (iters + 3):.1f} per step"
               + (f"; speculative slots, {repeats[0]} forwards repeated in {iters + 3} steps" if speculative else ""), flush=True)
+        if os.environ.get("TRAIN_BENCH_GRAPH") and ep_mode == "static" and not speculative:
+            # no host round trip left in the step and its collectives sit on the compute stream: the whole expert-parallel training
+            # step captures into one HIP graph
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    train_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            ep.check_static_overflow(flush=True)
+            gr = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(gr, capture_error_mode="relaxed"):
+                train_step()
+            tg = timed(gr.replay, iters)
+            print(f"{name} expert-parallel train step (static exchange) replayed from one HIP graph, batch {images}: {tg:.2f} ms = "
+                  f"{images / tg * 1e3:.0f} images/s (eager {t:.2f} ms)", flush=True)
+            gr = None
         torch.cuda.synchronize()
         dist.destroy_process_group()
         sys.exit(0)
