@@ -489,3 +489,32 @@ def test_exchange_inline_decision(monkeypatch):
     # slot tables carry a serial that is never re-used (a captured forward is keyed on it; id() of a freed table can come back)
     a, b = ep._SlotTable([3, 4], 0, 2, "cpu"), ep._SlotTable([3, 4], 0, 2, "cpu")
     assert b.serial > a.serial
+
+
+def test_speculative_exchange_in_training_is_opt_in_per_harness():
+    """ep.static_kind: a gate without a capacity takes the speculative static exchange in eval once ep.set_speculative switched it on, in
+    TRAINING only while a harness that repeats void forwards holds the flag (set_speculative(train=True): engine.train_one_epoch
+    sets and clears it); a capacity gate is "capacity" either way; ep.dynamic_only() switches both off."""
+    import torch
+    import slim_switch_moe_vit_amd as sm
+    from slim_switch_moe_vit_amd import ep
+
+    holder = torch.nn.Module()
+    holder.naive = sm.FMoETransformerMLP(4, 64, 128, torch.nn.GELU(), top_k=2)
+    holder.switch = sm.FMoETransformerMLP(4, 64, 128, torch.nn.GELU(), top_k=1, gate="switch", capacity_factor=1.0)
+    cd = torch.float16
+    holder.eval()
+    assert ep.static_kind(holder.naive, cd) is None and ep.static_kind(holder.switch, cd) == "capacity"
+    assert ep.set_speculative(holder, 1.5) == 1                     # only the gate without a capacity is touched
+    assert ep.static_kind(holder.naive, cd) == "speculative"
+    holder.train()
+    assert ep.static_kind(holder.naive, cd) is None and ep.static_kind(holder.switch, cd) == "capacity"
+    ep.set_speculative(holder, 1.5, train=True)
+    assert ep.static_kind(holder.naive, cd) == "speculative"
+    with ep.dynamic_only():
+        assert ep.static_kind(holder.naive, cd) is None and ep.static_kind(holder.switch, cd) is None
+    ep.set_speculative(holder, 1.5, train=False)
+    assert ep.static_kind(holder.naive, cd) is None
+    ep.set_speculative(holder, None, train=True)                    # off is off
+    holder.eval()
+    assert ep.static_kind(holder.naive, cd) is None
