@@ -259,8 +259,12 @@ def _two_rank_train_worker(rank, world, port, q, gate="naive"):
         part = load(make(E_local, world), sl)
         xg = xs[rank].to(DEV).requires_grad_(True)
         from slim_switch_moe_vit_amd import ep
-        static = ep.static_kind(part, torch.float16) == "capacity"
-        assert static == (gate == "switch")
+        if gate == "naive_spec":       # what engine.train_one_epoch switches on: speculative slots for the training forward too
+            holder = torch.nn.Module()
+            holder.mlp = part
+            ep.set_speculative(holder, 3.0, train=True)
+        kind = ep.static_kind(part, torch.float16)
+        assert kind == {"switch": "capacity", "naive_spec": "speculative", "naive": None}[gate]
         out = part(xg)
         (out * gs[rank].to(DEV)).sum().backward()
         ep.check_static_overflow(flush=True)
@@ -281,13 +285,14 @@ def _two_rank_train_worker(rank, world, port, q, gate="naive"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gate", ["naive", "switch"])
+@pytest.mark.parametrize("gate", ["naive", "switch", "naive_spec"])
 def test_two_expert_parallel_ranks_training_step_on_one_gpu(gate):
     """fwd + bwd of the MoE operator across TWO expert-parallel ranks (two processes on one GPU, gloo transport):
     outputs, dx and the router gradient of every rank match the single-rank operator on that rank's tokens, and each
     rank's expert weight / bias gradients are the single-rank gradients (summed over both ranks' tokens) of the
     experts it owns.  "naive": top-2 NaiveGate on the counted exchange; "switch": cfg 5's capacity gate on the static exchange
-    (fixed slots, counts in-band, ragged ranks: 700 / 433 rows against slots agreed for the larger one)."""
+    (fixed slots, counts in-band, ragged ranks: 700 / 433 rows against slots agreed for the larger one); "naive_spec": the top-2
+    NaiveGate on speculative slots (roomy: nothing overflows, which the flushed watch confirms on both ranks)."""
     import socket
     import torch.multiprocessing as mp
 
