@@ -518,3 +518,48 @@ def test_speculative_exchange_in_training_is_opt_in_per_harness():
     ep.set_speculative(holder, None, train=True)                    # off is off
     holder.eval()
     assert ep.static_kind(holder.naive, cd) is None
+
+
+def test_graph_harnesses_decide_capturability_of_expert_parallel_models_from_shared_settings(monkeypatch):
+    """engine.GraphedForward.supported / GraphedTrainStep.supported under expert parallelism (pure host logic): the forward captures
+    when every expert-parallel layer is on a static exchange AND the exchanges can sit on the compute stream (one micro-batch,
+    SLIMMOE_EP_INLINE not 0) AND the caller allows it (ep_graph: a group of one rank, or hip_graph=True); the training step only with
+    capacity gates (speculative slots need the host once per step)."""
+    import torch
+    import slim_switch_moe_vit_amd as sm
+    from slim_switch_moe_vit_amd import ep
+
+    monkeypatch.delenv("SLIMMOE_EP_INLINE", raising=False)
+
+    def model(gate):
+        kw = dict(gate="switch", capacity_factor=1.0) if gate == "switch" else {}
+        m = sm.create_model("moe_tiny_patch16_224_expert4_top1", num_classes=10, depth=1, **kw)
+        for blk in m.blocks:
+            blk.mlp.force_ep = True
+        m.ep_micro_batches = 1
+        return m.eval()
+
+    naive, switch = model("naive"), model("switch")
+    assert not sm.GraphedForward.supported(naive, "cuda")             # counted exchange: a host round trip per layer
+    ep.set_speculative(naive, 1.5)
+    assert sm.GraphedForward.supported(naive, "cuda") and sm.GraphedForward.supported(switch, "cuda")
+    assert not sm.GraphedForward.supported(naive, "cuda", ep_graph=False)
+    naive.ep_micro_batches = 2                                        # pipelined: the exchanges stay on RCCL's stream
+    assert not sm.GraphedForward.supported(naive, "cuda")
+    naive.ep_micro_batches = 1
+    monkeypatch.setenv("SLIMMOE_EP_INLINE", "0")
+    assert not sm.GraphedForward.supported(naive, "cuda")
+    monkeypatch.delenv("SLIMMOE_EP_INLINE")
+    assert not sm.GraphedForward.supported(naive.train(), "cuda")     # (a training-mode model is not the eval harness' business)
+    # the training step
+    opt_n, opt_s = sm.AdamW(naive.parameters(), lr=1e-3), sm.AdamW(switch.parameters(), lr=1e-3)
+    scaler = sm.NativeScaler()
+    switch.train()
+    switch.ep_micro_batches = 2                                       # (irrelevant in training: never cut into micro-batches)
+    assert sm.GraphedTrainStep.supported(switch, opt_s, scaler, "cuda", None, ep_graph=True)
+    assert not sm.GraphedTrainStep.supported(switch, opt_s, scaler, "cuda", None)             # expert parallel: only when allowed
+    ep.set_speculative(naive, 1.5, train=True)
+    assert not sm.GraphedTrainStep.supported(naive, opt_n, scaler, "cuda", None, ep_graph=True)
+    for blk in switch.blocks:
+        blk.mlp.force_ep = False
+    assert sm.GraphedTrainStep.supported(switch, opt_s, scaler, "cuda", None)                 # one rank: as before
