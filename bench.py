@@ -279,14 +279,15 @@ def main():
                 guarded()
             fence()
             t0 = time.perf_counter()
-            for _ in range(3):
-                step()
-            fence()
             ok = True
             try:
+                for _ in range(3):
+                    step()
+                fence()
                 _ep.check_static_overflow(flush=True)
-            except _ep.StaticExchangeOverflow:
-                ok = False                      # (the same steps fitted a moment ago: cannot happen with a fixed batch)
+            except _ep.StaticExchangeOverflow:  # (raised by every rank at the same exchange; the same steps fitted a moment ago, so
+                ok = False                      #  this is not expected with a fixed batch: the cell is void, not the bench)
+                fence()
             t = torch.tensor([(time.perf_counter() - t0) / 3 if ok else 1e9], dtype=torch.float64, device=device)
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -563,7 +563,8 @@ def check_static_overflow(flush: bool = False) -> None:
     step (on every rank) works; the outputs computed since the overflowing forward are void: that rank dropped the rows that did not
     fit to keep its buffers' agreed shape.  (2) Without an overflow, a speculative module whose slots are more than SHRINK_RATIO x
     what its observed routing needs gets slots of HEADROOM x the largest group seen PER EXPERT (the first, uniform alpha-sized table
-    knows nothing of the experts' shares): the all-to-all then carries ~HEADROOM x the routed rows instead of alpha x."""
+    knows nothing of the experts' shares): the all-to-all then carries ~HEADROOM x the routed rows instead of alpha x.  Slots are cut
+    at ``flush`` calls only (step boundaries)."""
     due = []
     while _overflow_pending and (flush or len(_overflow_pending) > OVERFLOW_LAG):
         due.append(_overflow_pending.pop(0))
@@ -587,7 +588,10 @@ def check_static_overflow(flush: bool = False) -> None:
                 report = (f"the ranks brought {[r[0] for r in rows]} rows, the buffers were agreed for {st.agreed}" if over_t else
                           f"the routing put up to {g_max} rows (per expert, from one source) into slots of {list(caps)}")
     if report is None:
-        for st, div in touched.values():          # (2) cut a speculative module's slots to its routing
+        # (2) cut a speculative module's slots to its routing -- only at a step boundary (``flush``), where every micro-batch of the
+        # step has reported: the deferred check in the middle of a forward has read SOME micro-batches' matrices of a layer only, and
+        # slots fitted to one micro-batch's routing overflow under its sibling's (E = 16, three micro-batches: bench.py's grid)
+        for st, div in (touched.values() if flush else ()):
             if st.kind == "speculative" and st.n_obs >= ADAPT_MIN_OBS:
                 fit = st.fitted_caps()
                 if sum(st.table.caps) > SHRINK_RATIO * sum(fit):

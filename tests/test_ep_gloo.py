@@ -311,6 +311,23 @@ def _speculative_control_worker(rank, W, port, q):
         res["third"] = ep.run_guarded(step)
         res["fitted"] = [st.table.caps for st in sts]
         res["splits"] = (sts[1].table.in_splits, sts[1].table.out_splits, sts[1].table.rows, sts[1].table.recv_rows)
+        # micro-batch siblings share a slot state: the deferred check in the MIDDLE of a forward has read some micro-batches' matrices
+        # only and must not cut the slots to them (bench.py's grid at E = 16 with three micro-batches did: the sibling overflowed)
+        mods[1].ep_speculative = 3.0
+        st = ep._slot_state(mods[1], "speculative", agreed[1], "cpu")          # re-made: ceil(3.0 * 40 / 6) = 20 per expert
+        res["roomy_caps"] = list(st.table.caps)
+        hA = [[5, 5, 5, 5, 5, 5], zero, [4, 4, 4, 4, 4, 4]]
+        hB = [[5, 5, 5, 5, 5, 18], zero, [4, 4, 4, 4, 4, 4]]                   # the sibling's routing: fits 20, not ceil(1.12 x 5)
+        lag, ep.OVERFLOW_LAG = ep.OVERFLOW_LAG, 2
+        try:
+            for h in (hA, hA, hA, hB):
+                ep._watch_overflow(mk(h), st)
+            ep.check_static_overflow()                                         # reads the two oldest (both hA): enough "observations"
+            res["caps_mid_forward"] = list(st.table.caps)
+            ep.check_static_overflow(flush=True)                               # the step boundary: everything has reported
+            res["caps_at_boundary"] = list(st.table.caps)
+        finally:
+            ep.OVERFLOW_LAG = lag
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -345,3 +362,5 @@ def test_speculative_exchange_control_plane_resizes_every_layer_and_repeats_once
         E_local, caps = 2, res["fitted"][1]
         blocks = [sum(caps[w * E_local:(w + 1) * E_local]) + E_local for w in range(W)]
         assert res["splits"] == (blocks, [blocks[r]] * W, sum(blocks), W * blocks[r]), (r, res)
+        assert res["roomy_caps"] == [20] * 6 and res["caps_mid_forward"] == [20] * 6, (r, res)
+        assert res["caps_at_boundary"] == fit([[5, 5, 5, 5, 5, 18], [4] * 6]), (r, res)
