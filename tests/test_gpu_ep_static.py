@@ -373,6 +373,19 @@ def test_expert_parallel_training_step_on_one_hip_graph_reproduces_the_eager_har
     assert res["params_equal"] and res["scaler_equal"] and res["loss"][0] == res["loss"][1], res
 
 
+def test_harnesses_with_batches_that_outgrow_the_agreed_buffers_keep_the_counted_exchanges_numbers():
+    """tools/ep_harness_fuzz.py in a child process (it makes its own one-rank group): loaders whose batches GROW after the exchange
+    buffers were agreed (8, 16, 4, 16, 12 images) through evaluate (speculative static, eager and HIP graph) and train_one_epoch
+    (speculative) -- evaluate's metrics and the trained parameters equal the counted exchange's exactly, whatever was repeated."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ep_harness_fuzz.py")], capture_output=True, text=True, timeout=500)
+    tail = "\n".join(l for l in r.stdout.splitlines() if ":" in l and ("evaluate" in l or "train_one_epoch" in l))
+    print(tail)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def _ranks_worker(rank, world, port, q):
     """One rank of W sharing cuda:0 over gloo: the MoE operator (NaiveGate, top-2, E = 8) and the residual-MoE block."""
     import torch.distributed as dist
