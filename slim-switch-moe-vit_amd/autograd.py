@@ -222,8 +222,11 @@ class _GroupFFN(torch.autograd.Function):
             G = E
         elif gend is not None:
             # separate row ranges (static expert exchange): one product per (source rank, local expert) slot, nothing read behind its end
-            dW1 = ops.grouped_wgrad_rows(dH, rows, offsets, group_end=gend)
-            dW2 = ops.grouped_wgrad_rows(dY, A, offsets, group_end=gend)
+            # (cut into pieces at small widths exactly as the compact layout is: ops.expert_wgrad_splits / split_ranges)
+            S = ops.expert_wgrad_splits(G, dH.shape[1], rows.shape[1], ctx.rows_hint or dH.shape[0], dH.device)
+            pieces = ops.split_ranges(offsets, gend, S) if S > 1 else None
+            dW1 = ops.grouped_wgrad_rows_split(dH, rows, offsets, S, pieces, group_end=gend)
+            dW2 = ops.grouped_wgrad_rows_split(dY, A, offsets, S, pieces, group_end=gend)
             db2, db1 = (cs2 if ctx.has_b2 else None), cs1
         else:
             # (few, long groups at small widths -- DeiT-Tiny: 24 tiles -- are cut into pieces: ops.expert_wgrad_splits)

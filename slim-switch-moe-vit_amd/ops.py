@@ -1033,10 +1033,30 @@ def expert_wgrad_splits(G: int, R1: int, R2: int, rows: int, device) -> int:
     return max(1, min(16, cus // max(tiles, 1), rows // max(G, 1) // 512))
 
 
+def split_ranges(starts: torch.Tensor, ends: torch.Tensor, S: int):
+    """smoe_split_offsets' rule for SEPARATE row ranges [starts[g], ends[g]) (the slots of the static expert exchange): S pieces of whole
+    64-row chunks each, the last ones possibly empty -> (starts i32 [G * S], ends i32 [G * S]); a few [G, S]-sized device ops, no sync."""
+    cnt = (ends - starts).to(torch.int64).view(-1, 1)
+    step = ((cnt + S * 64 - 1) // (S * 64)) * 64
+    at = torch.arange(S, device=starts.device, dtype=torch.int64).view(1, S) * step
+    lo = starts.to(torch.int64).view(-1, 1)
+    s0 = lo + torch.minimum(at, cnt)
+    e0 = lo + torch.minimum(at + step, cnt)
+    return s0.reshape(-1).to(torch.int32).contiguous(), e0.reshape(-1).to(torch.int32).contiguous()
+
+
 def grouped_wgrad_rows_split(P: torch.Tensor, Q: torch.Tensor, offsets: torch.Tensor, S: int,
-                             offsets_split: Optional[torch.Tensor] = None) -> torch.Tensor:
+                             offsets_split=None, group_end: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``grouped_wgrad_rows`` with every group cut into S pieces (``offsets_split`` = split_offsets(offsets, S), reusable by the
-    layer's second weight gradient) and the partial products summed in piece order: f32 [G, R1, R2]."""
+    layer's second weight gradient) and the partial products summed in piece order: f32 [G, R1, R2].  With ``group_end`` (separate
+    row ranges) ``offsets_split`` is the pair split_ranges(offsets, group_end, S)."""
+    if group_end is not None:
+        G = group_end.numel()
+        if S <= 1:
+            return grouped_wgrad_rows(P, Q, offsets, group_end=group_end)
+        s0, e0 = offsets_split if offsets_split is not None else split_ranges(offsets, group_end, S)
+        part = grouped_wgrad_rows(P, Q, s0, group_end=e0)
+        return part.view(G, S, part.shape[1], part.shape[2]).sum(1)
     G = offsets.numel() - 1
     if S <= 1:
         return grouped_wgrad_rows(P, Q, offsets)

@@ -153,7 +153,8 @@ def test_group_colsum_many_chunks_and_empty_groups(dtype, tol):
         assert (got[e].cpu().double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
 
 
-def test_expert_parallel_training_path_on_one_gpu():
+@pytest.mark.parametrize("T", [900, 9000])
+def test_expert_parallel_training_path_on_one_gpu(T):
     """fwd + bwd through the expert-parallel code path (count exchange, all-to-all-v each way and their adjoints,
     grouped GEMMs / wgrad with the group -> expert map) on a world of one rank == the single-rank training path."""
     import socket
@@ -165,7 +166,7 @@ def test_expert_parallel_training_path_on_one_gpu():
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device(DEV))
     try:
-        T, d, h, E = 900, 128, 256, 4
+        d, h, E = 128, 256, 4      # (T = 9000: narrow weight gradients are cut into row pieces, on separate row ranges too)
         x, wg, bg, w1, b1, w2, b2, gout = _params(T, d, h, E, seed=5, skew=True)
         from slim_switch_moe_vit_amd import ep
         import contextlib
@@ -193,7 +194,9 @@ def test_expert_parallel_training_path_on_one_gpu():
         worst = max(_rel(b.cpu(), a.cpu()) for a, b in zip(grads["ep_counted"], grads["ep"]))
         print("static vs counted exchange, training step: worst rel-L2", worst,
               "bit-identical" if all(torch.equal(a, b) for a, b in zip(grads["ep_counted"], grads["ep"])) else "")
-        assert worst == 0.0      # the same rows in the same groups through the same kernels: bit-identical
+        # the same rows in the same groups through the same kernels: bit-identical -- unless the weight gradients are cut into pieces,
+        # whose number comes from the routed rows here and from the received rows there (another, equally valid summation order)
+        assert worst == 0.0 if T == 900 else worst < 1e-5
     finally:
         dist.destroy_process_group()
 
