@@ -69,7 +69,8 @@ class GraphedForward:
     @staticmethod
     def supported(model: torch.nn.Module, device, ep_graph: bool = True) -> bool:
         """``ep_graph``: whether an expert-parallel model may be captured at all (evaluate(): "auto" = a group of ONE rank only -- no
-        run between distinct GPUs exists yet; hip_graph=True asks for it on any group)."""
+        run between distinct GPUs exists yet; hip_graph=True asks for it on any group).  The model must run one micro-batch
+        (``model.ep_micro_batches = 1``; the class default, 2, keeps the exchanges on RCCL's stream for overlap)."""
         dev = torch.device(device)
         if dev.type != "cuda" or model.training:
             return False
