@@ -451,6 +451,10 @@ class _SlotTable:
 
 
 HEADROOM = float(os.environ.get("SLIMMOE_EP_HEADROOM", "1.12"))   # speculative slots after adaptation: ceil(HEADROOM x the largest group seen)
+# ... but never less than SIGMA standard deviations of a count of that size above it: a group of n rows fluctuates by ~sqrt(n) from batch
+# to batch, which is 1 % of the bench's 6,300-row groups and 6 % of the 288-row groups of cfg 4's model at 16 images (E = 32: with 768
+# slots per forward at 1.12 x EVERY fresh batch overflowed one of them; tools/ep_static_soak.py)
+SIGMA = float(os.environ.get("SLIMMOE_EP_SIGMA", "8"))
 ADAPT_MIN_OBS = 2          # exchanges observed before a module's slots are cut to what its routing needs
 SHRINK_RATIO = 1.08        # ... and only when that saves more than this factor of the buffer rows
 
@@ -472,7 +476,7 @@ class _SlotState:
 
     def fitted_caps(self):
         import math
-        return [max(1, int(math.ceil(self.headroom * o))) for o in self.obs]
+        return [max(1, int(math.ceil(max(self.headroom * o, o + SIGMA * math.sqrt(o))))) for o in self.obs]
 
 
 def _slot_state(mod, kind: str, agreed: int, device) -> "_SlotState":

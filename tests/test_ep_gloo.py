@@ -265,6 +265,7 @@ def _speculative_control_worker(rank, W, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=W)
     try:
         from slim_switch_moe_vit_amd import ep
+        ep.SIGMA = 0.0                                       # (the toy counts below test the proportional rule: HEADROOM x the largest group)
         res = {}
         mods = []
         for _ in range(3):                                   # three "layers"

@@ -563,3 +563,19 @@ def test_graph_harnesses_decide_capturability_of_expert_parallel_models_from_sha
     for blk in switch.blocks:
         blk.mlp.force_ep = False
     assert sm.GraphedTrainStep.supported(switch, opt_s, scaler, "cuda", None)                 # one rank: as before
+
+
+def test_speculative_slots_leave_room_for_the_fluctuation_of_small_groups(monkeypatch):
+    """ep._SlotState.fitted_caps: HEADROOM x the largest group seen, but at least SIGMA standard deviations of a count of that size
+    above it -- 12 % is 9.6 sigma for a 6,300-row group (the bench) and under 2 sigma for a 288-row one (cfg 4's model at 16 images)."""
+    import math
+    from slim_switch_moe_vit_amd import ep
+
+    class St(ep._SlotState):
+        def __init__(self, obs):
+            self.obs, self.headroom = obs, ep.HEADROOM
+    monkeypatch.setattr(ep, "SIGMA", 4.0)
+    caps = St([6300, 288, 0, 1]).fitted_caps()
+    assert caps == [math.ceil(1.12 * 6300), math.ceil(288 + 4 * math.sqrt(288)), 1, 5]
+    monkeypatch.setattr(ep, "SIGMA", 0.0)
+    assert St([6300, 288, 0, 1]).fitted_caps() == [math.ceil(1.12 * 6300), math.ceil(1.12 * 288), 1, 2]
