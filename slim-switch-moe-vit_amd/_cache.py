@@ -18,6 +18,9 @@ import torch
 _ALL = weakref.WeakSet()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 class StreamCache:
     def __init__(self):
         self._c = {}
@@ -33,7 +36,7 @@ class StreamCache:
             ev = sid = None
             if t.is_cuda:
                 st = torch.cuda.current_stream(t.device)
-                sid = st.cuda_stream
+                sid = _raw_stream(t.device.index) if _raw_stream is not None else st.cuda_stream
                 if not torch.cuda.is_current_stream_capturing():   # (inside a HIP-graph capture everything is on the capturing
                     ev = torch.cuda.Event()                        #  stream; an event recorded there could not be waited for outside)
                     ev.record(st)
@@ -42,8 +45,11 @@ class StreamCache:
             return t
         _, t, ev, sid = hit
         if ev is not None:
+            # (the hit path runs a dozen times per layer: the raw handle first, a Stream object only when the stream really differs)
+            if _raw_stream is not None and _raw_stream(t.device.index) == sid:
+                return t
             st = torch.cuda.current_stream(t.device)
-            if st.cuda_stream != sid:
+            if (_raw_stream(t.device.index) if _raw_stream is not None else st.cuda_stream) != sid:
                 st.wait_event(ev)
                 # the consumer's stream is not the one the caching allocator knows this tensor by: without this, a version
                 # bump that drops the entry could hand its memory to a new allocation while this stream still reads it
@@ -66,7 +72,7 @@ class StreamCache:
         ev = sid = None
         if tensor.is_cuda:
             st = torch.cuda.current_stream(tensor.device)
-            sid = st.cuda_stream
+            sid = _raw_stream(tensor.device.index) if _raw_stream is not None else st.cuda_stream
             if not torch.cuda.is_current_stream_capturing():
                 ev = torch.cuda.Event()
                 ev.record(st)

@@ -35,8 +35,16 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the current stream's handle without building a Stream object
+
+
 def _stream(t: torch.Tensor):
-    _lib.init_device(t.device.index)  # first touch of a device: all launch attributes set before any launch
+    """The HIP stream torch would launch on for ``t``'s device right now (every launch function takes it).  ~250 calls per forward:
+    torch.cuda.current_stream() costs ~4.5 us each (a Python Stream object per call), the raw getter a tenth of that."""
+    idx = t.device.index
+    _lib.init_device(idx)  # first touch of a device: all launch attributes set before any launch
+    if _raw_stream is not None:
+        return _raw_stream(idx)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -104,7 +112,7 @@ def _router_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     redo pass clears the counter words on its way out (csrc/router16_kernel.h), so no call has to launch a clearing kernel
     in front of the router -- the caller says so with WS_KEPT_ZERO.  Keyed by the stream: two compute streams never share
     counters; a captured graph replays on the tensor it captured."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
     t = _router_ws.get(key)
     if t is None or t.numel() < nbytes:
         t = _router_ws[key] = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
@@ -811,7 +819,7 @@ def _ffn_workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
     """Ticket / row-counter words of smoe_expert_ffn: allocated ZEROED once per device and stream; every launch leaves them zero
     (the last workgroup to leave clears them), so no clearing launch runs in front of the GEMMs.  Keyed by the stream: launches on
     two streams may overlap and must not share counters."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
     t = _ffn_ws.get(key)
     if t is None or t.numel() < nbytes:
         t = _ffn_ws[key] = torch.zeros(max(nbytes, 1 << 14), dtype=torch.uint8, device=dev)
